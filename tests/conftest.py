@@ -1,0 +1,88 @@
+"""pytest configuration: the ``gpu`` marker, import paths, golden-fixture loading."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+MANIFEST = _manifest()
+
+
+class Golden:
+    """Lazy access to the committed fixtures written by tests/golden/make_golden.py."""
+
+    def __init__(self):
+        self._hp = None
+        self._core = None
+
+    @property
+    def hp(self):
+        if self._hp is None:
+            self._hp = np.load(os.path.join(GOLDEN, "hotpath.npz"))
+        return self._hp
+
+    @property
+    def core(self):
+        if self._core is None:
+            self._core = np.load(os.path.join(GOLDEN, "core.npz"))
+        return self._core
+
+    def hotpath_case(self, name):
+        meta = MANIFEST["hotpath"][name]
+        samples = [self.hp["%s/s%d" % (name, i)] for i in range(meta["D"])]
+        edges = [self.hp["%s/e%d" % (name, i)] for i in range(meta["D"])]
+        w = self.hp["%s/w" % name] if meta["weighted"] else None
+        return samples, edges, w, self.hp["%s/out" % name]
+
+    def core_case(self, name, section="core"):
+        meta = MANIFEST[section][name]
+        args = [self.core["%s/a%d" % (name, i)] for i in range(meta["n_args"])]
+        kw = {}
+        for k, v in meta["kw"].items():
+            if isinstance(v, dict) and v.get("__array__"):
+                kw[k] = self.core["%s/kw_%s" % (name, k)]
+            elif isinstance(v, dict) and "__array_list__" in v:
+                kw[k] = [self.core["%s/kw_bins%d" % (name, i)] for i in range(v["__array_list__"])]
+            elif k == "axis" and isinstance(v, list):
+                kw[k] = tuple(v)
+            elif k == "range" and isinstance(v, list):
+                kw[k] = tuple(tuple(i) if isinstance(i, list) else i for i in v)
+            else:
+                kw[k] = v
+        return args, kw, self.core["%s/h" % name], meta
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return Golden()
+
+
+def assert_hist_equal(got, want, weighted):
+    """Bit-exact for integer counts; 1e-6 relative (north_star) for float64 sums/densities.
+
+    NaN positions must coincide (NaN weights poison exactly their own bin; empty density rows).
+    """
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if not weighted and want.dtype.kind in "iu":
+        assert got.dtype.kind in "iu", got.dtype
+        np.testing.assert_array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True)
