@@ -1,0 +1,130 @@
+/*
+ * xhist_amd.h — C ABI of the MI355X-native xhistogram hot path (libxhist_amd.so).
+ *
+ * The reference (xgcm/xhistogram) is pure Python and has NO FFI; its hot path sits behind plain
+ * Python calls.  This header is the boundary a maintainer would bind (ctypes) in place of the body
+ * of `_bincount_2d_vectorized` — see INTEGRATION.md for the stub.  Every entry point cites the
+ * reference lines whose work it replaces (paths relative to /root/reference).
+ *
+ * Contract of the path (xhistogram/core.py:137-194):
+ *   D sample arrays of identical logical shape [M rows, C cols], D edge arrays (sorted, length
+ *   E_d >= 1), optional weights [M, C]  ->  out[M, nb_0, ..., nb_{D-1}],  nb_d = E_d - 1.
+ *   bin k of a dimension holds  edges[k] <= x < edges[k+1];  the last bin also holds
+ *   x == edges[E-1];  NaN, x < edges[0], x > edges[E-1] drop the sample (in ANY dimension).
+ *   Unweighted -> exact int64 counts.  Weighted -> float64 sums of weights (cast to f64 first).
+ *   The first input is the slowest-varying bin axis (C order), as `ravel_multi_index` at
+ *   core.py:178-181.  Comparisons are made in float64 (XHIST_CMP_F64: every sample is converted
+ *   to double first, which is what numpy's searchsorted does for f32/int data against f64 edges)
+ *   or exactly in int64 (XHIST_CMP_I64: integer / datetime64 data against integer edges).
+ *
+ * Ownership: the caller owns every input and output buffer; the library owns plans and scratch.
+ * Threading: all entry points are thread-safe; one plan may be executed from many threads.
+ * Errors: functions return XHIST_OK (0) or a negative xhist_status; xhist_last_error() returns a
+ * thread-local description.  The library never aborts and never falls back to a CPU path: without
+ * a usable HIP device every compute call fails with XHIST_ERR_NO_DEVICE.
+ */
+#ifndef XHIST_AMD_H
+#define XHIST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XHIST_ABI_VERSION 1
+#define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
+
+typedef enum {
+  XHIST_OK = 0,
+  XHIST_ERR_INVALID = -1,     /* bad argument: null pointer, bad dtype tag, sizes < 0, D out of range */
+  XHIST_ERR_UNSUPPORTED = -2, /* legal for the reference but not for this build (documented)        */
+  XHIST_ERR_NO_DEVICE = -3,   /* no HIP device visible / device index out of range                   */
+  XHIST_ERR_HIP = -4,         /* HIP runtime error (message in xhist_last_error)                      */
+  XHIST_ERR_NOMEM = -5,       /* host or device allocation failed                                     */
+  XHIST_ERR_EDGES = -6        /* edges decrease somewhere or contain NaN (numpy: ValueError)          */
+} xhist_status;
+
+/* element type tags (numpy dtypes the reference accepts for samples / weights) */
+typedef enum {
+  XHIST_F64 = 0, XHIST_F32 = 1, XHIST_F16 = 2,
+  XHIST_I64 = 3, XHIST_I32 = 4, XHIST_I16 = 5, XHIST_I8 = 6,
+  XHIST_U64 = 7, XHIST_U32 = 8, XHIST_U16 = 9, XHIST_U8 = 10,
+  XHIST_BOOL = 11
+} xhist_dtype;
+
+typedef enum { XHIST_CMP_F64 = 0, XHIST_CMP_I64 = 1 } xhist_cmp_domain;
+typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1 } xhist_mem_kind;
+
+/* A logical [M, C] array addressed as data[r * row_stride + c * col_stride] (strides in ELEMENTS).
+ * row_stride == 0 or col_stride == 0 express numpy broadcasting without materialising it
+ * (core.py:366 broadcast_arrays + 211-229 reshape copy it in the reference). */
+typedef struct {
+  const void* data;
+  int32_t dtype; /* xhist_dtype */
+  int32_t reserved;
+  int64_t row_stride;
+  int64_t col_stride;
+} xhist_array;
+
+typedef struct xhist_plan xhist_plan; /* opaque: device-resident edge tables + launch geometry */
+
+/* ---- library / device queries ------------------------------------------------------------ */
+int xhist_abi_version(void);
+const char* xhist_last_error(void);
+int xhist_device_count(int* count);
+/* name (may be NULL) receives the gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+int xhist_device_info(int device, char* name, size_t name_cap, int* compute_units, size_t* total_mem_bytes);
+
+/* ---- plans ------------------------------------------------------------------------------- */
+/* Upload D edge arrays (HOST pointers; float64 for XHIST_CMP_F64, int64 for XHIST_CMP_I64) and
+ * build the per-dimension bucket->edge-range tables used by the branch-free digitize.
+ * Replaces the per-call edge handling of core.py:154-155, 163-174. */
+int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
+                      int cmp_domain, xhist_plan** plan);
+int xhist_plan_destroy(xhist_plan* plan);
+
+/* The fused hot path — replaces core.py:137-194 (_bincount_2d_vectorized: searchsorted 170-173,
+ * ravel_multi_index 178-181, _dispatch_bincount/_bincount_2d 73-134, trim 189-192) in ONE kernel.
+ *   samples[n_inputs], weights (NULL = unweighted): xhist_array views, all HOST or all DEVICE.
+ *   out: contiguous [n_rows, prod(nb_d)];  out_dtype XHIST_I64 (unweighted) or XHIST_F64 (weighted).
+ *   accumulate != 0: add into `out` instead of overwriting it — this is the reference's
+ *     "sum over blocks" (dask `.sum(drop_axes)`, core.py:439) fused into the kernel's flush.
+ *   stream: hipStream_t (NULL = default stream).  XHIST_MEM_DEVICE calls are asynchronous on
+ *     `stream`; XHIST_MEM_HOST calls stage through device memory and return when `out` is final.
+ */
+int xhist_plan_execute(xhist_plan* plan, const xhist_array* samples, const xhist_array* weights,
+                       int64_t n_rows, int64_t n_cols, void* out, int out_dtype, int mem_kind,
+                       int accumulate, void* stream);
+
+/* One-shot form of the two calls above with an internal plan cache keyed on (device, edges). */
+int xhist_bincount_rows(int device, int n_inputs, const xhist_array* samples,
+                        const xhist_array* weights, int64_t n_rows, int64_t n_cols,
+                        const void* const* edges, const int64_t* n_edges, int cmp_domain, void* out,
+                        int out_dtype, int mem_kind, int accumulate, void* stream);
+
+/* min / max over a logical [M, C] array, NaN-propagating like numpy's a.min()/a.max(): feeds
+ * np.histogram_bin_edges' (first_edge, last_edge) when bins is an int and range is None
+ * (core.py:383-388).  result[0] = min, result[1] = max, as float64 (HOST pointer). */
+int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result,
+                 int mem_kind, void* stream);
+
+/* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
+/* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),
+ *       "lds_copies" (0 = auto), "profile" (0 = off, R = keep the last R kernel timings) */
+int xhist_plan_set_param(xhist_plan* plan, const char* key, int64_t value);
+/* human-readable description of the last launch (kernel family, LDS bytes, copies, grid...) */
+int xhist_plan_describe(xhist_plan* plan, char* buf, size_t cap);
+/* "profile" = R > 0 keeps HIP-event pairs (recorded on the caller's stream, tightly around the
+ * histogram kernel launch(es), after the output memset) for the R most recent device executes.
+ * This call synchronises them, writes up to `cap` durations (ms, oldest first) and resets. */
+int xhist_plan_profile_read(xhist_plan* plan, float* ms, int cap, int* n_out);
+
+/* free cached plans and scratch on every device */
+int xhist_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XHIST_AMD_H */

@@ -1,0 +1,389 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the committed golden vectors
+(outputs of the reference itself) and against the CPU oracle on seeded inputs.
+
+Bar (north_star): unweighted int64 counts bit-exact; float64 weighted / density within 1e-6
+relative (tests/conftest.py::assert_hist_equal).  Run with ``pytest -m gpu`` on an MI355X.
+"""
+import numpy as np
+import pytest
+
+from conftest import MANIFEST, assert_hist_equal
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def xh():
+    from xhistogram_amd import _native, core
+
+    _native.load()
+    assert _native.device_count() >= 1, "no MI355X visible: GPU tests must not pass on a fallback"
+    assert "gfx950" in _native.device_info(0)["name"]
+    return core
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _plan_for(core, samples, edges):
+    dts = [core._np_dtype_of(s) for s in samples]
+    cmp_domain, conv, _ = core._compare_domain(dts, edges)
+    return core._get_plan(conv, cmp_domain, 0)
+
+
+def _run(core, samples, edges, w, resident, **params):
+    """hot path on host (numpy) or device-resident (torch) inputs with optional plan tuning"""
+    if resident:
+        if any(s.dtype.kind in "mM" or s.dtype in (np.uint16, np.uint32, np.uint64) for s in samples):
+            pytest.skip("dtype has no torch equivalent")
+        samples = [_dev(s) for s in samples]
+        w = None if w is None else _dev(w)
+    plan = _plan_for(core, samples, edges)
+    for k, v in params.items():
+        plan.set_param(k, v)
+    try:
+        out = core._bincount_2d_vectorized(*samples, bins=edges, weights=w)
+        desc = plan.describe() if samples[0].shape[0] * samples[0].shape[1] and plan.n_bins else ""
+    finally:
+        for k in params:
+            plan.set_param(k, 0)
+    if resident:
+        out = out.cpu().numpy()
+    return out, desc
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors (reference outputs)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+@pytest.mark.parametrize("name", sorted(MANIFEST["hotpath"]))
+def test_hotpath_golden(xh, golden, name, resident):
+    samples, edges, w, want = golden.hotpath_case(name)
+    got, _ = _run(xh, samples, edges, w, resident)
+    assert got.dtype == want.dtype
+    assert_hist_equal(got, want, weighted=w is not None)
+
+
+@pytest.mark.parametrize("mode", ["force_global", "force_generic", "lds_copies1"])
+@pytest.mark.parametrize("name", sorted(MANIFEST["hotpath"]))
+def test_hotpath_golden_all_kernel_families(xh, golden, name, mode):
+    samples, edges, w, want = golden.hotpath_case(name)
+    params = {"lds_copies": 1} if mode == "lds_copies1" else {mode: 1}
+    got, desc = _run(xh, samples, edges, w, True, **params)
+    if desc:
+        if mode == "force_global":
+            assert "hist=global" in desc, desc
+        if mode == "force_generic":
+            assert "family=generic" in desc, desc
+    assert_hist_equal(got, want, weighted=w is not None)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["core"]))
+def test_public_api_golden(xh, golden, name):
+    args, kw, want, meta = golden.core_case(name)
+    got, edges = xh.histogram(*args, **kw)
+    assert got.shape == tuple(meta["h_shape"])
+    assert str(got.dtype) == meta["h_dtype"]
+    assert_hist_equal(got, want, weighted=("weights" in kw) or kw.get("density", False))
+    for i, e in enumerate(edges):
+        np.testing.assert_array_equal(e, golden.core["%s/edges%d" % (name, i)])
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["core"]))
+def test_public_api_golden_device_resident(xh, golden, name):
+    args, kw, want, meta = golden.core_case(name)
+    targs = [_dev(a) for a in args]
+    tkw = dict(kw)
+    if "weights" in kw:
+        tkw["weights"] = _dev(kw["weights"])
+    got, edges = xh.histogram(*targs, **tkw)
+    assert isinstance(got, torch.Tensor) and got.is_cuda
+    got = got.cpu().numpy()
+    assert got.shape == tuple(meta["h_shape"])
+    assert_hist_equal(got, want, weighted=("weights" in kw) or kw.get("density", False))
+    for i, e in enumerate(edges):
+        np.testing.assert_array_equal(e, golden.core["%s/edges%d" % (name, i)])
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["dask_cases"]))
+def test_dask_cases_unchunked_equivalence(xh, golden, name):
+    """reference dask-branch outputs (blockwise + sum) == our single-launch result"""
+    args, kw, want, meta = golden.core_case(name, "dask_cases")
+    got, _ = xh.histogram(*args, **kw)
+    assert_hist_equal(got, want, weighted=("weights" in kw) or kw.get("density", False))
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded comparisons with the oracle at sizes it finishes in seconds (BASELINE configs, scaled)
+# ---------------------------------------------------------------------------------------------
+def _nonuniform_edges(rng, n):
+    e = np.sort(rng.uniform(-4, 4, n))
+    e[0], e[-1] = -4.0, 4.0
+    return e
+
+
+CONFIGS = {
+    # name: (D, n, dtype, edges builder, weighted)
+    "C1_1d_f64_100bins": (1, 1_000_000, np.float64, lambda r: [np.linspace(-4, 4, 101)], False),
+    "C2_1d_f64_100bins_weighted": (1, 4_000_003, np.float64, lambda r: [np.linspace(-4, 4, 101)], True),
+    "C3_2d_256x256_nonuniform": (2, 2_000_000, np.float64, lambda r: [_nonuniform_edges(r, 257), _nonuniform_edges(r, 257)], False),
+    "C5_2d_1024x1024_weighted": (2, 2_000_000, np.float64, lambda r: [np.linspace(-4, 4, 1025)] * 2, True),
+    "f32_50bins": (1, 3_000_001, np.float32, lambda r: [np.linspace(-4, 4, 51)], False),
+    "3d_f32_weighted": (3, 1_000_000, np.float32, lambda r: [np.linspace(-3, 3, 13), np.linspace(-3, 3, 9), np.linspace(-3, 3, 17)], True),
+}
+
+
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+def test_configs_vs_oracle(xh, cfg, resident):
+    d, n, dt, mk, weighted = CONFIGS[cfg]
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(cfg.encode()))
+    samples = [rng.standard_normal((1, n)).astype(dt) for _ in range(d)]
+    edges = mk(rng)
+    w = rng.uniform(0, 1, (1, n)) if weighted else None
+    want = onp.bincount_rows(samples, edges, w)
+    got, _ = _run(xh, samples, edges, w, resident)
+    assert_hist_equal(got, want, weighted)
+
+
+def test_c4_rows_f32(xh):
+    """C4 miniature: (T, lat*lon) f32 rows, 50 bins, reduced over the trailing axes"""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((16, 72, 144)).astype(np.float32)
+    edges = np.linspace(-4, 4, 51)
+    want, _ = onp.histogram(x, bins=edges, axis=(1, 2))
+    got, _ = xh.histogram(x, bins=edges, axis=(1, 2))
+    np.testing.assert_array_equal(got, want)
+    got_t, _ = xh.histogram(_dev(x), bins=edges, axis=(1, 2))
+    np.testing.assert_array_equal(got_t.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.float16, np.int64, np.int32, np.int16, np.int8, np.uint8, np.bool_])
+def test_sample_dtypes(xh, dt):
+    rng = np.random.default_rng(5)
+    if np.dtype(dt).kind == "f":
+        x = (rng.standard_normal((3, 5000)) * 3).astype(dt)
+    elif np.dtype(dt).kind == "b":
+        x = rng.integers(0, 2, (3, 5000)).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        x = rng.integers(max(info.min, -100), min(info.max, 100), (3, 5000)).astype(dt)
+    edges = [np.linspace(-10, 10, 41)]
+    want = onp.bincount_rows([x], edges)
+    for resident in (False, True):
+        got, _ = _run(xh, [x], edges, None, resident)
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("wdt", [np.float64, np.float32, np.int64, np.int32, np.uint8, np.bool_, np.float16])
+def test_weight_dtypes(xh, wdt):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 7000))
+    w = rng.integers(0, 5, (2, 7000)).astype(wdt)
+    edges = [np.linspace(-3, 3, 25)]
+    want = onp.bincount_rows([x], edges, w)
+    for resident in (False, True):
+        got, _ = _run(xh, [x], edges, w, resident)
+        assert_hist_equal(got, want, True)
+
+
+def test_strided_and_broadcast_views_device(xh):
+    """row-broadcast, col-broadcast, transposed and sliced device views need no copies"""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((6, 4000))
+    edges = np.linspace(-3, 3, 31)
+    w_row = rng.uniform(0, 1, (1, 4000))
+    w_col = rng.uniform(0, 1, (6, 1))
+    for w in (w_row, w_col):
+        want, _ = onp.histogram(x, bins=edges, axis=1, weights=w)
+        got, _ = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w))
+        assert_hist_equal(got.cpu().numpy(), want, True)
+        got_h, _ = xh.histogram(x, bins=edges, axis=1, weights=w)
+        assert_hist_equal(got_h, want, True)
+    # reduce over the leading axis: rows have stride 1, columns stride 4000
+    want, _ = onp.histogram(x, bins=edges, axis=0)
+    got, _ = xh.histogram(_dev(x), bins=edges, axis=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(xh.histogram(x, bins=edges, axis=0)[0], want)
+    # unaligned slice (element offset 1) falls off the vector-load family but must stay exact
+    xs = _dev(x)[:, 1:3998]
+    want, _ = onp.histogram(x[:, 1:3998], bins=edges, axis=1)
+    np.testing.assert_array_equal(xh.histogram(xs, bins=edges, axis=1)[0].cpu().numpy(), want)
+
+
+def test_bins_int_on_device_matches_numpy_edges(xh):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(100_000)
+    want, we = onp.histogram(x, bins=37)
+    got, ge = xh.histogram(_dev(x), bins=37)
+    np.testing.assert_array_equal(ge[0], we[0])
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got, ge = xh.histogram(_dev(x.astype(np.float32)), bins=12, range=(-2, 2))
+    want, we = onp.histogram(x.astype(np.float32), bins=12, range=(-2, 2))
+    np.testing.assert_array_equal(ge[0], we[0])
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    with pytest.raises(ValueError):  # numpy: autodetected range of [nan, nan] is not finite
+        xn = x.copy()
+        xn[5] = np.nan
+        xh.histogram(_dev(xn), bins=10)
+
+
+def test_block_size_never_changes_results(xh):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((9, 3000))
+    edges = np.linspace(-4, 4, 10)
+    base, _ = xh.histogram(x, bins=edges, axis=1, block_size=None)
+    for bs in (1, 2, 4, 100, "auto"):
+        np.testing.assert_array_equal(xh.histogram(x, bins=edges, axis=1, block_size=bs)[0], base)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference known-answer tests, restated (test_core.py:72-113, test_xarray.py:38-67 idea)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("block_size", [None, 1, 2])
+def test_right_edge(xh, block_size):  # test_core.py:95-113
+    data = np.ones((5, 20))
+    bins = np.array([0, 0.5, 1])
+    h, _ = xh.histogram(data, bins=bins, axis=1, block_size=block_size)
+    assert h.shape == (5, 2)
+    np.testing.assert_array_equal(h.sum(axis=0), np.histogram(data, bins=bins)[0])
+    np.testing.assert_array_equal(xh.histogram(data, bins=bins, block_size=block_size)[0], np.histogram(data, bins=bins)[0])
+
+
+@pytest.mark.parametrize("block_size", [None, 1, 2, "auto"])
+def test_weights_twice_counts_exact(xh, block_size):  # test_core.py:72-92
+    rng = np.random.default_rng(10)
+    data = rng.standard_normal((5, 20))
+    bins = np.linspace(-4, 4, 10)
+    h, _ = xh.histogram(data, bins=bins, axis=1, block_size=block_size)
+    h_w, _ = xh.histogram(data, bins=bins, axis=1, weights=2 * np.ones_like(data), block_size=block_size)
+    np.testing.assert_array_equal(2 * h, h_w)
+    h_b, _ = xh.histogram(data, bins=bins, axis=1, weights=2 * np.ones((1, 20)), block_size=block_size)
+    np.testing.assert_array_equal(2 * h, h_b)
+
+
+def test_all_ones_known_answer(xh):  # test_xarray.py:38-67 on the numpy API
+    for shape in ((7,), (4, 5), (2, 3, 4), (2, 3, 4, 5)):
+        ones = np.ones(shape)
+        h, _ = xh.histogram(ones, bins=np.array([0.0, 0.9, 1.1, 2.0]))
+        np.testing.assert_array_equal(h, [0, ones.size, 0])
+
+
+def test_vs_numpy_histogramdd_density(xh):  # test_core.py:160-228
+    rng = np.random.default_rng(12)
+    a, b, c = (rng.standard_normal((5, 20)) for _ in range(3))
+    a.ravel()[rng.choice(100, 20, replace=False)] = np.nan
+    ba, bb, bc = np.linspace(-4, 4, 10), np.linspace(-4, 4, 11), np.linspace(-4, 4, 10)
+    h, _ = xh.histogram(a, b, c, bins=[ba, bb, bc], density=True)
+    want = np.histogramdd((a.ravel(), b.ravel(), c.ravel()), bins=[ba, bb, bc], density=True)[0]
+    np.testing.assert_allclose(h, want, rtol=1e-6)
+    areas = np.einsum("i,j,k", np.diff(ba), np.diff(bb), np.diff(bc))
+    np.testing.assert_allclose(np.sum(h * areas), 1.0, rtol=1e-9)
+
+
+def test_datetime64(xh):  # test_core.py:365-382
+    data = np.array(["2000-06-0%d" % d for d in range(1, 6)], dtype="datetime64[ns]")
+    bins = np.array([np.datetime64("1999-01-01"), np.datetime64("2000-01-01"), np.datetime64("2001-01-01")])
+    h = xh.histogram(data, bins=bins)[0]
+    np.testing.assert_array_equal(h, np.histogram(data.view("i8"), bins=bins.astype("datetime64[ns]").view("i8"))[0])
+    np.testing.assert_array_equal(h, [0, 5])
+
+
+def test_errors_mirror_reference(xh):
+    x = np.zeros((3, 4))
+    with pytest.raises(ValueError):
+        xh.histogram(x, bins=None)
+    with pytest.raises(ValueError):
+        xh.histogram(x, x, bins=[np.linspace(0, 1, 3)])
+    with pytest.raises(ValueError):
+        xh.histogram(x, bins=np.array([0.0, 2.0, 1.0]))  # numpy: bins must increase monotonically
+    with pytest.raises(ValueError):
+        xh.histogram(x, bins=5, range=[(0, 1), (0, 1)])
+    with pytest.raises(TypeError):
+        xh.histogram(x, bins="auto", weights=np.ones_like(x))
+    with pytest.raises(TypeError):
+        xh.histogram(x, bins=np.linspace(0, 1, 3), weights=np.ones_like(x) * 1j)
+    with pytest.raises(AssertionError):
+        xh.histogram(x, bins=np.linspace(0, 1, 3), axis=2)
+
+
+def test_empty_inputs(xh):
+    edges = np.linspace(0, 1, 5)
+    h, _ = xh.histogram(np.zeros((3, 0)), bins=edges, axis=1)
+    np.testing.assert_array_equal(h, np.zeros((3, 4), dtype=np.int64))
+    h, _ = xh.histogram(torch.zeros((3, 0), dtype=torch.float64, device="cuda"), bins=edges, axis=1)
+    np.testing.assert_array_equal(h.cpu().numpy(), np.zeros((3, 4), dtype=np.int64))
+    h, _ = xh.histogram(np.zeros((0, 7)), bins=edges, axis=1)
+    assert h.shape == (0, 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE C2 / C3 sizes; the oracle would take minutes)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    n = 1_000_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    x.normal_(generator=g)
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    w.uniform_(generator=g)
+    yield x, w
+    del x, w
+    torch.cuda.empty_cache()
+
+
+def test_full_size_c2_properties(xh, big):
+    x, w = big
+    n = x.numel()
+    edges = np.linspace(-4, 4, 101)
+    h, _ = xh.histogram(x, bins=edges)
+    h2, _ = xh.histogram(x, bins=edges)
+    assert h.dtype == torch.int64
+    assert torch.equal(h, h2), "int64 counts must be deterministic run to run"
+    in_range = int(((x >= -4.0) & (x <= 4.0)).sum().item())
+    assert int(h.sum().item()) == in_range
+    # linearity over a split of the sample axis (what the dask sum / multi-GPU all-reduce relies on)
+    k = 400_000_123
+    ha, _ = xh.histogram(x[:k], bins=edges)
+    hb, _ = xh.histogram(x[k:], bins=edges)
+    assert torch.equal(ha + hb, h)
+    # oracle on a 2e6 prefix, exact
+    pre = x[:2_000_000].cpu().numpy().reshape(1, -1)
+    np.testing.assert_array_equal(xh.histogram(x[:2_000_000], bins=edges)[0].cpu().numpy(), onp.bincount_rows([pre], [edges])[0])
+    # weighted: total weight of in-range samples, and weights == 2 gives exactly 2 x counts
+    hw, _ = xh.histogram(x, bins=edges, weights=w)
+    total = float(w[(x >= -4.0) & (x <= 4.0)].sum().item())
+    assert abs(float(hw.sum().item()) - total) <= 1e-9 * total
+    # per-bin check against a torch f64 reference of the same op (bucketize == searchsorted right)
+    e_t = torch.as_tensor(edges, device="cuda")
+    idx = torch.bucketize(x, e_t, right=True)
+    idx = torch.where(x == edges[-1], idx - 1, idx)
+    ref_counts = torch.bincount(idx, minlength=102)[1:101]
+    assert torch.equal(ref_counts, h)
+    ref_w = torch.bincount(idx, weights=w, minlength=102)[1:101]
+    torch.testing.assert_close(hw, ref_w, rtol=1e-6, atol=0)
+    assert n == 1_000_000_000
+
+
+def test_full_size_c3_properties(xh, big):
+    x, y = big  # second array reused as the other coordinate after an affine map to [-4, 4)
+    y = y * 8.0 - 4.0
+    rng = np.random.default_rng(1)
+    ea, eb = _nonuniform_edges(rng, 257), _nonuniform_edges(rng, 257)
+    h, _ = xh.histogram(x, y, bins=[ea, eb])
+    assert h.shape == (256, 256) and h.dtype == torch.int64
+    in_range = int(((x >= -4.0) & (x <= 4.0) & (y >= -4.0) & (y <= 4.0)).sum().item())
+    assert int(h.sum().item()) == in_range
+    # marginals equal the 1-D histograms of each coordinate restricted to the other's range
+    hx, _ = xh.histogram(x[(y >= -4.0) & (y <= 4.0)], bins=ea)
+    assert torch.equal(h.sum(dim=1), hx)
+    m = 3_000_000
+    want = onp.bincount_rows([x[:m].cpu().numpy().reshape(1, -1), y[:m].cpu().numpy().reshape(1, -1)], [ea, eb])[0]
+    np.testing.assert_array_equal(xh.histogram(x[:m], y[:m], bins=[ea, eb])[0].cpu().numpy(), want)

@@ -1,0 +1,222 @@
+"""ctypes shim over libxhist_amd.so (C ABI: include/xhist_amd.h).
+
+This is the only place where Python meets the native library.  There is no fallback: if the
+shared object is missing, ``load()`` raises; if no MI355X is visible, every compute entry point
+returns XHIST_ERR_NO_DEVICE and the shim raises ``RuntimeError``.  Nothing here imports torch,
+dask or the test oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxhist_amd.so")
+
+ABI_VERSION = 1
+MAX_DIMS = 8
+
+# status codes (xhist_status)
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_EDGES = 0, -1, -2, -3, -4, -5, -6
+
+# dtype tags (xhist_dtype)
+F64, F32, F16, I64, I32, I16, I8, U64, U32, U16, U8, BOOL = range(12)
+CMP_F64, CMP_I64 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_NP_TAG = {
+    np.dtype(np.float64): F64, np.dtype(np.float32): F32, np.dtype(np.float16): F16,
+    np.dtype(np.int64): I64, np.dtype(np.int32): I32, np.dtype(np.int16): I16, np.dtype(np.int8): I8,
+    np.dtype(np.uint64): U64, np.dtype(np.uint32): U32, np.dtype(np.uint16): U16, np.dtype(np.uint8): U8,
+    np.dtype(np.bool_): BOOL,
+}
+
+
+def dtype_tag(dt):
+    """xhist_dtype tag of a numpy dtype; TypeError for what numpy's bincount/searchsorted path
+    would reject too (complex) or what this build does not carry (longdouble, object)."""
+    dt = np.dtype(dt)
+    try:
+        return _NP_TAG[dt]
+    except KeyError:
+        raise TypeError("dtype %s is not supported by the MI355X histogram path" % dt) from None
+
+
+class XhistArray(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("reserved", C.c_int32),
+        ("row_stride", C.c_int64),
+        ("col_stride", C.c_int64),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+EXPORTS = (
+    "xhist_abi_version", "xhist_last_error", "xhist_device_count", "xhist_device_info",
+    "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_bincount_rows",
+    "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
+    "xhist_shutdown",
+)
+
+
+def load():
+    """Load libxhist_amd.so once; raise (never fall back) if it is absent or of another ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libxhist_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or xhistogram_amd/csrc/build.sh. There is no CPU fallback." % LIB_PATH
+            )
+        lib = C.CDLL(LIB_PATH)
+        lib.xhist_abi_version.restype = C.c_int
+        lib.xhist_last_error.restype = C.c_char_p
+        lib.xhist_device_count.argtypes = [C.POINTER(C.c_int)]
+        lib.xhist_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        lib.xhist_plan_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_void_p)]
+        lib.xhist_plan_destroy.argtypes = [C.c_void_p]
+        lib.xhist_plan_execute.argtypes = [
+            C.c_void_p, C.POINTER(XhistArray), C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+            C.c_int, C.c_void_p,
+        ]
+        lib.xhist_bincount_rows.argtypes = [
+            C.c_int, C.c_int, C.POINTER(XhistArray), C.POINTER(XhistArray), C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
+            C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+        ]
+        lib.xhist_minmax.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int, C.c_void_p]
+        lib.xhist_plan_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.xhist_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.xhist_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        for name in EXPORTS:
+            getattr(lib, name)  # AttributeError here = header and library disagree
+        if lib.xhist_abi_version() != ABI_VERSION:
+            raise RuntimeError("libxhist_amd.so ABI %d != expected %d" % (lib.xhist_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def _raise(rc):
+    msg = (load().xhist_last_error() or b"").decode("utf-8", "replace")
+    if rc == ERR_EDGES or rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError("xhist_amd: %s (status %d)" % (msg, rc))
+
+
+def check(rc):
+    if rc != OK:
+        _raise(rc)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().xhist_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_size_t(0)
+    check(load().xhist_device_info(device, name, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}
+
+
+def require_device(device=0):
+    n = device_count()
+    if device >= n:
+        raise RuntimeError(
+            "xhistogram_amd needs an AMD MI355X (gfx950) visible to HIP: device %d requested, %d visible. "
+            "There is no CPU fallback." % (device, n)
+        )
+
+
+def make_view(ptr, tag, row_stride, col_stride):
+    return XhistArray(C.c_void_p(ptr), tag, 0, int(row_stride), int(col_stride))
+
+
+class Plan:
+    """Device-resident edge tables for one set of bin edges (xhist_plan)."""
+
+    def __init__(self, edges, cmp_domain=CMP_F64, device=0):
+        lib = load()
+        self.device = int(device)
+        self.cmp = int(cmp_domain)
+        want = np.int64 if cmp_domain == CMP_I64 else np.float64
+        self._edges = [np.ascontiguousarray(e, dtype=want) for e in edges]
+        for e in self._edges:
+            if e.ndim != 1:
+                raise ValueError("bin edges must be 1-D")
+        d = len(self._edges)
+        if not 1 <= d <= MAX_DIMS:
+            raise NotImplementedError("this build histograms 1..%d input arrays at once, got %d" % (MAX_DIMS, d))
+        ptrs = (C.c_void_p * d)(*[e.ctypes.data for e in self._edges])
+        lens = (C.c_int64 * d)(*[e.shape[0] for e in self._edges])
+        handle = C.c_void_p(0)
+        check(lib.xhist_plan_create(self.device, d, ptrs, lens, self.cmp, C.byref(handle)))
+        self._h = handle
+        self.n_dims = d
+        self.bins_shape = tuple(max(e.shape[0] - 1, 0) for e in self._edges)
+        self.n_bins = int(np.prod(self.bins_shape, dtype=np.int64))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            load().xhist_plan_destroy(h)
+
+    __del__ = close
+
+    def set_param(self, key, value):
+        check(load().xhist_plan_set_param(self._h, key.encode(), int(value)))
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        check(load().xhist_plan_describe(self._h, buf, 512))
+        return buf.value.decode()
+
+    def profile_read(self, cap=4096):
+        """durations (ms) of the histogram kernel of the executes recorded since profiling was
+        switched on with set_param("profile", R) / since the last read"""
+        buf = (C.c_float * cap)()
+        n = C.c_int(0)
+        check(load().xhist_plan_profile_read(self._h, buf, cap, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def execute(self, sample_views, weight_view, n_rows, n_cols, out_ptr, weighted, mem_kind, accumulate=False, stream=0):
+        d = self.n_dims
+        if len(sample_views) != d:
+            raise ValueError("plan was built for %d inputs, got %d" % (d, len(sample_views)))
+        arr = (XhistArray * d)(*sample_views)
+        w = C.byref(weight_view) if weight_view is not None else None
+        check(
+            load().xhist_plan_execute(
+                self._h, arr, w, int(n_rows), int(n_cols), C.c_void_p(out_ptr), F64 if weighted else I64, int(mem_kind),
+                1 if accumulate else 0, C.c_void_p(stream or 0),
+            )
+        )
+
+
+def minmax(view, n_rows, n_cols, mem_kind, device=0, stream=0):
+    out = (C.c_double * 2)()
+    check(load().xhist_minmax(int(device), C.byref(view), int(n_rows), int(n_cols), out, int(mem_kind), C.c_void_p(stream or 0)))
+    return out[0], out[1]
+
+
+def shutdown():
+    if _lib is not None:
+        _lib.xhist_shutdown()

@@ -1,0 +1,517 @@
+"""Numpy-style API of the MI355X-native xhistogram hot path.
+
+Drop-in for ``xhistogram.core`` (reference: /root/reference/xhistogram/core.py): ``histogram``
+keeps the reference's exact signature and semantics (core.py:250-466) and so do the two internal
+layers the reference's dask branch and xarray wrapper call, ``_bincount`` (core.py:197-247) and
+``_bincount_2d_vectorized`` (core.py:137-194).  What changes is what runs underneath:
+``_bincount_2d_vectorized`` hands strided [rows, cols] views to ``libxhist_amd.so`` and ONE fused HIP
+kernel does digitize -> joint index -> scatter-add on the GPU (see csrc/xhist_kernels.hip.h).
+
+Inputs may be numpy arrays (staged to the GPU by the library, result returned as numpy, exactly
+like the reference), ``torch`` tensors resident on an MI355X (no copies; result returned as a
+torch tensor on the same device) or, when dask is importable, dask arrays (the reference's
+blockwise + sum graph, each block computed on the GPU).  There is no CPU implementation in this
+package: without the native library and a GPU the compute call raises.
+"""
+
+from __future__ import annotations
+
+import os
+import threading
+from collections import OrderedDict
+from collections.abc import Iterable
+
+import numpy as np
+
+from . import _native
+
+# range is a keyword of histogram(), like in the reference
+_range = range
+
+__all__ = ["histogram"]
+
+
+# ---------------------------------------------------------------------------------------------
+# backends: numpy (host memory) and torch (device memory)
+# ---------------------------------------------------------------------------------------------
+def _is_torch(a):
+    return type(a).__module__.split(".")[0] == "torch" and hasattr(a, "data_ptr")
+
+
+def _is_dask(a):
+    mod = type(a).__module__.split(".")[0]
+    return mod == "dask" and hasattr(a, "chunks")
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+_TORCH_TAGS = None
+
+
+def _torch_tag(dtype):
+    global _TORCH_TAGS
+    if _TORCH_TAGS is None:
+        t = _torch()
+        m = {
+            t.float64: _native.F64, t.float32: _native.F32, t.float16: _native.F16, t.int64: _native.I64,
+            t.int32: _native.I32, t.int16: _native.I16, t.int8: _native.I8, t.uint8: _native.U8, t.bool: _native.BOOL,
+        }
+        for name, tag in (("uint16", _native.U16), ("uint32", _native.U32), ("uint64", _native.U64)):
+            if hasattr(t, name):
+                m[getattr(t, name)] = tag
+        _TORCH_TAGS = m
+    try:
+        return _TORCH_TAGS[dtype]
+    except KeyError:
+        raise TypeError("torch dtype %s is not supported by the MI355X histogram path" % dtype) from None
+
+
+_TAG_NP = {
+    _native.F64: np.float64, _native.F32: np.float32, _native.F16: np.float16, _native.I64: np.int64,
+    _native.I32: np.int32, _native.I16: np.int16, _native.I8: np.int8, _native.U64: np.uint64,
+    _native.U32: np.uint32, _native.U16: np.uint16, _native.U8: np.uint8, _native.BOOL: np.bool_,
+}
+
+
+def default_device():
+    """GPU used for host (numpy) inputs: $XHIST_AMD_DEVICE, else $LOCAL_RANK, else 0."""
+    for key in ("XHIST_AMD_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def _np_dtype_of(a):
+    """numpy dtype describing the element type of a numpy array or torch tensor."""
+    if _is_torch(a):
+        return np.dtype(_TAG_NP[_torch_tag(a.dtype)])
+    return a.dtype
+
+
+# ---------------------------------------------------------------------------------------------
+# plan cache (edge tables live on the GPU; building one costs a launch + a sync)
+# ---------------------------------------------------------------------------------------------
+_plans = OrderedDict()
+_plans_lock = threading.Lock()
+_PLAN_CACHE = 32
+
+
+def _get_plan(edges, cmp_domain, device):
+    key = (device, cmp_domain) + tuple((e.dtype.str, e.tobytes()) for e in edges)
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is not None:
+            _plans.move_to_end(key)
+            return plan
+    plan = _native.Plan(edges, cmp_domain, device)
+    with _plans_lock:
+        _plans[key] = plan
+        while len(_plans) > _PLAN_CACHE:
+            _plans.popitem(last=False)
+    return plan
+
+
+def _compare_domain(sample_dtypes, edges):
+    """Decide how samples are compared with edges, following numpy's promotion in searchsorted
+    (core.py:170): float64 compares unless BOTH sides are integers / datetimes, then exact int64.
+    Returns (cmp_domain, edges converted to the domain's dtype, per-input 'view as int64' flag)."""
+    doms = []
+    conv = []
+    for sd, e in zip(sample_dtypes, edges):
+        e = np.asarray(e)
+        if e.ndim != 1:
+            raise AssertionError("bin edges must be 1-D")  # core.py:148
+        if sd.kind in "mM" or e.dtype.kind in "mM":
+            common = np.result_type(sd, e.dtype)  # TypeError when only one side is a datetime
+            conv.append(e.astype(common).view(np.int64))
+            doms.append((_native.CMP_I64, common))
+            continue
+        if sd.kind == "c" or e.dtype.kind == "c":
+            raise TypeError("complex samples / bin edges are not supported")
+        if sd.kind not in "fiub" or e.dtype.kind not in "fiub":
+            raise TypeError("cannot histogram dtype %s against bin edges of dtype %s" % (sd, e.dtype))
+        if sd.itemsize > 8 or e.dtype.itemsize > 8:
+            raise TypeError("extended-precision floats are not supported on the GPU path")
+        common = np.result_type(sd, e.dtype)
+        if common.kind == "f":
+            conv.append(e.astype(np.float64))
+            doms.append((_native.CMP_F64, None))
+        elif common == np.dtype(np.uint64):
+            raise NotImplementedError("uint64 samples against uint64 edges need a uint64 compare domain")
+        else:
+            conv.append(e.astype(np.int64))
+            doms.append((_native.CMP_I64, None))
+    kinds = {d for d, _ in doms}
+    if len(kinds) > 1:
+        # mixed: everything goes to float64 unless that could round an int64/datetime dimension
+        for (d, common), sd, e in zip(doms, sample_dtypes, edges):
+            if d == _native.CMP_I64 and (common is not None or sd.itemsize == 8 or np.asarray(e).dtype.itemsize == 8):
+                raise NotImplementedError("mixing 64-bit integer/datetime dimensions with float dimensions")
+        conv = [np.asarray(e).astype(np.float64) for e in edges]
+        return _native.CMP_F64, conv, [None] * len(edges)
+    return doms[0][0], conv, [c for _, c in doms]
+
+
+# ---------------------------------------------------------------------------------------------
+# L1: the hot path                                                     (core.py:137-194)
+# ---------------------------------------------------------------------------------------------
+def _strided_view(a2d, backend):
+    """(pointer, dtype tag, row stride, col stride, keepalive) of a 2-D array, in elements.
+    Falls back to a contiguous copy only for layouts the C ABI does not take (negative strides;
+    host arrays with a column stride other than 0/1)."""
+    if backend == "torch":
+        rs, cs = a2d.stride()
+        if rs < 0 or cs < 0:
+            a2d = a2d.contiguous()
+            rs, cs = a2d.stride()
+        if a2d.shape[0] <= 1:
+            rs = 0 if a2d.shape[0] == 0 else rs
+        return a2d.data_ptr(), _torch_tag(a2d.dtype), rs, cs, a2d
+    if a2d.dtype.kind in "mM":
+        a2d = a2d.view(np.int64)
+    item = a2d.dtype.itemsize
+    rs, cs = (s // item for s in a2d.strides)
+    ok = rs >= 0 and cs in (0, 1) and all(s % item == 0 for s in a2d.strides) and (rs == 0 or rs >= a2d.shape[1] * cs)
+    if a2d.shape[1] <= 1 and rs >= 0:
+        ok, cs = True, 1
+    if not ok or not a2d.dtype.isnative:
+        a2d = np.ascontiguousarray(a2d, dtype=a2d.dtype.newbyteorder("="))
+        rs, cs = a2d.shape[1], 1
+    return a2d.ctypes.data, _native.dtype_tag(a2d.dtype), rs, cs, a2d
+
+
+def _bincount_2d_vectorized(*args, bins=None, weights=None, density=False, right=False, block_size=None):
+    """Histogram independently on each row of 2-D arrays — the fused GPU replacement of the
+    reference function of the same name (core.py:137-194).
+
+    ``args``: D arrays of equal shape [M, C] (numpy or torch-on-GPU, any strides); ``bins``: D 1-D
+    edge arrays; ``weights``: None or [M, C].  Returns [M, nb_0, ..., nb_{D-1}]: int64 counts
+    (unweighted) or float64 sums.  ``density`` and ``right`` are accepted and ignored, as in the
+    reference (core.py:138).  ``block_size`` (None, "auto" or a positive int) only sets how many
+    rows one kernel launch covers: the reference's row blocking (core.py:86-134) bounds numpy
+    temporaries that do not exist here, and never changes the result.
+    """
+    a0 = args[0]
+    backend = "torch" if _is_torch(a0) else "numpy"
+    for a, b in zip(args, bins):  # core.py:146-151
+        assert a.ndim == 2
+        assert np.ndim(b) == 1
+        assert tuple(a.shape) == tuple(a0.shape)
+    if weights is not None:
+        assert tuple(weights.shape) == tuple(a0.shape)
+    if len(bins) != len(args):
+        raise ValueError("one array of bin edges per input array")
+    nrows, ncols = (int(s) for s in a0.shape)
+
+    cmp_domain, edges, dt_common = _compare_domain([_np_dtype_of(a) for a in args], bins)
+    if backend == "numpy":
+        args = [a.astype(c) if c is not None and a.dtype != c else a for a, c in zip(args, dt_common)]
+        if weights is not None and weights.dtype.kind == "c":
+            raise TypeError("Cannot cast array data from complex to float64 (weights)")  # numpy bincount
+        device = default_device()
+        stream = 0
+        mem = _native.MEM_HOST
+    else:
+        torch = _torch()
+        if a0.device.type != "cuda":
+            raise RuntimeError("torch inputs must live on an MI355X (device='cuda'); got %s" % a0.device)
+        device = a0.device.index if a0.device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        mem = _native.MEM_DEVICE
+        if weights is not None and weights.dtype.is_complex:
+            raise TypeError("complex weights are not supported")
+    _native.require_device(device)
+    plan = _get_plan(edges, cmp_domain, device)
+
+    weighted = weights is not None
+    out_shape = (nrows,) + plan.bins_shape
+    if backend == "numpy":
+        out = np.zeros(out_shape, dtype=np.float64 if weighted else np.int64)
+        out_ptr = out.ctypes.data
+    else:
+        out = torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=a0.device)
+        out_ptr = out.data_ptr()
+    if out.size == 0 if backend == "numpy" else out.numel() == 0:
+        return out
+
+    views = [_strided_view(a, backend) for a in args]
+    wview = _strided_view(weights, backend) if weighted else None
+
+    if block_size in (None, "auto"):
+        row_blocks = [(0, nrows)]
+    else:
+        if not isinstance(block_size, (int, np.integer)) or isinstance(block_size, bool):
+            raise AssertionError("block_size must be None, 'auto' or an int")  # core.py:116
+        if block_size <= 0:
+            raise ZeroDivisionError("block_size must be positive")  # core.py:117 raises the same
+        row_blocks = [(r, min(r + int(block_size), nrows)) for r in _range(0, nrows, int(block_size))]
+
+    def shifted(view, r0):
+        ptr, tag, rs, cs, _ = view
+        return _native.make_view(ptr + r0 * rs * np.dtype(_TAG_NP[tag]).itemsize, tag, rs, cs)
+
+    row_bytes = plan.n_bins * 8
+    for r0, r1 in row_blocks:
+        plan.execute(
+            [shifted(v, r0) for v in views],
+            shifted(wview, r0) if weighted else None,
+            r1 - r0,
+            ncols,
+            out_ptr + r0 * row_bytes,
+            weighted,
+            mem,
+            accumulate=False,
+            stream=stream,
+        )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# L2: block adapter                                                    (core.py:197-247)
+# ---------------------------------------------------------------------------------------------
+def _rows_cols(a, axis, do_full_array):
+    """[M, C] arrangement of an N-D block: kept axes -> rows, reduced axes (in the order given)
+    -> cols (core.py:211-227).  A view whenever the strides allow it — broadcast (stride-0)
+    inputs and trailing reduced axes are NOT materialised, unlike the reference's reshape."""
+    if _is_torch(a):
+        if do_full_array:
+            return a.reshape(1, -1)
+        moved = a.movedim(tuple(axis), tuple(_range(-len(axis), 0)))
+        keep = moved.shape[: moved.ndim - len(axis)]
+        m = 1
+        for k in keep:
+            m *= int(k)
+        return moved.reshape(m, -1)
+    if do_full_array:
+        moved, m = a, 1
+    else:
+        moved = np.moveaxis(a, axis, tuple(_range(-len(axis), 0)))
+        m = int(np.prod(moved.shape[: moved.ndim - len(axis)], dtype=np.int64))
+    c = (a.size // m) if m else 0
+    v = moved.view()
+    try:
+        v.shape = (m, c)  # succeeds only when no copy is needed
+        return v
+    except AttributeError:
+        return moved.reshape(m, c)
+
+
+def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
+    """Block adapter with the reference's contract (core.py:197-247): N-D block(s) in, array of
+    shape kept-axes (1 for each reduced axis) + bin dims out.  Called directly for numpy/torch
+    inputs and once per block by the dask branch (core.py:429-437)."""
+    a0 = all_arrays[0]
+    ndim = a0.ndim
+    do_full_array = (axis is None) or (set(axis) == set(_range(ndim)))
+    if do_full_array:
+        kept_axes_shape = (1,) * ndim
+    else:
+        kept_axes_shape = tuple(int(a0.shape[i]) if i not in axis else 1 for i in _range(ndim))
+
+    blocks = [_rows_cols(a, axis, do_full_array) for a in all_arrays]
+    weights_block = blocks.pop() if weights else None
+
+    counts = _bincount_2d_vectorized(*blocks, bins=bins, weights=weights_block, density=density, block_size=block_size)
+    return counts.reshape(kept_axes_shape + tuple(counts.shape[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# L3: public API                                                       (core.py:250-466)
+# ---------------------------------------------------------------------------------------------
+def _ensure_correctly_formatted_bins(bins, N_expected):
+    """core.py:37-48."""
+    if bins is None:
+        raise ValueError("bins must be provided")
+    if isinstance(bins, (int, str, np.ndarray)):
+        bins = N_expected * [bins]
+    if len(bins) == N_expected:
+        return bins
+    raise ValueError("The number of bin definitions doesn't match the number of args")
+
+
+def _ensure_correctly_formatted_range(range_, N_expected):
+    """core.py:51-70."""
+    if range_ is None:
+        return N_expected * [range_]
+    nested = all(isinstance(i, Iterable) for i in range_)
+    if (len(range_) == 2) and not nested:
+        return N_expected * [range_]
+    if N_expected == len(range_):
+        if all(len(x) == 2 for x in range_):
+            return range_
+        raise ValueError(
+            "range should be provided as (lower_range, upper_range). In the "
+            "case of multiple args, range should be a list of such tuples"
+        )
+    raise ValueError("The number of ranges doesn't match the number of args")
+
+
+def _device_bin_edges(a, b, r, has_weights):
+    """np.histogram_bin_edges (core.py:383-388) for a GPU-resident array without moving it:
+    explicit edges are validated by numpy; an integer ``bins`` needs only the data's min/max
+    (reduced on the GPU, NaN-propagating like numpy) and its dtype; string estimators need the
+    data itself and take the slow path through host memory."""
+    proto_dtype = _np_dtype_of(a)
+    if isinstance(b, str):
+        if has_weights:
+            raise TypeError("Automated estimation of the number of bins is not supported for weighted data")
+        return np.histogram_bin_edges(a.detach().cpu().numpy(), bins=b, range=r)
+    if np.ndim(b) == 0 and r is None:
+        if a.numel() == 0:
+            return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=None)
+        flat = a.reshape(1, -1)
+        ptr, tag, rs, cs, keep = _strided_view(flat, "torch")
+        torch = _torch()
+        dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
+        lo, hi = _native.minmax(
+            _native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev, torch.cuda.current_stream(dev).cuda_stream
+        )
+        return np.histogram_bin_edges(np.array([lo, hi]).astype(proto_dtype), bins=b, range=None)
+    return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=r)
+
+
+def _density(counts, bins, n_inputs):
+    """core.py:444-462.  bin areas are the outer product of the bin widths; the reference's
+    ``np.prod(np.ix_(...))`` for three or more inputs (core.py:454) fails on numpy >= 1.24, the
+    outer product is what it was meant to compute (and what np.histogramdd does)."""
+    widths = [np.diff(b) for b in bins]
+    areas = widths[0]
+    for w in widths[1:]:
+        areas = np.multiply.outer(areas, w)
+    bin_axes = tuple(_range(-n_inputs, 0))
+    if _is_torch(counts):
+        torch = _torch()
+        areas_t = torch.as_tensor(np.asarray(areas, dtype=np.float64), device=counts.device)
+        sums = counts.sum(dim=bin_axes, keepdim=True)
+        return counts / areas_t / sums
+    if _is_dask(counts):
+        sums = counts.sum(axis=bin_axes)
+        return counts / areas / sums.reshape(sums.shape + n_inputs * (1,))
+    sums = counts.sum(axis=bin_axes)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return counts / areas / np.reshape(sums, sums.shape + n_inputs * (1,))
+
+
+def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto"):
+    """Histogram applied along specified axis / axes, computed on an MI355X.
+
+    Same signature, argument meaning, return value and error behaviour as
+    ``xhistogram.core.histogram`` (core.py:250-466):
+
+    args : array_like
+        Input data; N arguments give an N-dimensional histogram.  numpy arrays, GPU-resident
+        torch tensors or dask arrays; all broadcast against each other.
+    bins : int, str, array, or a list with one of those per argument
+        Number of bins, a ``numpy.histogram_bin_edges`` estimator name, or the bin edges.  All
+        but the last bin are half-open ``[left, right)``; the last bin includes both edges.
+        With dask inputs, bins must be arrays of edges (TypeError otherwise).
+    range : (float, float) or a list of such pairs, optional
+        Outer edges for integer / string ``bins``; default ``(arg.min(), arg.max())``.
+    axis : None, int or tuple of ints
+        Axes to histogram over; default all (flattened).
+    weights : array_like, optional
+        Weights broadcastable to the data; each sample contributes its weight.  A NaN weight
+        turns its own bin into NaN.
+    density : bool
+        Normalise so that the integral over the range is 1 (per kept row).
+    block_size : int or 'auto'
+        Number of rows (non-histogram positions) handled per kernel launch; results never
+        depend on it.  (The reference's 'auto' heuristic divides by zero above 10^7 samples per
+        row, core.py:114-117; here 'auto' and None mean one launch.)
+
+    Returns ``(hist, bin_edges)``: ``hist`` has the kept axes followed by one axis per argument;
+    int64 counts, or float64 when weighted / density.  numpy in -> numpy out, torch in -> torch
+    out (same device), dask in -> lazy dask array.
+    """
+    a0 = args[0]
+    ndim = a0.ndim if hasattr(a0, "ndim") else np.ndim(a0)
+    n_inputs = len(args)
+
+    is_dask_array = any(_is_dask(a) for a in list(args) + [weights])
+
+    if axis is not None:
+        axis = np.atleast_1d(axis)
+        assert axis.ndim == 1
+        axis_normed = []
+        for ax in axis:
+            ax_positive = ax if ax >= 0 else ndim + ax
+            assert ax_positive < ndim, "axis must be less than ndim"
+            axis_normed.append(ax_positive)
+        axis = [int(i) for i in axis_normed]
+
+    all_arrays = list(args)
+    has_weights = weights is not None
+    if has_weights:
+        all_arrays.append(weights)
+
+    # ---- bring every input to one backend and broadcast (core.py:366) -------------------------
+    if is_dask_array:
+        import dask.array as dsa
+
+        all_arrays = [a if _is_dask(a) else dsa.asarray(np.asarray(a)) for a in all_arrays]
+        all_arrays = list(dsa.broadcast_arrays(*all_arrays))
+        backend = "dask"
+    elif any(_is_torch(a) for a in all_arrays):
+        torch = _torch()
+        dev = next(a.device for a in all_arrays if _is_torch(a) and a.device.type == "cuda")
+        all_arrays = [a.to(dev) if _is_torch(a) else torch.as_tensor(np.asarray(a)).to(dev) for a in all_arrays]
+        all_arrays = list(torch.broadcast_tensors(*all_arrays))
+        backend = "torch"
+    else:
+        all_arrays = list(np.broadcast_arrays(*[np.asarray(a) for a in all_arrays]))
+        backend = "numpy"
+    input_axes = tuple(_range(all_arrays[0].ndim))
+
+    bins = _ensure_correctly_formatted_bins(bins, n_inputs)
+    range = _ensure_correctly_formatted_range(range, n_inputs)
+
+    # ---- bin edges (core.py:377-388) ---------------------------------------------------------
+    if is_dask_array:
+        if not all(isinstance(b, np.ndarray) for b in bins):
+            raise TypeError("When using dask arrays, bins must be provided as numpy array(s) of edges")
+    elif backend == "torch":
+        bins = [_device_bin_edges(a, b, r, has_weights) for a, b, r in zip(all_arrays, bins, range)]
+    else:
+        bins = [
+            np.histogram_bin_edges(a, bins=b, range=r, weights=all_arrays[-1] if has_weights else None)
+            for a, b, r in zip(all_arrays, bins, range)
+        ]
+    bincount_kwargs = dict(weights=has_weights, axis=axis, bins=bins, density=density, block_size=block_size)
+
+    drop_axes = tuple(axis) if axis is not None else input_axes
+
+    if backend == "dask":
+        # the reference's graph (core.py:403-439): one _bincount task per block, reduced axes kept
+        # as singleton block dims, then a sum over them
+        import dask.array as dsa
+
+        dtype = "i8" if not has_weights else all_arrays[-1].dtype
+        adjust_chunks = {i: (lambda x: 1) for i in drop_axes}
+        new_axes_start = max(input_axes) + 1
+        new_axes = {new_axes_start + i: len(b) - 1 for i, b in enumerate(bins)}
+        out_index = input_axes + tuple(new_axes)
+        blockwise_args = []
+        for arg in all_arrays:
+            blockwise_args.append(arg)
+            blockwise_args.append(input_axes)
+        bin_counts = dsa.blockwise(
+            _bincount, out_index, *blockwise_args, new_axes=new_axes, adjust_chunks=adjust_chunks,
+            meta=np.array((), dtype), **bincount_kwargs,
+        )
+        bin_counts = bin_counts.sum(drop_axes)
+    else:
+        bin_counts = _bincount(*all_arrays, **bincount_kwargs)
+        squeeze_axes = tuple(int(i) for i in drop_axes)
+        if backend == "torch":
+            keep = [s for i, s in enumerate(bin_counts.shape) if i not in squeeze_axes]
+            bin_counts = bin_counts.reshape(keep)
+        else:
+            bin_counts = bin_counts.squeeze(squeeze_axes)
+
+    h = _density(bin_counts, bins, n_inputs) if density else bin_counts
+    return h, bins

@@ -1,0 +1,787 @@
+// xhist_capi.hip — host side of libxhist_amd.so: the C ABI declared in include/xhist_amd.h.
+// Plans (device-resident edge tables), kernel-family selection, launch geometry, host staging.
+// No CPU compute path exists here on purpose: without a HIP device every compute entry point
+// fails with XHIST_ERR_NO_DEVICE.
+#include "xhist_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/xhist_amd.h"
+
+using namespace xhist;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string tl_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  tl_err = buf;
+  return code;
+}
+
+#define HIPC(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {  // set the plan's device for this call, restore the caller's on exit
+  int prev = -1;
+  bool changed = false;
+  int set(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) return fail(XHIST_ERR_NO_DEVICE, "no HIP device is usable in this process");
+    if (prev != dev) {
+      if (hipSetDevice(dev) != hipSuccess) return fail(XHIST_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
+      changed = true;
+    }
+    return XHIST_OK;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+static int n_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+static int dtype_size(int dt) {
+  switch (dt) {
+    case XHIST_F64: case XHIST_I64: case XHIST_U64: return 8;
+    case XHIST_F32: case XHIST_I32: case XHIST_U32: return 4;
+    case XHIST_F16: case XHIST_I16: case XHIST_U16: return 2;
+    case XHIST_I8: case XHIST_U8: case XHIST_BOOL: return 1;
+    default: return 0;
+  }
+}
+
+static bool dtype_is_int(int dt) { return dt >= XHIST_I64 && dt <= XHIST_BOOL; }
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct xhist_plan {
+  int device = 0;
+  int n_dims = 0;
+  int cmp = 0;
+  DimTable dim[kMaxDims];
+  uint64_t* d_tables = nullptr;
+  int32_t table_words = 0;
+  int64_t n_bins = 0;
+  int cus = 256;
+  size_t lds_max = 64 * 1024;
+  // tuning / diagnostics
+  int block_threads = 0;
+  int grid_blocks = 0;
+  int force_global = 0;
+  int force_generic = 0;
+  int lds_copies = 0;
+  int profile = 0;
+  std::mutex mu;  // guards events + desc
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;  // profile > 0: event pairs around the main kernel
+  int64_t n_recorded = 0;                                // executes recorded since the last read
+  std::string desc;
+};
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+extern "C" int xhist_abi_version(void) { return XHIST_ABI_VERSION; }
+
+extern "C" const char* xhist_last_error(void) { return tl_err.c_str(); }
+
+extern "C" int xhist_device_count(int* count) {
+  if (!count) return fail(XHIST_ERR_INVALID, "count is NULL");
+  *count = n_devices();
+  return XHIST_OK;
+}
+
+extern "C" int xhist_device_info(int device, char* name, size_t name_cap, int* compute_units, size_t* total_mem_bytes) {
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "device %d not available", device);
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, device));
+  if (name && name_cap) {
+    strncpy(name, prop.gcnArchName, name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
+                                 int cmp_domain, xhist_plan** out_plan) {
+  if (!out_plan) return fail(XHIST_ERR_INVALID, "plan out-pointer is NULL");
+  *out_plan = nullptr;
+  if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS)
+    return fail(XHIST_ERR_INVALID, "n_inputs must be in [1, %d], got %d", XHIST_MAX_DIMS, n_inputs);
+  if (!edges || !n_edges) return fail(XHIST_ERR_INVALID, "edges / n_edges is NULL");
+  if (cmp_domain != XHIST_CMP_F64 && cmp_domain != XHIST_CMP_I64)
+    return fail(XHIST_ERR_INVALID, "unknown compare domain %d", cmp_domain);
+  int64_t max_e = 0;
+  for (int d = 0; d < n_inputs; ++d) {
+    if (!edges[d]) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL", d);
+    if (n_edges[d] < 1) return fail(XHIST_ERR_INVALID, "edges[%d] needs at least one edge", d);
+    if (n_edges[d] > 65535)
+      return fail(XHIST_ERR_UNSUPPORTED, "edges[%d] has %lld edges; this build supports at most 65535 per dimension", d,
+                  (long long)n_edges[d]);
+    max_e = std::max(max_e, n_edges[d]);
+    if (cmp_domain == XHIST_CMP_F64) {
+      const double* e = static_cast<const double*>(edges[d]);
+      for (int64_t j = 0; j < n_edges[d]; ++j) {
+        if (e[j] != e[j]) return fail(XHIST_ERR_EDGES, "edges[%d] contains NaN", d);
+        if (j && e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
+      }
+    } else {
+      const int64_t* e = static_cast<const int64_t*>(edges[d]);
+      for (int64_t j = 1; j < n_edges[d]; ++j)
+        if (e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
+    }
+  }
+  if (device < 0 || device >= n_devices())
+    return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available (%d visible); this library has no CPU path", device,
+                n_devices());
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+
+  xhist_plan* p = new (std::nothrow) xhist_plan();
+  if (!p) return fail(XHIST_ERR_NOMEM, "out of host memory");
+  p->device = device;
+  p->n_dims = n_inputs;
+  p->cmp = cmp_domain;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p->lds_max = prop.sharedMemPerBlock;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > 0)
+      p->lds_max = std::max(p->lds_max, (size_t)optin);
+  }
+
+  // blob layout: [edges of dim 0..D-1 (8-byte words)] [bucket tables of dim 0..D-1 (4-byte words)]
+  int32_t edge_off = 0;
+  int64_t n_bins = 1;
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = p->dim[d];
+    memset(&t, 0, sizeof t);
+    const int E = (int)n_edges[d];
+    t.n_edges = E;
+    t.nb = E - 1;
+    t.edge_off = edge_off;
+    edge_off += E;
+    double range;
+    if (cmp_domain == XHIST_CMP_F64) {
+      const double* e = static_cast<const double*>(edges[d]);
+      t.e0_f = e[0];
+      t.eL_f = e[E - 1];
+      range = t.eL_f - t.e0_f;
+    } else {
+      const int64_t* e = static_cast<const int64_t*>(edges[d]);
+      t.e0_i = e[0];
+      t.eL_i = e[E - 1];
+      range = (double)((uint64_t)t.eL_i - (uint64_t)t.e0_i);
+    }
+    int K = std::min(4096, std::max(8, next_pow2(4 * E)));
+    double scale = (double)K / range;
+    if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
+      K = 1;  // degenerate span: one bucket holding every edge, pure binary search
+      scale = 0.0;
+    }
+    t.lut_k = K;
+    t.scale = scale;
+    if (t.nb > 0 && n_bins > (int64_t)1 << 40) {
+      delete p;
+      return fail(XHIST_ERR_UNSUPPORTED, "histogram has more than 2^40 bins");
+    }
+    n_bins *= t.nb;
+  }
+  int64_t stride = 1;
+  for (int d = n_inputs - 1; d >= 0; --d) {
+    p->dim[d].out_stride = stride;
+    stride *= p->dim[d].nb;
+  }
+  p->n_bins = n_bins;
+  int32_t off4 = 2 * edge_off;
+  for (int d = 0; d < n_inputs; ++d) {
+    p->dim[d].lut_off = off4;
+    off4 += p->dim[d].lut_k;
+  }
+  p->table_words = (off4 + 1) / 2;
+
+  std::vector<uint64_t> blob((size_t)p->table_words, 0);
+  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + p->dim[d].edge_off, edges[d], (size_t)n_edges[d] * 8);
+
+  int32_t* d_scratch = nullptr;
+  auto cleanup = [&](int rc) {
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (rc != XHIST_OK) {
+      if (p->d_tables) (void)hipFree(p->d_tables);
+      delete p;
+    }
+    return rc;
+  };
+#define HIPP(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  HIPP(hipMalloc(&p->d_tables, blob.size() * 8));
+  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
+  HIPP(hipMemcpy(p->d_tables, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+  for (int d = 0; d < n_inputs; ++d) {
+    if (cmp_domain == XHIST_CMP_F64)
+      hipLaunchKernelGGL(build_tables<0>, dim3(1), dim3(256), 0, 0, p->dim[d], p->d_tables, d_scratch);
+    else
+      hipLaunchKernelGGL(build_tables<1>, dim3(1), dim3(256), 0, 0, p->dim[d], p->d_tables, d_scratch);
+    HIPP(hipGetLastError());
+    HIPP(hipDeviceSynchronize());
+  }
+  HIPP(hipMemcpy(blob.data(), p->d_tables, blob.size() * 8, hipMemcpyDeviceToHost));
+  const uint32_t* lut4 = reinterpret_cast<const uint32_t*>(blob.data());
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = p->dim[d];
+    uint32_t maxcnt = 0;
+    uint64_t total = 0;
+    for (int b = 0; b < t.lut_k; ++b) {
+      const uint32_t cnt = lut4[t.lut_off + b] >> 16;
+      maxcnt = std::max(maxcnt, cnt);
+      total += cnt;
+    }
+    if (total != (uint64_t)t.n_edges) return cleanup(fail(XHIST_ERR_HIP, "bucket table of dim %d is inconsistent", d));
+    int steps = 0;
+    while ((1u << steps) <= maxcnt) ++steps;
+    t.steps = steps;
+  }
+#undef HIPP
+  *out_plan = p;
+  return cleanup(XHIST_OK);
+}
+
+extern "C" int xhist_plan_destroy(xhist_plan* p) {
+  if (!p) return XHIST_OK;
+  DeviceGuard g;
+  if (g.set(p->device) == XHIST_OK) {
+    if (p->d_tables) (void)hipFree(p->d_tables);
+    for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+  delete p;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return fail(XHIST_ERR_INVALID, "plan / key is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (!strcmp(key, "block_threads")) {
+    if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(XHIST_ERR_INVALID, "block_threads must be a multiple of 64 in [64, 1024]");
+    p->block_threads = (int)value;
+  } else if (!strcmp(key, "grid_blocks")) {
+    if (value < 0) return fail(XHIST_ERR_INVALID, "grid_blocks must be >= 0");
+    p->grid_blocks = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (!strcmp(key, "force_global")) {
+    p->force_global = value != 0;
+  } else if (!strcmp(key, "force_generic")) {
+    p->force_generic = value != 0;
+  } else if (!strcmp(key, "lds_copies")) {
+    if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
+    p->lds_copies = (int)value;
+  } else if (!strcmp(key, "profile")) {
+    // value = number of most recent executes whose main-kernel duration is kept (0 = off)
+    if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "profile must be in [0, 4096]");
+    DeviceGuard g;
+    if (int rc = g.set(p->device)) return rc;
+    while ((int64_t)p->ring.size() < value) {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIPC(hipEventCreate(&a));
+      HIPC(hipEventCreate(&b));
+      p->ring.emplace_back(a, b);
+    }
+    p->profile = (int)value;
+    p->n_recorded = 0;
+  } else {
+    return fail(XHIST_ERR_INVALID, "unknown parameter '%s'", key);
+  }
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_describe(xhist_plan* p, char* buf, size_t cap) {
+  if (!p || !buf || !cap) return fail(XHIST_ERR_INVALID, "plan / buf is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  strncpy(buf, p->desc.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n_out) {
+  if (!p || !ms || !n_out || cap < 0) return fail(XHIST_ERR_INVALID, "plan / ms / n_out is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  *n_out = 0;
+  if (!p->profile || p->n_recorded == 0) return XHIST_OK;
+  DeviceGuard g;
+  if (int rc = g.set(p->device)) return rc;
+  const int64_t kept = std::min<int64_t>(p->n_recorded, p->profile);
+  for (int64_t k = p->n_recorded - kept; k < p->n_recorded && *n_out < cap; ++k) {
+    auto& e = p->ring[(size_t)(k % p->profile)];
+    HIPC(hipEventSynchronize(e.second));
+    HIPC(hipEventElapsedTime(&ms[*n_out], e.first, e.second));
+    ++*n_out;
+  }
+  p->n_recorded = 0;
+  return XHIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel selection
+// ------------------------------------------------------------------------------------------
+typedef void (*kernel_fn)(const Params);
+
+constexpr int kUnroll = 4;
+
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick(bool lds) {
+  constexpr int wsz = std::is_same<WT, NoWeight>::value ? 0 : (int)sizeof(typename std::conditional<std::is_same<WT, NoWeight>::value, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  return lds ? (kernel_fn)hist_fast<ST, WT, D, VEC, kUnroll, true> : (kernel_fn)hist_fast<ST, WT, D, VEC, kUnroll, false>;
+}
+
+template <typename ST, typename WT>
+static kernel_fn fast_pick_d(int D, bool lds) {
+  switch (D) {
+    case 1: return fast_pick<ST, WT, 1>(lds);
+    case 2: return fast_pick<ST, WT, 2>(lds);
+    case 3: return fast_pick<ST, WT, 3>(lds);
+    default: return nullptr;
+  }
+}
+
+template <typename ST>
+static kernel_fn fast_pick_w(int wdt, int D, bool lds) {
+  switch (wdt) {
+    case -1: return fast_pick_d<ST, NoWeight>(D, lds);
+    case XHIST_F64: return fast_pick_d<ST, double>(D, lds);
+    case XHIST_F32: return fast_pick_d<ST, float>(D, lds);
+    default: return nullptr;
+  }
+}
+
+static kernel_fn fast_kernel(int sdt, int wdt, int D, bool lds, int* vec) {
+  const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
+  *vec = 16 / std::max(ssz, wsz);
+  switch (sdt) {
+    case XHIST_F64: return fast_pick_w<double>(wdt, D, lds);
+    case XHIST_F32: return fast_pick_w<float>(wdt, D, lds);
+    default: return nullptr;
+  }
+}
+
+static kernel_fn generic_kernel(int cmp, bool weighted, bool lds) {
+  if (cmp == XHIST_CMP_F64) {
+    if (weighted) return lds ? (kernel_fn)hist_generic<0, true, true> : (kernel_fn)hist_generic<0, true, false>;
+    return lds ? (kernel_fn)hist_generic<0, false, true> : (kernel_fn)hist_generic<0, false, false>;
+  }
+  if (weighted) return lds ? (kernel_fn)hist_generic<1, true, true> : (kernel_fn)hist_generic<1, true, false>;
+  return lds ? (kernel_fn)hist_generic<1, false, true> : (kernel_fn)hist_generic<1, false, false>;
+}
+
+// ------------------------------------------------------------------------------------------
+// device-resident execute
+// ------------------------------------------------------------------------------------------
+static int validate_arrays(const xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
+                           int64_t n_cols, const void* out, int out_dtype) {
+  if (!p) return fail(XHIST_ERR_INVALID, "plan is NULL");
+  if (!samples) return fail(XHIST_ERR_INVALID, "samples is NULL");
+  if (n_rows < 0 || n_cols < 0) return fail(XHIST_ERR_INVALID, "negative shape");
+  const bool empty = n_rows == 0 || n_cols == 0;
+  for (int d = 0; d < p->n_dims; ++d) {
+    if (!empty && !samples[d].data) return fail(XHIST_ERR_INVALID, "samples[%d].data is NULL", d);
+    if (!dtype_size(samples[d].dtype)) return fail(XHIST_ERR_INVALID, "samples[%d] has unknown dtype tag %d", d, samples[d].dtype);
+    if (samples[d].row_stride < 0 || samples[d].col_stride < 0)
+      return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
+    if (p->cmp == XHIST_CMP_I64 && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
+      return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", samples[d].dtype);
+  }
+  if (weights) {
+    if (!empty && !weights->data) return fail(XHIST_ERR_INVALID, "weights.data is NULL");
+    if (!dtype_size(weights->dtype)) return fail(XHIST_ERR_INVALID, "weights has unknown dtype tag %d", weights->dtype);
+    if (weights->row_stride < 0 || weights->col_stride < 0)
+      return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
+    if (out_dtype != XHIST_F64) return fail(XHIST_ERR_INVALID, "weighted histograms are float64 (out_dtype XHIST_F64)");
+  } else if (out_dtype != XHIST_I64) {
+    return fail(XHIST_ERR_INVALID, "unweighted histograms are int64 (out_dtype XHIST_I64)");
+  }
+  if (!out && n_rows * p->n_bins > 0) return fail(XHIST_ERR_INVALID, "out is NULL");
+  return XHIST_OK;
+}
+
+static const void* advance(const void* base, int dt, int64_t elems) {
+  return static_cast<const char*>(base) + elems * dtype_size(dt);
+}
+
+static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
+                          int64_t n_cols, void* out, int accumulate, hipStream_t stream) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  const int64_t out_elems = n_rows * p->n_bins;
+  if (!accumulate && out_elems > 0) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
+  if (out_elems == 0 || n_cols == 0) return XHIST_OK;
+
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
+    force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile;
+  }
+
+  // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
+  const size_t table_bytes = (size_t)p->table_words * 8;
+  const size_t lds_cap = p->lds_max;
+  const bool tables_fit = table_bytes + 1024 <= lds_cap;
+  bool fast = !force_generic && p->cmp == XHIST_CMP_F64 && D <= 3 && tables_fit && p->n_bins < ((int64_t)1 << 31);
+  int vec = 1;
+  const int sdt = samples[0].dtype;
+  const int wdt = weighted ? weights->dtype : -1;
+  if (fast) {
+    fast = (sdt == XHIST_F64 || sdt == XHIST_F32) && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32);
+    if (fast) {
+      vec = 16 / std::max(dtype_size(sdt), wdt < 0 ? 0 : dtype_size(wdt));
+      for (int d = 0; d < D && fast; ++d) {
+        const xhist_array& a = samples[d];
+        fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)(vec * dtype_size(sdt)) == 0) &&
+               (n_rows == 1 || a.row_stride % vec == 0);
+      }
+      if (fast && weighted)
+        fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)(vec * dtype_size(wdt)) == 0) &&
+               (n_rows == 1 || weights->row_stride % vec == 0);
+    }
+  }
+
+  // ---- histogram placement: LDS sub-histograms (replicated per lane bank) or global atomics ---
+  const int acc_size = weighted ? 8 : 4;
+  const int max_cl2 = weighted ? 4 : 5;
+  bool lds_hist = !force_global && tables_fit && p->n_bins < ((int64_t)1 << 24);
+  int cl2 = 0;
+  size_t hist_bytes = 0;
+  if (lds_hist) {
+    const size_t soft = 24 * 1024;  // keeps >= 6 workgroups of 256 threads resident per CU
+    cl2 = max_cl2;
+    if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
+    auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
+    if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
+    while (cl2 > 0 && table_bytes + bytes_at(cl2) > lds_cap) --cl2;
+    hist_bytes = bytes_at(cl2);
+    if (table_bytes + hist_bytes > lds_cap) lds_hist = false;
+  }
+  if (!lds_hist) { cl2 = 0; hist_bytes = 0; }
+  const bool tables_in_lds = tables_fit;
+  const size_t lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
+
+  kernel_fn fn = nullptr;
+  if (fast) fn = fast_kernel(sdt, wdt, D, lds_hist, &vec);
+  if (!fn) { fast = false; fn = generic_kernel(p->cmp, weighted, lds_hist); }
+
+  // ---- geometry -----------------------------------------------------------------------------
+  int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? 1024 : 256);
+  int bpc = std::min<int>(2048 / block, 8);
+  if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
+  const int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc;
+  const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
+  const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
+  if (lds_bytes > 64 * 1024) HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+
+  // rows per launch bounded by the grid limit; columns per launch bounded so that no workgroup
+  // can overflow a uint32 LDS counter (< 2^31 samples per workgroup per launch)
+  const int64_t kMaxGrid = ((int64_t)1 << 31) - 1;
+  int64_t col_chunk = n_cols;
+  {
+    int64_t segs_full = std::max<int64_t>(1, std::min<int64_t>(tiles_per_row, (target + n_rows - 1) / n_rows));
+    const int64_t per_wg = ((tiles_per_row + segs_full - 1) / segs_full) * tile;
+    if (per_wg >= ((int64_t)1 << 31)) col_chunk = segs_full * (((int64_t)1 << 30) / tile) * tile;
+  }
+  bool first_launch = true;
+  int ring_slot = -1;
+  char desc[384];
+  for (int64_t c0 = 0; c0 < n_cols; c0 += col_chunk) {
+    const int64_t nc = std::min(col_chunk, n_cols - c0);
+    const int64_t tpr = (nc + tile - 1) / tile;
+    for (int64_t r0 = 0; r0 < n_rows;) {
+      int64_t segs = std::max<int64_t>(1, std::min<int64_t>(tpr, (target + (n_rows - r0) - 1) / (n_rows - r0)));
+      const int64_t nr = std::min<int64_t>(n_rows - r0, kMaxGrid / segs);
+      Params kp;
+      memset(&kp, 0, sizeof kp);
+      for (int d = 0; d < D; ++d) {
+        const xhist_array& a = samples[d];
+        kp.s_ptr[d] = advance(a.data, a.dtype, r0 * a.row_stride + c0 * a.col_stride);
+        kp.s_rs[d] = a.row_stride;
+        kp.s_cs[d] = a.col_stride;
+        kp.s_dt[d] = a.dtype;
+        kp.dim[d] = p->dim[d];
+      }
+      if (weighted) {
+        kp.w_ptr = advance(weights->data, weights->dtype, r0 * weights->row_stride + c0 * weights->col_stride);
+        kp.w_rs = weights->row_stride;
+        kp.w_cs = weights->col_stride;
+        kp.w_dt = weights->dtype;
+      }
+      kp.n_dims = D;
+      kp.tables = p->d_tables;
+      kp.table_words = p->table_words;
+      kp.tables_in_lds = tables_in_lds ? 1 : 0;
+      kp.n_rows = nr;
+      kp.n_cols = nc;
+      kp.n_bins = p->n_bins;
+      kp.out = static_cast<char*>(out) + (size_t)r0 * p->n_bins * 8;
+      kp.copies_log2 = cl2;
+      kp.segs = (int32_t)segs;
+      const dim3 grid((unsigned)(nr * segs));
+      if (profile && first_launch) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        ring_slot = (int)(p->n_recorded % profile);
+        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
+      }
+      hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
+      HIPC(hipGetLastError());
+      if (first_launch) {
+        snprintf(desc, sizeof desc,
+                 "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
+                 "lut_k0=%d steps0=%d weighted=%d D=%d",
+                 fast ? "fast" : "generic", lds_hist ? "lds" : "global", fast ? vec : 1, fast ? kUnroll : 1, block,
+                 (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2, table_bytes, p->dim[0].lut_k, p->dim[0].steps,
+                 (int)weighted, D);
+      }
+      first_launch = false;
+      r0 += nr;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (ring_slot >= 0) {
+      HIPC(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
+      ++p->n_recorded;
+    }
+    p->desc = desc;
+  }
+  return XHIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-resident execute: stage chunks through device memory (PCIe-bound by construction)
+// ------------------------------------------------------------------------------------------
+struct Staged {
+  void* dptr = nullptr;
+  size_t cap = 0;
+};
+
+static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0, int64_t nc, Staged& st, xhist_array* view,
+                       hipStream_t stream) {
+  const int es = dtype_size(a.dtype);
+  if (a.col_stride != 0 && a.col_stride != 1)
+    return fail(XHIST_ERR_UNSUPPORTED, "host arrays need col_stride 0 or 1 (got %lld); pass a contiguous copy", (long long)a.col_stride);
+  const int64_t rows = a.row_stride == 0 ? 1 : nr;
+  const int64_t cols = a.col_stride == 0 ? 1 : nc;
+  const size_t need = (size_t)rows * cols * es;
+  if (need > st.cap) {
+    if (st.dptr) (void)hipFree(st.dptr);
+    st.dptr = nullptr;
+    st.cap = 0;
+    HIPC(hipMalloc(&st.dptr, need));
+    st.cap = need;
+  }
+  const char* src = static_cast<const char*>(a.data) + ((a.row_stride ? r0 * a.row_stride : 0) + (a.col_stride ? c0 : 0)) * es;
+  if (rows == 1 || a.row_stride == cols) {
+    HIPC(hipMemcpyAsync(st.dptr, src, need, hipMemcpyHostToDevice, stream));
+  } else {
+    HIPC(hipMemcpy2DAsync(st.dptr, (size_t)cols * es, src, (size_t)a.row_stride * es, (size_t)cols * es, (size_t)rows,
+                          hipMemcpyHostToDevice, stream));
+  }
+  view->data = st.dptr;
+  view->dtype = a.dtype;
+  view->reserved = 0;
+  view->row_stride = a.row_stride == 0 ? 0 : cols;
+  view->col_stride = a.col_stride == 0 ? 0 : 1;
+  return XHIST_OK;
+}
+
+static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows, int64_t n_cols,
+                        void* out, int accumulate, hipStream_t stream) {
+  const int D = p->n_dims;
+  const int64_t out_elems = n_rows * p->n_bins;
+  if (out_elems == 0) return XHIST_OK;
+  if (n_cols == 0) {
+    if (!accumulate) memset(out, 0, (size_t)out_elems * 8);
+    return XHIST_OK;
+  }
+  void* d_out = nullptr;
+  Staged st[kMaxDims + 1];
+  int rc = XHIST_OK;
+  auto done = [&](int code) {
+    for (auto& s : st)
+      if (s.dptr) (void)hipFree(s.dptr);
+    if (d_out) (void)hipFree(d_out);
+    return code;
+  };
+  if (hipMalloc(&d_out, (size_t)out_elems * 8) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
+  if (hipMemsetAsync(d_out, 0, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_HIP, "hipMemsetAsync failed"));
+
+  // chunks of <= 2^27 elements per array: whole rows when a row fits, else column spans of one row
+  const int64_t kChunk = (int64_t)1 << 27;
+  const int64_t rows_per = n_cols <= kChunk ? std::max<int64_t>(1, kChunk / n_cols) : 1;
+  const int64_t cols_per = n_cols <= kChunk ? n_cols : kChunk;
+  for (int64_t r0 = 0; r0 < n_rows && rc == XHIST_OK; r0 += rows_per) {
+    const int64_t nr = std::min(rows_per, n_rows - r0);
+    for (int64_t c0 = 0; c0 < n_cols && rc == XHIST_OK; c0 += cols_per) {
+      const int64_t nc = std::min(cols_per, n_cols - c0);
+      xhist_array views[kMaxDims];
+      xhist_array wview;
+      for (int d = 0; d < D && rc == XHIST_OK; ++d) rc = stage_chunk(samples[d], r0, nr, c0, nc, st[d], &views[d], stream);
+      if (rc == XHIST_OK && weights) rc = stage_chunk(*weights, r0, nr, c0, nc, st[kMaxDims], &wview, stream);
+      if (rc == XHIST_OK)
+        rc = execute_device(p, views, weights ? &wview : nullptr, nr, nc, static_cast<char*>(d_out) + (size_t)r0 * p->n_bins * 8, 1, stream);
+      // the staging buffers are reused by the next chunk: same-stream ordering makes that safe
+    }
+  }
+  if (rc != XHIST_OK) { (void)hipStreamSynchronize(stream); return done(rc); }
+  if (!accumulate) {
+    if (hipMemcpyAsync(out, d_out, (size_t)out_elems * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+      return done(fail(XHIST_ERR_HIP, "copy of the result to the host failed: %s", hipGetErrorString(hipGetLastError())));
+  } else {
+    std::vector<uint64_t> tmp((size_t)out_elems);
+    if (hipMemcpyAsync(tmp.data(), d_out, (size_t)out_elems * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+      return done(fail(XHIST_ERR_HIP, "copy of the result to the host failed: %s", hipGetErrorString(hipGetLastError())));
+    if (weights) {
+      double* o = static_cast<double*>(out);
+      const double* t = reinterpret_cast<const double*>(tmp.data());
+      for (int64_t i = 0; i < out_elems; ++i) o[i] += t[i];
+    } else {
+      int64_t* o = static_cast<int64_t*>(out);
+      for (int64_t i = 0; i < out_elems; ++i) o[i] += (int64_t)tmp[(size_t)i];
+    }
+  }
+  return done(XHIST_OK);
+}
+
+extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
+                                  int64_t n_cols, void* out, int out_dtype, int mem_kind, int accumulate, void* stream) {
+  if (int rc = validate_arrays(p, samples, weights, n_rows, n_cols, out, out_dtype)) return rc;
+  if (mem_kind != XHIST_MEM_HOST && mem_kind != XHIST_MEM_DEVICE) return fail(XHIST_ERR_INVALID, "unknown mem_kind %d", mem_kind);
+  DeviceGuard g;
+  if (int rc = g.set(p->device)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mem_kind == XHIST_MEM_DEVICE) return execute_device(p, samples, weights, n_rows, n_cols, out, accumulate, s);
+  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// one-shot form with a plan cache
+// ------------------------------------------------------------------------------------------
+static std::mutex g_cache_mu;
+static std::map<std::string, xhist_plan*> g_cache;
+
+static std::string cache_key(int device, int n_inputs, const void* const* edges, const int64_t* n_edges, int cmp) {
+  std::string k;
+  k.append(reinterpret_cast<const char*>(&device), sizeof device);
+  k.append(reinterpret_cast<const char*>(&cmp), sizeof cmp);
+  for (int d = 0; d < n_inputs; ++d) {
+    k.append(reinterpret_cast<const char*>(&n_edges[d]), sizeof(int64_t));
+    k.append(static_cast<const char*>(edges[d]), (size_t)n_edges[d] * 8);
+  }
+  return k;
+}
+
+extern "C" int xhist_bincount_rows(int device, int n_inputs, const xhist_array* samples, const xhist_array* weights,
+                                   int64_t n_rows, int64_t n_cols, const void* const* edges, const int64_t* n_edges,
+                                   int cmp_domain, void* out, int out_dtype, int mem_kind, int accumulate, void* stream) {
+  if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS || !edges || !n_edges) return fail(XHIST_ERR_INVALID, "bad n_inputs / edges");
+  for (int d = 0; d < n_inputs; ++d)
+    if (!edges[d] || n_edges[d] < 1) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL or empty", d);
+  xhist_plan* plan = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    const std::string key = cache_key(device, n_inputs, edges, n_edges, cmp_domain);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) {
+      plan = it->second;
+    } else {
+      if (int rc = xhist_plan_create(device, n_inputs, edges, n_edges, cmp_domain, &plan)) return rc;
+      if (g_cache.size() >= 64) {  // bounded: drop everything rather than track recency
+        for (auto& kv : g_cache) xhist_plan_destroy(kv.second);
+        g_cache.clear();
+      }
+      g_cache[key] = plan;
+    }
+  }
+  return xhist_plan_execute(plan, samples, weights, n_rows, n_cols, out, out_dtype, mem_kind, accumulate, stream);
+}
+
+extern "C" int xhist_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (auto& kv : g_cache) xhist_plan_destroy(kv.second);
+  g_cache.clear();
+  return XHIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// min / max
+// ------------------------------------------------------------------------------------------
+extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result, int mem_kind,
+                            void* stream) {
+  if (!a || !result) return fail(XHIST_ERR_INVALID, "array / result is NULL");
+  if (!dtype_size(a->dtype)) return fail(XHIST_ERR_INVALID, "unknown dtype tag %d", a->dtype);
+  if (n_rows <= 0 || n_cols <= 0) return fail(XHIST_ERR_INVALID, "min/max of an empty array");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available; this library has no CPU path", device);
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Staged st;
+  xhist_array view = *a;
+  if (mem_kind == XHIST_MEM_HOST) {
+    if (n_rows * n_cols > ((int64_t)1 << 31)) return fail(XHIST_ERR_UNSUPPORTED, "host min/max above 2^31 elements: reduce on the host");
+    if (int rc = stage_chunk(*a, 0, n_rows, 0, n_cols, st, &view, s)) { if (st.dptr) (void)hipFree(st.dptr); return rc; }
+  }
+  const int grid = 1024;
+  double* d_part = nullptr;
+  auto done = [&](int code) {
+    if (d_part) (void)hipFree(d_part);
+    if (st.dptr) (void)hipFree(st.dptr);
+    return code;
+  };
+  if (hipMalloc(&d_part, sizeof(double) * 3 * grid) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc failed"));
+  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, n_rows, n_cols, d_part);
+  std::vector<double> part(3 * grid);
+  if (hipGetLastError() != hipSuccess ||
+      hipMemcpyAsync(part.data(), d_part, sizeof(double) * 3 * grid, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return done(fail(XHIST_ERR_HIP, "min/max kernel failed: %s", hipGetErrorString(hipGetLastError())));
+  double mn = HUGE_VAL, mx = -HUGE_VAL;
+  bool nan = false;
+  for (int b = 0; b < grid; ++b) {
+    mn = std::fmin(mn, part[3 * b]);
+    mx = std::fmax(mx, part[3 * b + 1]);
+    nan |= part[3 * b + 2] != 0.0;
+  }
+  result[0] = nan ? NAN : mn;
+  result[1] = nan ? NAN : mx;
+  return done(XHIST_OK);
+}

@@ -1,0 +1,467 @@
+// xhist_kernels.hip.h — CDNA4 (gfx950) kernels of the fused digitize -> joint index -> scatter-add
+// hot path.  Written for MI355X only: 64-wide wavefronts, 160 KiB LDS/CU, 256 CUs in 8 XCDs.
+//
+// What one kernel launch replaces in the reference (/root/reference/xhistogram/core.py):
+//   searchsorted(side="right") + right-edge fix-up   core.py:163-174
+//   ravel_multi_index over the (E_d+1)-sized axes     core.py:178-183
+//   row-offset trick + np.bincount (+ weights)        core.py:73-83
+//   trimming the under/overflow (and NaN) bins        core.py:189-192
+// The intermediate int64 index arrays of the reference (>= 40 B/sample of DRAM traffic) never
+// exist: a sample is read once from HBM (8 B f64 / 4 B f32), binned in registers against edge
+// tables staged in LDS, and added to a replicated sub-histogram in LDS with ds_add_u32 /
+// ds_add_f64; each workgroup flushes its LDS partial into the output with global atomics.
+//
+// Exactness of digitize (the hard part of parity): the bin of x is defined by comparisons against
+// the caller's exact edge values, never by (x - lo) * inv_width.  A uniform bucket grid over
+// [e_0, e_last] is used ONLY as an accelerator: bucket(x) = clamp(int((x - e_0) * scale)) is a
+// monotone non-decreasing function of x (IEEE subtraction, multiplication and truncation are all
+// monotone), and the per-bucket table entry (start, cnt) is built by applying the SAME device
+// function to the edges themselves.  Hence for every x in bucket b:
+//     #{j : e_j <= x} = start[b] + #{ j in [start[b], start[b]+cnt[b]) : e_j <= x }
+// exactly — edges in lower buckets are certainly <= x, edges in higher buckets certainly > x, and
+// the (usually 0 or 1) edges sharing x's bucket are compared explicitly.  No assumption about
+// uniformity or about rounding of the bucket arithmetic is needed for correctness.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xhist {
+
+constexpr int kMaxDims = 8;
+
+// dtype tags — must match xhist_dtype in include/xhist_amd.h
+enum : int32_t {
+  DT_F64 = 0, DT_F32 = 1, DT_F16 = 2, DT_I64 = 3, DT_I32 = 4, DT_I16 = 5, DT_I8 = 6,
+  DT_U64 = 7, DT_U32 = 8, DT_U16 = 9, DT_U8 = 10, DT_BOOL = 11
+};
+
+// Per-dimension digitize parameters; lives in the kernel-argument segment (-> SGPRs).
+struct DimTable {
+  double e0_f, eL_f;    // first / last edge, float64 domain
+  int64_t e0_i, eL_i;   // first / last edge, int64 domain
+  double scale;         // lut_k / (e_last - e_0); 0 when the bucket grid is disabled (lut_k == 1)
+  int32_t n_edges;      // E
+  int32_t nb;           // E - 1 real bins
+  int32_t lut_k;        // number of buckets K
+  int32_t steps;        // binary-search steps inside one bucket: 2^steps > max edges per bucket
+  int32_t edge_off;     // offset of this dimension's edges in the table blob, in 8-byte words
+  int32_t lut_off;      // offset of this dimension's bucket table in the blob, in 4-byte words
+  int64_t out_stride;   // stride of this dimension in the flat real-bin index (C order)
+};
+
+struct Params {
+  const void* s_ptr[kMaxDims];
+  int64_t s_rs[kMaxDims];  // row stride, elements
+  int64_t s_cs[kMaxDims];  // col stride, elements
+  int32_t s_dt[kMaxDims];
+  const void* w_ptr;       // nullptr = unweighted
+  int64_t w_rs, w_cs;
+  int32_t w_dt;
+  int32_t n_dims;
+  DimTable dim[kMaxDims];
+  const uint64_t* tables;  // device blob: edges of every dimension, then bucket tables
+  int32_t table_words;     // blob size in 8-byte words
+  int32_t tables_in_lds;   // generic family only: stage the blob in LDS (1) or read it from L2 (0)
+  int64_t n_rows, n_cols;
+  int64_t n_bins;          // prod(nb_d)
+  void* out;               // [n_rows, n_bins] uint64 counts or float64 sums
+  int32_t copies_log2;     // LDS sub-histogram replication (lane-private banks)
+  int32_t segs;            // workgroups cooperating on one row
+};
+
+// ---------------------------------------------------------------------------------------------
+// compare domains
+// ---------------------------------------------------------------------------------------------
+template <int CMP>
+struct Dom;
+
+template <>
+struct Dom<0> {  // float64 compares (numpy promotes f32/int samples to f64 against f64 edges)
+  using T = double;
+  static __device__ __forceinline__ bool in_range(double x, const DimTable& t) {
+    return (x >= t.e0_f) & (x <= t.eL_f);  // false for NaN
+  }
+  static __device__ __forceinline__ double offset(double x, const DimTable& t) { return x - t.e0_f; }
+};
+
+template <>
+struct Dom<1> {  // exact int64 compares (integer / datetime64 samples against integer edges)
+  using T = int64_t;
+  static __device__ __forceinline__ bool in_range(int64_t x, const DimTable& t) {
+    return (x >= t.e0_i) & (x <= t.eL_i);
+  }
+  static __device__ __forceinline__ double offset(int64_t x, const DimTable& t) {
+    // x >= e0 for every x that matters; the unsigned difference is exact modulo 2^64 and its
+    // conversion to double is monotone
+    return (double)((uint64_t)x - (uint64_t)t.e0_i);
+  }
+};
+
+// Monotone bucket index in [0, K-1] for ANY x (NaN -> 0).  Used by the table builder (on the
+// edges) and by digitize (on the samples): the two must be the same code.
+template <int CMP>
+__device__ __forceinline__ int bucket_of(typename Dom<CMP>::T x, const DimTable& t) {
+  double tt = Dom<CMP>::offset(x, t) * t.scale;
+  tt = fmax(fmin(tt, (double)(t.lut_k - 1)), 0.0);  // fmin/fmax drop a NaN operand
+  return (int)tt;
+}
+
+// digitize, split so that a tile's samples can run the common (one edge per bucket) part as one
+// branch-free batch: begin = bucket-table read + first upper_bound step, more = further steps
+// (only when some bucket holds more than one edge), end = right-edge fix-up + range check.
+struct DigState {
+  uint32_t lo;   // edges known to be <= x so far
+  uint32_t len;  // edges of x's bucket still undecided
+  bool ok;       // x inside [e_0, e_last] and not NaN
+};
+
+template <int CMP, typename TabPtr>
+__device__ __forceinline__ void upper_bound_step(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab, DigState& s) {
+  using T = typename Dom<CMP>::T;
+  auto edges = reinterpret_cast<const T*>(tab + t.edge_off);
+  const uint32_t half = s.len >> 1;
+  const uint32_t mid = s.lo + half;
+  const T e = edges[min((int)mid, t.n_edges - 1)];
+  const bool le = (s.len != 0u) & (e <= x);
+  s.lo = le ? mid + 1u : s.lo;
+  s.len = le ? s.len - half - 1u : half;
+}
+
+template <int CMP, typename TabPtr>
+__device__ __forceinline__ DigState digitize_begin(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
+  auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
+  DigState s;
+  s.ok = Dom<CMP>::in_range(x, t);
+  const uint32_t ent = lut[bucket_of<CMP>(x, t)];
+  s.lo = ent & 0xffffu;  // edges below x's bucket: certainly <= x
+  s.len = ent >> 16;     // edges sharing the bucket: compared explicitly
+  upper_bound_step<CMP>(x, t, tab, s);
+  return s;
+}
+
+template <int CMP, typename TabPtr>
+__device__ __forceinline__ void digitize_more(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab, DigState& s) {
+#pragma unroll 1
+  for (int k = 1; k < t.steps; ++k) upper_bound_step<CMP>(x, t, tab, s);
+}
+
+// Real-bin index in [0, nb), or -1 when the reference would drop the sample.
+// s.lo == #{j : e_j <= x} (searchsorted side="right"); x == e_last gives E -> last bin.
+__device__ __forceinline__ int digitize_end(const DimTable& t, const DigState& s) {
+  const int bin = min((int)s.lo - 1, t.nb - 1);
+  return s.ok ? bin : -1;
+}
+
+template <int CMP, typename TabPtr>
+__device__ __forceinline__ int digitize(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
+  DigState s = digitize_begin<CMP>(x, t, tab);
+  digitize_more<CMP>(x, t, tab, s);
+  return digitize_end(t, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// element loads with conversion into the compare domain / to float64 weights
+// ---------------------------------------------------------------------------------------------
+template <typename OUT>
+__device__ __forceinline__ OUT load_as(const void* p, int32_t dt, int64_t i) {
+  switch (dt) {
+    case DT_F64: return (OUT) reinterpret_cast<const double*>(p)[i];
+    case DT_F32: return (OUT) reinterpret_cast<const float*>(p)[i];
+    case DT_F16: return (OUT)(float) reinterpret_cast<const _Float16*>(p)[i];
+    case DT_I64: return (OUT) reinterpret_cast<const int64_t*>(p)[i];
+    case DT_I32: return (OUT) reinterpret_cast<const int32_t*>(p)[i];
+    case DT_I16: return (OUT) reinterpret_cast<const int16_t*>(p)[i];
+    case DT_I8: return (OUT) reinterpret_cast<const int8_t*>(p)[i];
+    case DT_U64: return (OUT) reinterpret_cast<const uint64_t*>(p)[i];
+    case DT_U32: return (OUT) reinterpret_cast<const uint32_t*>(p)[i];
+    case DT_U16: return (OUT) reinterpret_cast<const uint16_t*>(p)[i];
+    case DT_U8: return (OUT) reinterpret_cast<const uint8_t*>(p)[i];
+    default: return (OUT)(reinterpret_cast<const uint8_t*>(p)[i] != 0);  // DT_BOOL
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulators: uint32 counts / float64 weight sums in LDS, uint64 / float64 in global memory
+// ---------------------------------------------------------------------------------------------
+struct NoWeight {};
+
+template <typename WT>
+struct Acc {  // weighted
+  using lds_t = double;
+  using out_t = double;
+  static constexpr int kMaxCopiesLog2 = 4;  // 16 lanes x 8 B cover the 32 LDS write banks
+  static __device__ __forceinline__ void lds_add(lds_t* h, uint32_t i, double w) { unsafeAtomicAdd(h + i, w); }
+  static __device__ __forceinline__ void out_add(out_t* o, int64_t i, double w) { unsafeAtomicAdd(o + i, w); }
+};
+
+template <>
+struct Acc<NoWeight> {  // unweighted
+  using lds_t = uint32_t;
+  using out_t = unsigned long long;
+  static constexpr int kMaxCopiesLog2 = 5;  // 32 lanes x 4 B cover the 32 LDS write banks
+  static __device__ __forceinline__ void lds_add(lds_t* h, uint32_t i, uint32_t) { atomicAdd(h + i, 1u); }
+  static __device__ __forceinline__ void out_add(out_t* o, int64_t i, unsigned long long v) { atomicAdd(o + i, v); }
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char xhist_smem[];
+
+// stage the table blob (edges + bucket tables) in LDS; returns the LDS copy
+__device__ __forceinline__ const uint64_t* stage_tables(const Params& p) {
+  uint64_t* dst = reinterpret_cast<uint64_t*>(xhist_smem);
+  for (int i = threadIdx.x; i < p.table_words; i += blockDim.x) dst[i] = p.tables[i];
+  return dst;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST family: homogeneous float samples (f64 / f32), contiguous columns, 16-byte vector loads.
+//   ST sample type, WT weight type (NoWeight / double / float), D inputs, VEC elements per load,
+//   UNROLL loads in flight per input per lane, LDS_HIST: sub-histograms in LDS (else global atomics)
+// Work split: workgroups (row, seg); the `segs` workgroups of a row walk its tiles interleaved
+// (tile = seg, seg + segs, ...) so that the whole grid sweeps HBM as one front.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+
+template <typename ST, typename WT, int D, int VEC, int UNROLL, bool LDS_HIST>
+__global__ void __launch_bounds__(1024) hist_fast(const Params p) {
+  using A = Acc<WT>;
+  using lds_t = typename A::lds_t;
+  using out_t = typename A::out_t;
+  using svec = typename VecOf<ST, VEC>::type;
+  constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  using wvec = typename VecOf<wscalar, VEC>::type;
+
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x / p.segs;
+  const int seg = blockIdx.x % p.segs;
+
+  const uint64_t* tab = stage_tables(p);
+  lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem + (size_t)p.table_words * 8);
+  const uint32_t cmask = (1u << p.copies_log2) - 1u;
+  const uint32_t mycopy = (uint32_t)tid & cmask;
+  const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
+  if (LDS_HIST) {
+    const uint32_t n = ((uint32_t)p.n_bins + 1u) << p.copies_log2;
+    for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
+  }
+  __syncthreads();
+
+  const ST* sp[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + row * p.s_rs[d];
+  const wscalar* wp = nullptr;
+  if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row * p.w_rs;
+  out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
+
+  auto scatter = [&](bool ok, uint32_t flat, double w) {
+    if (LDS_HIST) {
+      const uint32_t idx = ok ? ((flat << p.copies_log2) + mycopy) : trash;
+      A::lds_add(hist, idx, w);
+    } else if (ok) {
+      if (kWeighted) A::out_add(out, (int64_t)flat, w);
+      else A::out_add(out, (int64_t)flat, 1);
+    }
+  };
+  int max_steps = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
+
+  const int64_t tile_elems = (int64_t)blockDim.x * VEC * UNROLL;
+  const int64_t n_tiles = (p.n_cols + tile_elems - 1) / tile_elems;
+  for (int64_t tile = seg; tile < n_tiles; tile += p.segs) {
+    const int64_t base = tile * tile_elems;
+    if (base + tile_elems <= p.n_cols) {
+      svec xv[D][UNROLL];
+      wvec wv[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + ((int64_t)u * blockDim.x + tid) * VEC;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(sp[d] + i));
+        if (kWeighted) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + i));
+      }
+      // whole tile as one branch-free batch: table reads of all samples are independent
+      DigState st[D][UNROLL][VEC];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+          for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<0>((double)xv[d][u][v], p.dim[d], tab);
+      // wave-uniform extra rounds when some bucket holds several edges (non-uniform / duplicate
+      // edges); a round is a no-op for a sample whose bucket is already decided (len == 0)
+#pragma unroll 1
+      for (int k = 1; k < max_steps; ++k) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int d = 0; d < D; ++d) upper_bound_step<0>((double)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          bool ok = true;
+          uint32_t flat = 0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const int b = digitize_end(p.dim[d], st[d][u][v]);
+            ok &= (b >= 0);
+            flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
+          }
+          scatter(ok, flat, kWeighted ? (double)wv[u][v] : 0.0);
+        }
+    } else {  // ragged last tile: scalar, bounds-checked
+      for (int64_t i = base + tid; i < p.n_cols; i += blockDim.x) {
+        bool ok = true;
+        uint32_t flat = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int b = digitize<0>((double)sp[d][i], p.dim[d], tab);
+          ok &= (b >= 0);
+          flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
+        }
+        scatter(ok, flat, kWeighted ? (double)wp[i] : 0.0);
+      }
+    }
+  }
+
+  if (LDS_HIST) {
+    __syncthreads();
+    const uint32_t copies = 1u << p.copies_log2;
+    for (uint32_t b = tid; b < (uint32_t)p.n_bins; b += blockDim.x) {
+      typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
+      for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
+      if (sum != 0) A::out_add(out, (int64_t)b, sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GENERIC family: any dtype per input, any element strides (broadcast rows/cols), 1..8 inputs,
+// float64 or int64 compare domain, tables in LDS or read through L2.  Scalar coalesced loads.
+// ---------------------------------------------------------------------------------------------
+template <int CMP, bool WEIGHTED, bool LDS_HIST>
+__global__ void __launch_bounds__(1024) hist_generic(const Params p) {
+  using WT = typename std::conditional<WEIGHTED, double, NoWeight>::type;
+  using A = Acc<WT>;
+  using lds_t = typename A::lds_t;
+  using out_t = typename A::out_t;
+  using CT = typename Dom<CMP>::T;
+
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x / p.segs;
+  const int seg = blockIdx.x % p.segs;
+
+  const uint64_t* tab = p.tables;  // generic (flat) pointer: LDS copy or global blob
+  size_t hist_off = 0;
+  if (p.tables_in_lds) {
+    tab = stage_tables(p);
+    hist_off = (size_t)p.table_words * 8;
+  }
+  lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem + hist_off);
+  const uint32_t cmask = (1u << p.copies_log2) - 1u;
+  const uint32_t mycopy = (uint32_t)tid & cmask;
+  const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
+  if (LDS_HIST) {
+    const uint32_t n = ((uint32_t)p.n_bins + 1u) << p.copies_log2;
+    for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
+  }
+  __syncthreads();
+
+  out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
+  const int nd = p.n_dims;
+
+  for (int64_t i = (int64_t)seg * blockDim.x + tid; i < p.n_cols; i += (int64_t)p.segs * blockDim.x) {
+    bool ok = true;
+    int64_t flat = 0;
+    for (int d = 0; d < nd; ++d) {
+      const CT x = load_as<CT>(p.s_ptr[d], p.s_dt[d], row * p.s_rs[d] + i * p.s_cs[d]);
+      const int b = digitize<CMP>(x, p.dim[d], tab);
+      ok &= (b >= 0);
+      flat += (int64_t)b * p.dim[d].out_stride;
+    }
+    double w = 0.0;
+    if (WEIGHTED) w = load_as<double>(p.w_ptr, p.w_dt, row * p.w_rs + i * p.w_cs);
+    if (LDS_HIST) {
+      const uint32_t idx = ok ? (((uint32_t)flat << p.copies_log2) + mycopy) : trash;
+      A::lds_add(hist, idx, w);
+    } else if (ok) {
+      if (WEIGHTED) A::out_add(out, flat, w);
+      else A::out_add(out, flat, 1);
+    }
+  }
+
+  if (LDS_HIST) {
+    __syncthreads();
+    const uint32_t copies = 1u << p.copies_log2;
+    for (uint32_t b = tid; b < (uint32_t)p.n_bins; b += blockDim.x) {
+      typename std::conditional<WEIGHTED, double, unsigned long long>::type sum = 0;
+      for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
+      if (sum != 0) A::out_add(out, (int64_t)b, sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket-table builder: one workgroup per dimension applies bucket_of to that dimension's edges
+// (scratch[j] = bucket of edge j) and turns the sorted bucket ids into (start | cnt << 16).
+// ---------------------------------------------------------------------------------------------
+template <int CMP>
+__global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* blob, int32_t* scratch) {
+  using T = typename Dom<CMP>::T;
+  const T* edges = reinterpret_cast<const T*>(blob + t.edge_off);
+  uint32_t* lut = reinterpret_cast<uint32_t*>(blob) + t.lut_off;
+  for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x) scratch[j] = bucket_of<CMP>(edges[j], t);
+  __syncthreads();
+  for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
+    // lower_bound of b and of b+1 in the non-decreasing scratch[0..E)
+    int lo = 0, hi = t.n_edges;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b) lo = m + 1; else hi = m; }
+    const int start = lo;
+    hi = t.n_edges;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b + 1) lo = m + 1; else hi = m; }
+    lut[b] = (uint32_t)start | ((uint32_t)(lo - start) << 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// min / max with numpy's NaN propagation (feeds np.histogram_bin_edges, core.py:383-388)
+// partial[3*b + {0,1,2}] = {min, max, saw_nan} of workgroup b
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs,
+                                                       int64_t n_rows, int64_t n_cols, double* partial) {
+  double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+  int nan = 0;
+  const int64_t total = n_rows * n_cols;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = k / n_cols, c = k - r * n_cols;
+    const double x = load_as<double>(ptr, dt, r * rs + c * cs);
+    nan |= (x != x);
+    mn = fmin(mn, x);
+    mx = fmax(mx, x);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fmin(mn, __shfl_down(mn, off, 64));
+    mx = fmax(mx, __shfl_down(mx, off, 64));
+    nan |= __shfl_down(nan, off, 64);
+  }
+  __shared__ double s_mn[4], s_mx[4];
+  __shared__ int s_nan[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_mn[wave] = mn; s_mx[wave] = mx; s_nan[wave] = nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { mn = fmin(mn, s_mn[w]); mx = fmax(mx, s_mx[w]); nan |= s_nan[w]; }
+    partial[3 * blockIdx.x + 0] = mn;
+    partial[3 * blockIdx.x + 1] = mx;
+    partial[3 * blockIdx.x + 2] = (double)nan;
+  }
+}
+
+}  // namespace xhist
