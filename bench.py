@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--bins", type=int, default=100)
     ap.add_argument("--unweighted", action="store_true", help="8 B/sample variant (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     return ap.parse_args()
 
 

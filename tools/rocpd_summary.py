@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite) result: per-kernel stats and PMC counters.
+
+    python tools/rocpd_summary.py gpurun_out/prof_stats/bench_results.db > profiles/<name>.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name, n=110):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+def main(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    print("# rocprofv3 summary of", path)
+    print("## kernel stats (name | calls | total_us | avg_us | min_us | max_us | %)")
+    rows = list(cur.execute(
+        "select name, count(*), sum(duration)/1e3, avg(duration)/1e3, min(duration)/1e3, max(duration)/1e3 from kernels group by name order by 3 desc"))
+    tot = sum(r[2] for r in rows) or 1.0
+    for r in rows:
+        print("%-112s | %5d | %12.1f | %10.2f | %10.2f | %10.2f | %5.2f" % (short(r[0]), r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
+    k = list(cur.execute(
+        "select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels where name like '%xhist::%' group by name, grid_x, workgroup_x"))
+    if k:
+        print("## xhist dispatch geometry (name | grid | workgroup | lds | vgpr | agpr | sgpr | scratch)")
+        for r in k:
+            print("%-112s | %s" % (short(r[0]), " | ".join(str(v) for v in r[1:])))
+    try:
+        c = list(cur.execute(
+            "select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection group by kernel_name, counter_name order by 1, 2"))
+    except sqlite3.Error:
+        c = []
+    if c:
+        print("## PMC counters (kernel | counter | dispatches | avg | min | max)")
+        for r in c:
+            print("%-112s | %-18s | %4d | %16.3f | %16.3f | %16.3f" % (short(r[0]), r[1], r[2], r[3], r[4], r[5]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -501,8 +501,16 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   if (!fn) { fast = false; fn = generic_kernel(p->cmp, weighted, lds_hist); }
 
   // ---- geometry -----------------------------------------------------------------------------
+  // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
+  // (profiles/r01_a_sweep.jsonl) the streaming rate peaks at ~64 KiB of outstanding loads per CU
+  // (f64+weights: 2 x 256 threads x 128 B; f64: 4 x 256 x 64 B) and falls by 5-10% with more.
   int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? 1024 : 256);
-  int bpc = std::min<int>(2048 / block, 8);
+  int64_t lane_bytes = 0;
+  for (int d = 0; d < D; ++d) lane_bytes += dtype_size(samples[d].dtype);
+  if (weighted) lane_bytes += dtype_size(weights->dtype);
+  lane_bytes *= fast ? (int64_t)vec * kUnroll : 4;
+  int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
+  bpc = std::min<int>(bpc, 2048 / block);
   if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
   const int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc;
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
