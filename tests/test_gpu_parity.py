@@ -387,3 +387,57 @@ def test_full_size_c3_properties(xh, big):
     m = 3_000_000
     want = onp.bincount_rows([x[:m].cpu().numpy().reshape(1, -1), y[:m].cpu().numpy().reshape(1, -1)], [ea, eb])[0]
     np.testing.assert_array_equal(xh.histogram(x[:m], y[:m], bins=[ea, eb])[0].cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# packed-uint16 LDS mode (mid-size joint histograms): wrap bookkeeping must be exact
+# ---------------------------------------------------------------------------------------------
+def test_packed16_mode_wraps_are_exact(xh):
+    rng = np.random.default_rng(21)
+    edges = [np.linspace(0, 256, 257), np.linspace(0, 256, 257)]  # 65536 bins -> packed16 in LDS
+    n = 6_000_000
+    # heavy hitters: one even bin, its odd neighbour (same LDS word), the very last bin, plus noise
+    x = np.full(n, 10.5)
+    y = np.full(n, 20.5)          # flat = 10*256+20 (even)
+    y[1::3] = 21.5                # flat+1 (odd, same word): carries from the low half land here
+    x[2::7], y[2::7] = 255.5, 255.5  # last bin (odd half of the last word)
+    m = rng.integers(0, n, 200_000)
+    x[m] = rng.uniform(-5, 260, m.size)
+    y[m] = rng.uniform(-5, 260, m.size)
+    samples = [x.reshape(1, -1), y.reshape(1, -1)]
+    want = onp.bincount_rows(samples, edges)
+    got, desc = _run(xh, samples, edges, None, True)
+    assert "hist=packed16" in desc, desc
+    np.testing.assert_array_equal(got, want)
+    assert want.max() > 3 * 65536  # the test really wrapped 16-bit halves several times
+    # odd number of bins: the last word has an unused high half
+    e1 = [np.linspace(0, 1, 14_002)]  # 14001 bins + 128 KB of edge/bucket tables: uint32 no longer fits -> packed16
+    z = rng.uniform(-0.1, 1.1, (1, 3_000_000))
+    z[0, ::2] = 0.999999  # last bin, wraps
+    z[0, 1::4] = 0.0
+    got, desc = _run(xh, [z], e1, None, True)
+    assert "hist=packed16" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([z], e1))
+
+
+def test_f32_threshold_domain_is_exact_at_edges(xh):
+    """float32 samples are compared in float32 against thresholds thr = min{f32 >= edge}; probe
+    every float32 neighbour of every edge, where a rounding slip would move a sample"""
+    edges = np.linspace(-4, 4, 51)  # most edges are not float32-representable
+    e32 = edges.astype(np.float32)
+    pts = np.concatenate([e32, np.nextafter(e32, np.float32(np.inf)), np.nextafter(e32, np.float32(-np.inf)),
+                          np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 4.0, -4.0], dtype=np.float32)])
+    x = np.tile(pts, 300).astype(np.float32).reshape(3, -1)
+    want = onp.bincount_rows([x], [edges])
+    for resident in (False, True):
+        got, desc = _run(xh, [x], [edges], None, resident)
+        np.testing.assert_array_equal(got, want)
+    assert "cmp=f32thr" in desc, desc
+    # last edge not representable in float32: no float32 sample can equal it
+    e2 = np.array([0.0, 0.1, 0.30000000000000004])
+    x2 = np.array([[0.3, 0.30000001192092896, 0.29999998211860657, 0.1, 0.0]], dtype=np.float32)
+    np.testing.assert_array_equal(_run(xh, [x2], [e2], None, True)[0], onp.bincount_rows([x2], [e2]))
+    # huge / infinite edges
+    e3 = np.array([-1e300, -1.0, 1.0, 1e300])
+    x3 = np.array([[-np.inf, -3.4e38, -1.0, 0.0, 1.0, 3.4e38, np.inf, np.nan]], dtype=np.float32)
+    np.testing.assert_array_equal(_run(xh, [x3], [e3], None, True)[0], onp.bincount_rows([x3], [e3]))

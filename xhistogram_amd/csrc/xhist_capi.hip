@@ -83,9 +83,12 @@ struct xhist_plan {
   int device = 0;
   int n_dims = 0;
   int cmp = 0;
-  DimTable dim[kMaxDims];
+  DimTable dim[kMaxDims];   // native domain (float64 or int64)
   uint64_t* d_tables = nullptr;
   int32_t table_words = 0;
+  DimTable dimf[kMaxDims];  // float32-threshold domain (float64 plans only)
+  uint64_t* d_tables_f = nullptr;
+  int32_t table_words_f = 0;
   int64_t n_bins = 0;
   int cus = 256;
   size_t lds_max = 64 * 1024;
@@ -129,6 +132,113 @@ extern "C" int xhist_device_info(int device, char* name, size_t name_cap, int* c
   if (compute_units) *compute_units = prop.multiProcessorCount;
   if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
   return XHIST_OK;
+}
+
+// Build the device table blob of one compare domain:
+//   [per-dimension edge arrays, 8-byte aligned] [per-dimension bucket tables (uint32 x K)]
+// dom: 0 float64, 1 int64, 2 float32 thresholds.  `words[d]` holds dimension d's edge array
+// already converted to the domain's element type; `edges` are the caller's original arrays.
+static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_edges,
+                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, DimTable* dims,
+                        uint64_t** d_blob_out, int32_t* table_words_out) {
+  int32_t edge_off = 0;
+  int64_t max_e = 0;
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = dims[d];
+    memset(&t, 0, sizeof t);
+    const int E = (int)n_edges[d];
+    max_e = std::max<int64_t>(max_e, E);
+    t.n_edges = E;
+    t.nb = E - 1;
+    t.edge_off = edge_off;
+    edge_off += (int32_t)words[d].size();
+    double range;
+    if (dom == 0) {
+      const double* e = static_cast<const double*>(edges[d]);
+      t.e0_f = e[0];
+      t.eL_f = e[E - 1];
+      range = t.eL_f - t.e0_f;
+    } else if (dom == 1) {
+      const int64_t* e = static_cast<const int64_t*>(edges[d]);
+      t.e0_i = e[0];
+      t.eL_i = e[E - 1];
+      range = (double)((uint64_t)t.eL_i - (uint64_t)t.e0_i);
+    } else {
+      const double* e = static_cast<const double*>(edges[d]);
+      const float* thr = reinterpret_cast<const float*>(words[d].data());
+      float last = (float)e[E - 1];  // largest float32 <= e_last
+      if ((double)last > e[E - 1]) last = std::nextafterf(last, -INFINITY);
+      t.e0_f = (double)thr[0];
+      t.eL_f = (double)last;
+      range = (double)((float)t.eL_f - (float)t.e0_f);
+    }
+    int K = std::min(4096, std::max(8, next_pow2(4 * E)));
+    double scale = (double)K / range;
+    if (dom == 2) scale = (double)(float)scale;
+    if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
+      K = 1;  // degenerate span: one bucket holding every edge, pure binary search
+      scale = 0.0;
+    }
+    t.lut_k = K;
+    t.scale = scale;
+  }
+  int64_t stride = 1;
+  for (int d = n_inputs - 1; d >= 0; --d) {
+    dims[d].out_stride = stride;
+    stride *= dims[d].nb;
+  }
+  int32_t off4 = 2 * edge_off;
+  for (int d = 0; d < n_inputs; ++d) {
+    dims[d].lut_off = off4;
+    off4 += dims[d].lut_k;
+  }
+  const int32_t table_words = (off4 + 1) / 2;
+  std::vector<uint64_t> blob((size_t)table_words, 0);
+  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + dims[d].edge_off, words[d].data(), words[d].size() * 8);
+
+  uint64_t* d_blob = nullptr;
+  int32_t* d_scratch = nullptr;
+  auto cleanup = [&](int rc) {
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (rc != XHIST_OK && d_blob) (void)hipFree(d_blob);
+    return rc;
+  };
+#define HIPP(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  HIPP(hipMalloc(&d_blob, blob.size() * 8));
+  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
+  HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+  for (int d = 0; d < n_inputs; ++d) {
+    if (dom == 0) hipLaunchKernelGGL(build_tables<0>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (dom == 1) hipLaunchKernelGGL(build_tables<1>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else hipLaunchKernelGGL(build_tables<2>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    HIPP(hipGetLastError());
+    HIPP(hipDeviceSynchronize());
+  }
+  HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));
+#undef HIPP
+  const uint32_t* lut4 = reinterpret_cast<const uint32_t*>(blob.data());
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = dims[d];
+    uint32_t maxcnt = 0;
+    uint64_t total = 0;
+    for (int b = 0; b < t.lut_k; ++b) {
+      const uint32_t cnt = lut4[t.lut_off + b] >> 16;
+      maxcnt = std::max(maxcnt, cnt);
+      total += cnt;
+    }
+    if (total != (uint64_t)t.n_edges) return cleanup(fail(XHIST_ERR_HIP, "bucket table of dim %d is inconsistent", d));
+    int steps = 0;
+    while ((1u << steps) <= maxcnt) ++steps;
+    t.steps = steps;
+  }
+  (void)p;
+  *d_blob_out = d_blob;
+  *table_words_out = table_words;
+  return cleanup(XHIST_OK);
 }
 
 extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
@@ -180,110 +290,59 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
       p->lds_max = std::max(p->lds_max, (size_t)optin);
   }
 
-  // blob layout: [edges of dim 0..D-1 (8-byte words)] [bucket tables of dim 0..D-1 (4-byte words)]
-  int32_t edge_off = 0;
+  // ---- table sets: one per compare domain this plan can be asked for -----------------------
+  //   native (float64 or int64): every kernel family;  float32 thresholds: float32 fast family
   int64_t n_bins = 1;
   for (int d = 0; d < n_inputs; ++d) {
-    DimTable& t = p->dim[d];
-    memset(&t, 0, sizeof t);
-    const int E = (int)n_edges[d];
-    t.n_edges = E;
-    t.nb = E - 1;
-    t.edge_off = edge_off;
-    edge_off += E;
-    double range;
-    if (cmp_domain == XHIST_CMP_F64) {
-      const double* e = static_cast<const double*>(edges[d]);
-      t.e0_f = e[0];
-      t.eL_f = e[E - 1];
-      range = t.eL_f - t.e0_f;
-    } else {
-      const int64_t* e = static_cast<const int64_t*>(edges[d]);
-      t.e0_i = e[0];
-      t.eL_i = e[E - 1];
-      range = (double)((uint64_t)t.eL_i - (uint64_t)t.e0_i);
-    }
-    int K = std::min(4096, std::max(8, next_pow2(4 * E)));
-    double scale = (double)K / range;
-    if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
-      K = 1;  // degenerate span: one bucket holding every edge, pure binary search
-      scale = 0.0;
-    }
-    t.lut_k = K;
-    t.scale = scale;
-    if (t.nb > 0 && n_bins > (int64_t)1 << 40) {
+    const int64_t nb = n_edges[d] - 1;
+    if (nb > 0 && n_bins > (int64_t)1 << 40) {
       delete p;
       return fail(XHIST_ERR_UNSUPPORTED, "histogram has more than 2^40 bins");
     }
-    n_bins *= t.nb;
-  }
-  int64_t stride = 1;
-  for (int d = n_inputs - 1; d >= 0; --d) {
-    p->dim[d].out_stride = stride;
-    stride *= p->dim[d].nb;
+    n_bins *= nb;
   }
   p->n_bins = n_bins;
-  int32_t off4 = 2 * edge_off;
+  std::vector<std::vector<uint64_t>> words(n_inputs);
+  std::vector<double> lo(n_inputs), hi(n_inputs);
   for (int d = 0; d < n_inputs; ++d) {
-    p->dim[d].lut_off = off4;
-    off4 += p->dim[d].lut_k;
+    const int E = (int)n_edges[d];
+    words[d].assign((size_t)E, 0);
+    memcpy(words[d].data(), edges[d], (size_t)E * 8);
   }
-  p->table_words = (off4 + 1) / 2;
-
-  std::vector<uint64_t> blob((size_t)p->table_words, 0);
-  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + p->dim[d].edge_off, edges[d], (size_t)n_edges[d] * 8);
-
-  int32_t* d_scratch = nullptr;
-  auto cleanup = [&](int rc) {
-    if (d_scratch) (void)hipFree(d_scratch);
-    if (rc != XHIST_OK) {
-      if (p->d_tables) (void)hipFree(p->d_tables);
-      delete p;
+  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, n_inputs, n_edges, words, edges, p->dim, &p->d_tables, &p->table_words);
+  if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) {
+    // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
+    for (int d = 0; d < n_inputs; ++d) {
+      const int E = (int)n_edges[d];
+      const double* e = static_cast<const double*>(edges[d]);
+      std::vector<float> thr((size_t)E + 1, 0.0f);
+      for (int j = 0; j < E; ++j) {
+        float f = (float)e[j];
+        if ((double)f < e[j]) f = std::nextafterf(f, INFINITY);
+        thr[(size_t)j] = f;
+      }
+      words[d].assign(((size_t)E + 1) / 2, 0);
+      memcpy(words[d].data(), thr.data(), (size_t)E * 4);
     }
+    rc = build_domain(p, 2, n_inputs, n_edges, words, edges, p->dimf, &p->d_tables_f, &p->table_words_f);
+  }
+  if (rc != XHIST_OK) {
+    if (p->d_tables) (void)hipFree(p->d_tables);
+    if (p->d_tables_f) (void)hipFree(p->d_tables_f);
+    delete p;
     return rc;
-  };
-#define HIPP(expr)                                                                                     \
-  do {                                                                                                 \
-    hipError_t e_ = (expr);                                                                            \
-    if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
-  } while (0)
-  HIPP(hipMalloc(&p->d_tables, blob.size() * 8));
-  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
-  HIPP(hipMemcpy(p->d_tables, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
-  for (int d = 0; d < n_inputs; ++d) {
-    if (cmp_domain == XHIST_CMP_F64)
-      hipLaunchKernelGGL(build_tables<0>, dim3(1), dim3(256), 0, 0, p->dim[d], p->d_tables, d_scratch);
-    else
-      hipLaunchKernelGGL(build_tables<1>, dim3(1), dim3(256), 0, 0, p->dim[d], p->d_tables, d_scratch);
-    HIPP(hipGetLastError());
-    HIPP(hipDeviceSynchronize());
   }
-  HIPP(hipMemcpy(blob.data(), p->d_tables, blob.size() * 8, hipMemcpyDeviceToHost));
-  const uint32_t* lut4 = reinterpret_cast<const uint32_t*>(blob.data());
-  for (int d = 0; d < n_inputs; ++d) {
-    DimTable& t = p->dim[d];
-    uint32_t maxcnt = 0;
-    uint64_t total = 0;
-    for (int b = 0; b < t.lut_k; ++b) {
-      const uint32_t cnt = lut4[t.lut_off + b] >> 16;
-      maxcnt = std::max(maxcnt, cnt);
-      total += cnt;
-    }
-    if (total != (uint64_t)t.n_edges) return cleanup(fail(XHIST_ERR_HIP, "bucket table of dim %d is inconsistent", d));
-    int steps = 0;
-    while ((1u << steps) <= maxcnt) ++steps;
-    t.steps = steps;
-  }
-#undef HIPP
   *out_plan = p;
-  return cleanup(XHIST_OK);
+  return XHIST_OK;
 }
+
 
 extern "C" int xhist_plan_destroy(xhist_plan* p) {
   if (!p) return XHIST_OK;
   DeviceGuard g;
   if (g.set(p->device) == XHIST_OK) {
     if (p->d_tables) (void)hipFree(p->d_tables);
+    if (p->d_tables_f) (void)hipFree(p->d_tables_f);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   delete p;
@@ -356,41 +415,54 @@ extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n
 // ------------------------------------------------------------------------------------------
 typedef void (*kernel_fn)(const Params);
 
-constexpr int kUnroll = 4;
+// Samples a lane bins as one branch-free batch = VEC x UNROLL; capped by register pressure
+// (D digitize states per sample must stay in VGPRs: 16 / 8 / 4 samples for D = 1 / 2 / 3).
+constexpr int unroll_for(int D, int vec) {
+  const int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
+  const int u = cap / vec < 1 ? 1 : cap / vec;
+  return u > 4 ? 4 : u;
+}
 
 template <typename ST, typename WT, int D>
-static kernel_fn fast_pick(bool lds) {
-  constexpr int wsz = std::is_same<WT, NoWeight>::value ? 0 : (int)sizeof(typename std::conditional<std::is_same<WT, NoWeight>::value, float, WT>::type);
+static kernel_fn fast_pick(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
-  return lds ? (kernel_fn)hist_fast<ST, WT, D, VEC, kUnroll, true> : (kernel_fn)hist_fast<ST, WT, D, VEC, kUnroll, false>;
+  constexpr int U = unroll_for(D, VEC);
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked>;
+    else return nullptr;
+  }
+  return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal>;
 }
 
 template <typename ST, typename WT>
-static kernel_fn fast_pick_d(int D, bool lds) {
+static kernel_fn fast_pick_d(int D, int hist) {
   switch (D) {
-    case 1: return fast_pick<ST, WT, 1>(lds);
-    case 2: return fast_pick<ST, WT, 2>(lds);
-    case 3: return fast_pick<ST, WT, 3>(lds);
+    case 1: return fast_pick<ST, WT, 1>(hist);
+    case 2: return fast_pick<ST, WT, 2>(hist);
+    case 3: return fast_pick<ST, WT, 3>(hist);
     default: return nullptr;
   }
 }
 
 template <typename ST>
-static kernel_fn fast_pick_w(int wdt, int D, bool lds) {
+static kernel_fn fast_pick_w(int wdt, int D, int hist) {
   switch (wdt) {
-    case -1: return fast_pick_d<ST, NoWeight>(D, lds);
-    case XHIST_F64: return fast_pick_d<ST, double>(D, lds);
-    case XHIST_F32: return fast_pick_d<ST, float>(D, lds);
+    case -1: return fast_pick_d<ST, NoWeight>(D, hist);
+    case XHIST_F64: return fast_pick_d<ST, double>(D, hist);
+    case XHIST_F32: return fast_pick_d<ST, float>(D, hist);
     default: return nullptr;
   }
 }
 
-static kernel_fn fast_kernel(int sdt, int wdt, int D, bool lds, int* vec) {
+static kernel_fn fast_kernel(int sdt, int wdt, int D, int hist, int* vec) {
   const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
   *vec = 16 / std::max(ssz, wsz);
   switch (sdt) {
-    case XHIST_F64: return fast_pick_w<double>(wdt, D, lds);
-    case XHIST_F32: return fast_pick_w<float>(wdt, D, lds);
+    case XHIST_F64: return fast_pick_w<double>(wdt, D, hist);
+    case XHIST_F32: return fast_pick_w<float>(wdt, D, hist);
     default: return nullptr;
   }
 }
@@ -454,51 +526,72 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   }
 
   // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
-  const size_t table_bytes = (size_t)p->table_words * 8;
   const size_t lds_cap = p->lds_max;
-  const bool tables_fit = table_bytes + 1024 <= lds_cap;
-  bool fast = !force_generic && p->cmp == XHIST_CMP_F64 && D <= 3 && tables_fit && p->n_bins < ((int64_t)1 << 31);
-  int vec = 1;
   const int sdt = samples[0].dtype;
   const int wdt = weighted ? weights->dtype : -1;
+  int vec = 1;
+  bool fast = !force_generic && p->cmp == XHIST_CMP_F64 && D <= 3 && p->n_bins < ((int64_t)1 << 31) &&
+              (sdt == XHIST_F64 || sdt == XHIST_F32) && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32);
   if (fast) {
-    fast = (sdt == XHIST_F64 || sdt == XHIST_F32) && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32);
-    if (fast) {
-      vec = 16 / std::max(dtype_size(sdt), wdt < 0 ? 0 : dtype_size(wdt));
-      for (int d = 0; d < D && fast; ++d) {
-        const xhist_array& a = samples[d];
-        fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)(vec * dtype_size(sdt)) == 0) &&
-               (n_rows == 1 || a.row_stride % vec == 0);
-      }
-      if (fast && weighted)
-        fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)(vec * dtype_size(wdt)) == 0) &&
-               (n_rows == 1 || weights->row_stride % vec == 0);
+    vec = 16 / std::max(dtype_size(sdt), wdt < 0 ? 0 : dtype_size(wdt));
+    for (int d = 0; d < D && fast; ++d) {
+      const xhist_array& a = samples[d];
+      fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)(vec * dtype_size(sdt)) == 0) &&
+             (n_rows == 1 || a.row_stride % vec == 0);
     }
+    if (fast && weighted)
+      fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)(vec * dtype_size(wdt)) == 0) &&
+             (n_rows == 1 || weights->row_stride % vec == 0);
   }
+  // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
+  bool use_f32 = fast && sdt == XHIST_F32 && p->d_tables_f != nullptr;
+  size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  if (fast && table_bytes + 1024 > lds_cap) {  // the fast family keeps its tables in LDS
+    fast = false;
+    use_f32 = false;
+    table_bytes = (size_t)p->table_words * 8;
+  }
+  const bool tables_fit = table_bytes + 1024 <= lds_cap;
 
-  // ---- histogram placement: LDS sub-histograms (replicated per lane bank) or global atomics ---
+  // ---- histogram placement -------------------------------------------------------------------
+  //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
+  //   packed: unweighted fast family only, uint16 counters packed two per word (exact, see kernel)
+  //   global: device-scope atomics straight into the output
   const int acc_size = weighted ? 8 : 4;
   const int max_cl2 = weighted ? 4 : 5;
-  bool lds_hist = !force_global && tables_fit && p->n_bins < ((int64_t)1 << 24);
+  int hist = kHistGlobal;
   int cl2 = 0;
   size_t hist_bytes = 0;
-  if (lds_hist) {
-    const size_t soft = 24 * 1024;  // keeps >= 6 workgroups of 256 threads resident per CU
+  if (!force_global && tables_fit && p->n_bins < ((int64_t)1 << 24)) {
+    const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
     cl2 = max_cl2;
     if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
     auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
     if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
     while (cl2 > 0 && table_bytes + bytes_at(cl2) > lds_cap) --cl2;
-    hist_bytes = bytes_at(cl2);
-    if (table_bytes + hist_bytes > lds_cap) lds_hist = false;
+    if (table_bytes + bytes_at(cl2) <= lds_cap) {
+      hist = kHistLds;
+      hist_bytes = bytes_at(cl2);
+    } else if (fast && !weighted && table_bytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
+      hist = kHistPacked;
+      cl2 = 0;
+      hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+    }
   }
-  if (!lds_hist) { cl2 = 0; hist_bytes = 0; }
+  if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
+  const bool lds_hist = hist == kHistLds;
   const bool tables_in_lds = tables_fit;
   const size_t lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
 
   kernel_fn fn = nullptr;
-  if (fast) fn = fast_kernel(sdt, wdt, D, lds_hist, &vec);
-  if (!fn) { fast = false; fn = generic_kernel(p->cmp, weighted, lds_hist); }
+  if (fast) fn = fast_kernel(sdt, wdt, D, hist, &vec);
+  if (!fn) {
+    if (hist == kHistPacked) return fail(XHIST_ERR_HIP, "internal: packed histogram without a fast kernel");
+    fast = false;
+    fn = generic_kernel(p->cmp, weighted, lds_hist);
+  }
+  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  const int kUnroll = fast ? unroll_for(D, vec) : 1;
 
   // ---- geometry -----------------------------------------------------------------------------
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
@@ -515,7 +608,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc;
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
   const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
-  if (lds_bytes > 64 * 1024) HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  if (lds_bytes > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
   // rows per launch bounded by the grid limit; columns per launch bounded so that no workgroup
   // can overflow a uint32 LDS counter (< 2^31 samples per workgroup per launch)
@@ -543,7 +636,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         kp.s_rs[d] = a.row_stride;
         kp.s_cs[d] = a.col_stride;
         kp.s_dt[d] = a.dtype;
-        kp.dim[d] = p->dim[d];
+        kp.dim[d] = dims[d];
       }
       if (weighted) {
         kp.w_ptr = advance(weights->data, weights->dtype, r0 * weights->row_stride + c0 * weights->col_stride);
@@ -552,8 +645,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         kp.w_dt = weights->dtype;
       }
       kp.n_dims = D;
-      kp.tables = p->d_tables;
-      kp.table_words = p->table_words;
+      kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
+      kp.table_words = use_f32 ? p->table_words_f : p->table_words;
       kp.tables_in_lds = tables_in_lds ? 1 : 0;
       kp.n_rows = nr;
       kp.n_cols = nc;
@@ -572,10 +665,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       if (first_launch) {
         snprintf(desc, sizeof desc,
                  "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
-                 "lut_k0=%d steps0=%d weighted=%d D=%d",
-                 fast ? "fast" : "generic", lds_hist ? "lds" : "global", fast ? vec : 1, fast ? kUnroll : 1, block,
-                 (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2, table_bytes, p->dim[0].lut_k, p->dim[0].steps,
-                 (int)weighted, D);
+                 "lut_k0=%d steps0=%d weighted=%d D=%d cmp=%s lds_cap=%zu",
+                 fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
+                 fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
+                 table_bytes, dims[0].lut_k, dims[0].steps, (int)weighted, D,
+                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : "f64"), lds_cap);
       }
       first_launch = false;
       r0 += nr;

@@ -98,11 +98,28 @@ struct Dom<1> {  // exact int64 compares (integer / datetime64 samples against i
   }
 };
 
+template <>
+struct Dom<2> {  // float32 samples against float64 edges, compared EXACTLY in float32:
+  // the table holds thr_j = the smallest float32 >= e_j, so for every float32 x
+  //   (double)x >= e_j  <=>  x >= thr_j ;   e0_f = thr_0,  eL_f = the largest float32 <= e_last
+  // (both exactly representable, kept in the double fields of DimTable)
+  using T = float;
+  static __device__ __forceinline__ bool in_range(float x, const DimTable& t) {
+    return (x >= (float)t.e0_f) & (x <= (float)t.eL_f);
+  }
+  static __device__ __forceinline__ float offset(float x, const DimTable& t) { return x - (float)t.e0_f; }
+};
+
 // Monotone bucket index in [0, K-1] for ANY x (NaN -> 0).  Used by the table builder (on the
 // edges) and by digitize (on the samples): the two must be the same code.
 template <int CMP>
 __device__ __forceinline__ int bucket_of(typename Dom<CMP>::T x, const DimTable& t) {
-  double tt = Dom<CMP>::offset(x, t) * t.scale;
+  if (CMP == 2) {  // all-float32 arithmetic (full-rate VALU); any monotone map is valid
+    float tt = (float)Dom<CMP>::offset(x, t) * (float)t.scale;
+    tt = fmaxf(fminf(tt, (float)(t.lut_k - 1)), 0.0f);
+    return (int)tt;
+  }
+  double tt = (double)Dom<CMP>::offset(x, t) * t.scale;
   tt = fmax(fmin(tt, (double)(t.lut_k - 1)), 0.0);  // fmin/fmax drop a NaN operand
   return (int)tt;
 }
@@ -223,8 +240,24 @@ __device__ __forceinline__ const uint64_t* stage_tables(const Params& p) {
 template <typename T, int N>
 struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
 
-template <typename ST, typename WT, int D, int VEC, int UNROLL, bool LDS_HIST>
+// HIST: where a workgroup accumulates
+//   kHistGlobal  device-scope atomics straight into the output (histogram too large for LDS)
+//   kHistLds     replicated sub-histograms in LDS, one copy per lane bank (uint32 / float64)
+//   kHistPacked  unweighted only: ONE sub-histogram of uint16 counters packed two per LDS word,
+//                which lets a 256x256 joint histogram (128 KiB) live in the 160 KiB LDS of a CU.
+//                Exactness under overflow: every increment is a RETURNING ds_add; the lane whose
+//                own add wraps a 16-bit half (it sees the old half == 0xFFFF) books the lost 2^16
+//                to the output with a global atomic, and when the wrapped half is the low one it
+//                also books -1 to the neighbour bin whose half received the carry (and that
+//                half's own wrap if the carry caused one).  Word values are sums of addends mod
+//                2^32, so the result is independent of interleaving: no timing assumption.
+constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
+
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
+  constexpr bool LDS_HIST = HIST == kHistLds;
+  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  using CT = typename Dom<CMP>::T;
   using A = Acc<WT>;
   using lds_t = typename A::lds_t;
   using out_t = typename A::out_t;
@@ -242,9 +275,14 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   const uint32_t cmask = (1u << p.copies_log2) - 1u;
   const uint32_t mycopy = (uint32_t)tid & cmask;
   const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
+  uint32_t* packed = reinterpret_cast<uint32_t*>(hist);
   if (LDS_HIST) {
     const uint32_t n = ((uint32_t)p.n_bins + 1u) << p.copies_log2;
     for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
+  }
+  if (HIST == kHistPacked) {
+    const uint32_t n = ((uint32_t)p.n_bins + 1u) >> 1;
+    for (uint32_t i = tid; i < n; i += blockDim.x) packed[i] = 0u;
   }
   __syncthreads();
 
@@ -262,6 +300,26 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     } else if (ok) {
       if (kWeighted) A::out_add(out, (int64_t)flat, w);
       else A::out_add(out, (int64_t)flat, 1);
+    }
+  };
+  // packed mode, step 1: returning add of 1 into the sample's 16-bit half (0 for a dropped sample)
+  auto packed_add = [&](bool ok, uint32_t flat) -> uint32_t {
+    const uint32_t idx = ok ? (flat >> 1) : 0u;
+    const uint32_t inc = ok ? (1u << ((flat & 1u) << 4)) : 0u;
+    return atomicAdd(packed + idx, inc);
+  };
+  // packed mode, step 2: book the wraps this lane's own add caused (rare)
+  auto packed_fix = [&](bool ok, uint32_t flat, uint32_t old) {
+    if (!ok) return;
+    const bool hi = flat & 1u;
+    const uint32_t half = hi ? (old >> 16) : (old & 0xffffu);
+    if (half == 0xffffu) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(out) + flat, 65536ull);
+      if (!hi && (int64_t)flat + 1 < p.n_bins) {  // the carry landed in the neighbour's half
+        unsigned long long fix = ~0ull;            // -1
+        if ((old >> 16) == 0xffffu) fix += 65536ull;  // ...and wrapped it too
+        atomicAdd(reinterpret_cast<unsigned long long*>(out) + flat + 1, fix);
+      }
     }
   };
   int max_steps = 1;
@@ -290,7 +348,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
 #pragma unroll
-          for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<0>((double)xv[d][u][v], p.dim[d], tab);
+          for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
       // wave-uniform extra rounds when some bucket holds several edges (non-uniform / duplicate
       // edges); a round is a no-op for a sample whose bucket is already decided (len == 0)
 #pragma unroll 1
@@ -300,8 +358,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v)
 #pragma unroll
-            for (int d = 0; d < D; ++d) upper_bound_step<0>((double)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
+            for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
       }
+      bool okv[UNROLL][VEC];
+      uint32_t flatv[UNROLL][VEC], oldv[UNROLL][VEC];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -314,20 +374,45 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
             ok &= (b >= 0);
             flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
           }
-          scatter(ok, flat, kWeighted ? (double)wv[u][v] : 0.0);
+          if (HIST == kHistPacked) {
+            okv[u][v] = ok;
+            flatv[u][v] = flat;
+            oldv[u][v] = packed_add(ok, flat);
+          } else {
+            scatter(ok, flat, kWeighted ? (double)wv[u][v] : 0.0);
+          }
         }
+      if (HIST == kHistPacked) {  // all returning adds are in flight before the first check
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) packed_fix(okv[u][v], flatv[u][v], oldv[u][v]);
+      }
     } else {  // ragged last tile: scalar, bounds-checked
       for (int64_t i = base + tid; i < p.n_cols; i += blockDim.x) {
         bool ok = true;
         uint32_t flat = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const int b = digitize<0>((double)sp[d][i], p.dim[d], tab);
+          const int b = digitize<CMP>((CT)sp[d][i], p.dim[d], tab);
           ok &= (b >= 0);
           flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
         }
-        scatter(ok, flat, kWeighted ? (double)wp[i] : 0.0);
+        if (HIST == kHistPacked) packed_fix(ok, flat, packed_add(ok, flat));
+        else scatter(ok, flat, kWeighted ? (double)wp[i] : 0.0);
       }
+    }
+  }
+
+  if (HIST == kHistPacked) {
+    __syncthreads();
+    const uint32_t n = ((uint32_t)p.n_bins + 1u) >> 1;
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+      const uint32_t word = packed[i];
+      const uint32_t lo = word & 0xffffu, hi = word >> 16;
+      if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * (int64_t)i, (unsigned long long)lo);
+      if (hi && 2 * (int64_t)i + 1 < p.n_bins)
+        atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * (int64_t)i + 1, (unsigned long long)hi);
     }
   }
 
