@@ -1,0 +1,36 @@
+"""dask branch of core.histogram (the reference's blockwise + sum graph, core.py:403-439).
+The default interpreter has no dask; the image's conda python 3.9 does, and the package needs
+only numpy + ctypes, so the checks run there in a subprocess (skipped if it is absent)."""
+import os
+import subprocess
+
+import pytest
+
+PY39 = "/opt/conda/bin/python3.9"
+SCRIPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dask_branch_script.py")
+
+
+def _have_dask_python():
+    if not os.path.exists(PY39):
+        return False
+    return subprocess.run([PY39, "-c", "import dask.array, numpy"], capture_output=True).returncode == 0
+
+
+needs = pytest.mark.skipif(not _have_dask_python(), reason="no interpreter with dask in this image")
+
+
+def _run(mode):
+    r = subprocess.run([PY39, "-W", "ignore", SCRIPT, mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+@needs
+def test_dask_graph_is_lazy_and_shaped_like_the_reference():
+    assert "LAZY-OK" in _run("lazy")
+
+
+@needs
+@pytest.mark.gpu
+def test_dask_blocks_compute_on_gpu():
+    assert "COMPUTE-OK" in _run("compute")

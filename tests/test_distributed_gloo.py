@@ -1,0 +1,135 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` process groups run the sharding / collective logic of
+xhistogram_amd.distributed with the rank-local compute swapped for the oracle (test double; the
+product default is the HIP path and is covered by the gpu-marked test at the bottom)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_local(arrays, has_weights, axis, edges, block_size):
+    from oracle import oracle_np as onp
+
+    arrs = [a.numpy() if hasattr(a, "numpy") else np.asarray(a) for a in arrays]
+    w = arrs.pop() if has_weights else None
+    return onp.block_adapter(arrs, edges, w, axis)
+
+
+CASES = {
+    # name: (shape, n_args, kwargs, shard_axis, use_torch)
+    "full_reduce_1d_weighted": ((1001,), 1, dict(bins=np.linspace(-4, 4, 101), weights=True), 0, True),
+    "full_reduce_2d_hist": ((37, 41), 2, dict(bins=[np.linspace(-4, 4, 10), np.linspace(-3, 3, 8)]), 0, False),
+    "reduced_axis_shard_keep_rows": ((6, 101), 1, dict(bins=np.linspace(-4, 4, 21), axis=1), 1, True),
+    "kept_axis_shard_c4_like": ((7, 8, 9), 1, dict(bins=np.linspace(-4, 4, 51), axis=(1, 2)), 0, True),
+    "kept_axis_shard_middle": ((5, 7, 6), 1, dict(bins=np.linspace(-4, 4, 11), axis=(0, 2)), 1, False),
+    "bins_int_global_minmax": ((1001,), 1, dict(bins=17), 0, True),
+    "bins_int_range_density": ((64, 33), 1, dict(bins=9, range=(-2, 2), density=True, axis=1, weights=True), 1, False),
+    "density_full": ((500,), 1, dict(bins=np.linspace(-4, 4, 13), density=True), 0, True),
+}
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle_np as onp
+        from xhistogram_amd import distributed as xd
+
+        shape, n_args, kw, shard_axis, use_torch = CASES[case]
+        rng = np.random.default_rng(99)
+        full = [rng.standard_normal(shape) for _ in range(n_args)]
+        kw = dict(kw)
+        wfull = rng.uniform(0, 1, shape) if kw.pop("weights", False) else None
+        lo, hi = xd.shard_bounds(shape[shard_axis], world, rank)
+        sl = [slice(None)] * len(shape)
+        sl[shard_axis] = slice(lo, hi)
+        conv = (lambda a: torch.from_numpy(np.ascontiguousarray(a))) if use_torch else (lambda a: a)
+        mine = [conv(a[tuple(sl)]) for a in full]
+        wmine = None if wfull is None else conv(wfull[tuple(sl)])
+        h, edges = xd.histogram(*mine, weights=wmine, shard_axis=shard_axis, _local=_oracle_local, **kw)
+        want, wedges = onp.histogram(*full, weights=wfull, **kw)
+        h = h.numpy() if hasattr(h, "numpy") else np.asarray(h)
+        ok = h.shape == want.shape and np.allclose(h, want, rtol=1e-12, atol=0, equal_nan=True)
+        ok = ok and all(np.array_equal(a, b) for a, b in zip(edges, wedges))
+        if want.dtype.kind in "iu":
+            ok = ok and h.dtype.kind in "iu" and np.array_equal(h, want)
+        q.put((rank, bool(ok), "" if ok else "shape %s vs %s" % (h.shape, want.shape)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_world2_gloo(case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, "rank %d: %s" % (rank, msg)
+
+
+def test_shard_bounds_cover_everything():
+    from xhistogram_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 8, 3650, 10**9):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.gpu
+def test_single_rank_nccl_group_uses_hip_path():
+    """world_size 1 on a real GPU: the default rank-local compute is the HIP kernel and the
+    RCCL all-reduce / all-gather paths run end to end"""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_np as onp
+    from xhistogram_amd import distributed as xd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((16, 5000)).astype(np.float32)
+        w = rng.uniform(0, 1, (16, 5000))
+        edges = np.linspace(-4, 4, 51)
+        xt, wt = torch.as_tensor(x).cuda(), torch.as_tensor(w).cuda()
+        h, _ = xd.histogram(xt, bins=edges, axis=1, shard_axis=0)  # kept-axis shards -> gather
+        np.testing.assert_array_equal(h.cpu().numpy(), onp.histogram(x, bins=edges, axis=1)[0])
+        h, _ = xd.histogram(xt, bins=edges, weights=wt, shard_axis=1)  # reduced-axis shards -> all-reduce
+        np.testing.assert_allclose(h.cpu().numpy(), onp.histogram(x, bins=edges, weights=w)[0], rtol=1e-6)
+        h, e = xd.histogram(xt, bins=23)  # global min/max on device
+        want, we = onp.histogram(x, bins=23)
+        np.testing.assert_array_equal(e[0], we[0])
+        np.testing.assert_array_equal(h.cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,122 @@
+"""Label handling of xhistogram_amd.xarray.histogram, restating the reference's test_xarray.py
+known answers (dims, coords = bin centres, name, keep_coords, weights broadcast, errors).
+
+CPU tests swap the compute for the oracle (the wrapper does no arithmetic besides bin centres);
+the gpu-marked test runs the same wrapper over the HIP path.  Uses the real xarray if present,
+else the small double in tests/doubles/."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+try:
+    import xarray as xr  # noqa: F401
+except ImportError:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "doubles"))
+    import xarray as xr  # the double
+
+from oracle import oracle_np as onp
+
+xhx = importlib.import_module("xhistogram_amd.xarray")
+
+
+@pytest.fixture
+def cpu_compute(monkeypatch):
+    monkeypatch.setattr(xhx, "_core_histogram", onp.histogram)
+
+
+def _ones(dims, shape, name="T", with_coords=True):
+    coords = {d: np.arange(n) * 10.0 for d, n in zip(dims, shape)} if with_coords else None
+    return xr.DataArray(np.ones(shape), dims=dims, coords=coords, name=name, attrs={"units": "K"})
+
+
+@pytest.mark.parametrize("ndims", [1, 2, 3, 4])
+def test_ones_every_dim_combination(cpu_compute, ndims):  # test_xarray.py:38-67
+    from itertools import combinations
+
+    dims = ["x", "y", "z", "t"][:ndims]
+    shape = (3, 4, 5, 6)[:ndims]
+    da = _ones(dims, shape)
+    bins = np.array([0.0, 0.9, 1.1, 2.0])
+    centres = 0.5 * (bins[:-1] + bins[1:])
+    h = xhx.histogram(da, bins=[bins])
+    assert h.dims == ("T_bin",) and h.name == "histogram_T"
+    np.testing.assert_array_equal(h.values, [0, da.values.size, 0])
+    np.testing.assert_array_equal(h["T_bin"].values, centres)
+    assert h["T_bin"].attrs == {"units": "K"}
+    for k in range(1, ndims + 1):
+        for red in combinations(dims, k):
+            h = xhx.histogram(da, bins=[bins], dim=red)
+            kept = [d for d in dims if d not in red]
+            assert list(h.dims) == kept + ["T_bin"]
+            n_red = int(np.prod([s for d, s in zip(dims, shape) if d in red]))
+            want = np.zeros([s for d, s in zip(dims, shape) if d not in red] + [3])
+            want[..., 1] = n_red
+            np.testing.assert_array_equal(h.values, want)
+            for d in kept:  # dimension coordinates of kept dims are carried over
+                np.testing.assert_array_equal(h[d].values, da[d].values)
+
+
+def test_weights_of_every_sub_dimensionality(cpu_compute):  # test_xarray.py:99-135
+    da = _ones(["x", "y", "z"], (3, 4, 5))
+    bins = np.array([0.0, 0.9, 1.1, 2.0])
+    for wdims, wshape in ((["x"], (3,)), (["y", "z"], (4, 5)), (["z", "x"], (5, 3)), (["x", "y", "z"], (3, 4, 5))):
+        w = xr.DataArray(0.5 * np.ones(wshape), dims=wdims, name="w")
+        h = xhx.histogram(da, bins=[bins], weights=w)
+        np.testing.assert_allclose(h.values, [0, 0.5 * 60, 0])
+        h = xhx.histogram(da, bins=[bins], weights=w, dim=["y", "z"])
+        assert list(h.dims) == ["x", "T_bin"]
+        np.testing.assert_allclose(h.values[:, 1], 0.5 * 20)
+
+
+def test_two_args_dims_order_and_name(cpu_compute):  # test_xarray.py:139-173 (issue #5)
+    rng = np.random.default_rng(0)
+    a = xr.DataArray(rng.standard_normal((4, 5, 6)), dims=["t", "y", "x"], name="a")
+    b = xr.DataArray(rng.standard_normal((5, 6)), dims=["y", "x"], name="b")  # broadcast over t
+    ba, bb = np.linspace(-3, 3, 7), np.linspace(-3, 3, 5)
+    h = xhx.histogram(a, b, bins=[ba, bb], dim=["y", "x"])
+    assert list(h.dims) == ["t", "a_bin", "b_bin"] and h.name == "histogram_a_b"
+    want = np.stack([np.histogram2d(a.values[i].ravel(), b.values.ravel(), bins=[ba, bb])[0] for i in range(4)])
+    np.testing.assert_array_equal(h.values, want)
+    h2 = xhx.histogram(a, b, bins=[ba, bb], bin_dim_suffix="_edges")
+    assert list(h2.dims) == ["a_edges", "b_edges"]
+
+
+def test_keep_coords(cpu_compute):  # test_xarray.py:176-211
+    da = xr.DataArray(np.ones((3, 4)), dims=["x", "y"], name="T",
+                      coords={"x": np.arange(3.0), "y": np.arange(4.0), "lon": (("x",), np.array([7.0, 8.0, 9.0])),
+                              "area": (("x", "y"), np.ones((3, 4)))})
+    bins = np.array([0.0, 2.0])
+    h = xhx.histogram(da, bins=[bins], dim=["y"])
+    assert "lon" not in h.coords and "area" not in h.coords
+    h = xhx.histogram(da, bins=[bins], dim=["y"], keep_coords=True)
+    assert "lon" in h.coords and "area" not in h.coords  # area spans the reduced dim
+    np.testing.assert_array_equal(h["lon"].values, [7.0, 8.0, 9.0])
+
+
+def test_errors(cpu_compute):  # test_xarray.py:215-218, xarray.py:116-117, 126
+    with pytest.raises(TypeError):
+        xhx.histogram(np.ones(3), bins=[np.linspace(0, 1, 3)])
+    with pytest.raises(AssertionError):
+        xhx.histogram(xr.DataArray(np.ones(3), dims=["x"]), bins=[np.linspace(0, 1, 3)])
+    a = xr.DataArray(np.ones(3), dims=["x"], coords={"x": [0.0, 1.0, 2.0]}, name="a")
+    b = xr.DataArray(np.ones(3), dims=["x"], coords={"x": [0.0, 1.0, 5.0]}, name="b")
+    with pytest.raises(ValueError):
+        xhx.histogram(a, b, bins=[np.linspace(0, 2, 3)] * 2)
+
+
+@pytest.mark.gpu
+def test_wrapper_over_hip_path():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    t = rng.standard_normal((6, 40, 50)).astype(np.float32)
+    bins = np.linspace(-4, 4, 51)
+    da = xr.DataArray(t, dims=["time", "lat", "lon"], name="T", coords={"time": np.arange(6.0)})
+    h = xhx.histogram(da, bins=[bins], dim=["lat", "lon"])
+    assert list(h.dims) == ["time", "T_bin"]
+    np.testing.assert_array_equal(h.values, onp.histogram(t, bins=bins, axis=(1, 2))[0])
+    dg = xr.DataArray(torch.as_tensor(t).cuda(), dims=["time", "lat", "lon"], name="T")  # GPU-resident data
+    hg = xhx.histogram(dg, bins=[bins], dim=["lat", "lon"])
+    np.testing.assert_array_equal(hg.values, h.values)
