@@ -1,0 +1,112 @@
+"""Host-side logic of xhistogram_amd.core that needs no GPU: argument formatters (the reference's
+tables, test_core.py:316-362), the [rows, cols] arrangement (views, no copies), compare-domain
+selection (numpy's promotion rules), strided views handed to the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from xhistogram_amd import _native, core
+
+bins_int, bins_str, bins_arr, range_ = 10, "auto", np.linspace(-4, 4, 10), (0, 1)
+
+
+@pytest.mark.parametrize(
+    "bins_in,n,expected",
+    [
+        (bins_int, 1, [bins_int]), (bins_str, 1, [bins_str]), (bins_arr, 1, [bins_arr]), ([bins_int], 1, [bins_int]),
+        (bins_int, 2, 2 * [bins_int]), (bins_str, 2, 2 * [bins_str]), (bins_arr, 2, 2 * [bins_arr]),
+        ([bins_int, bins_str, bins_arr], 3, [bins_int, bins_str, bins_arr]),
+        ([bins_arr], 2, None), (None, 1, None), ([bins_arr, bins_arr], 1, None),
+    ],
+)
+def test_format_bins(bins_in, n, expected):  # test_core.py:316-340
+    if expected is None:
+        with pytest.raises((ValueError, TypeError)):
+            core._ensure_correctly_formatted_bins(bins_in, n)
+    else:
+        got = core._ensure_correctly_formatted_bins(bins_in, n)
+        assert len(got) == len(expected) and all(g is e or g == e for g, e in zip(got, expected))
+
+
+@pytest.mark.parametrize(
+    "range_in,n,expected",
+    [(range_, 1, [range_]), (range_, 2, [range_, range_]), ([range_, range_], 2, [range_, range_]),
+     ([(range_[0],)], 1, None), ([range_], 2, None), ([range_, range_], 1, None)],
+)
+def test_format_range(range_in, n, expected):  # test_core.py:343-362
+    if expected is None:
+        with pytest.raises(ValueError):
+            core._ensure_correctly_formatted_range(range_in, n)
+    else:
+        assert core._ensure_correctly_formatted_range(range_in, n) == expected
+    assert core._ensure_correctly_formatted_range(None, 3) == [None, None, None]
+
+
+def test_rows_cols_matches_reference_layout_without_copies():
+    x = np.arange(3 * 4 * 5 * 6, dtype=np.float64).reshape(3, 4, 5, 6)
+    for axis in ([3], [2, 3], [0], [1, 3], [3, 1], [0, 1, 2], [2, 0]):
+        got = core._rows_cols(x, axis, False)
+        np.testing.assert_array_equal(got, onp.to_rows_cols(x, axis))
+    assert np.shares_memory(core._rows_cols(x, [2, 3], False), x)  # trailing axes: a view (C4's case)
+    assert np.shares_memory(core._rows_cols(x, None, True), x)
+    w = np.broadcast_to(np.arange(6.0), (3, 4, 5, 6))  # stride-0 weights stay stride-0
+    v = core._rows_cols(w, [3], False)
+    assert v.shape == (60, 6) and v.strides == (0, 8)
+    ptr, tag, rs, cs, keep = core._strided_view(v, "numpy")
+    assert (tag, rs, cs) == (_native.F64, 0, 1) and ptr == w.ctypes.data
+    col = np.broadcast_to(np.arange(5.0)[:, None], (5, 7))  # column broadcast: cs == 0
+    assert core._strided_view(col, "numpy")[2:4] == (1, 0)
+    neg = x[0, 0][:, ::-1]  # negative stride: one contiguous copy
+    ptr, tag, rs, cs, keep = core._strided_view(neg, "numpy")
+    assert (rs, cs) == (6, 1) and not np.shares_memory(keep, x)
+    np.testing.assert_array_equal(keep, neg)
+
+
+def test_compare_domain_follows_numpy_promotion():
+    f64, f32, i64, i32, u8 = (np.dtype(t) for t in (np.float64, np.float32, np.int64, np.int32, np.uint8))
+    e_f = np.linspace(0, 1, 3)
+    e_i = np.array([0, 5, 10])
+    assert core._compare_domain([f64], [e_f])[0] == _native.CMP_F64
+    assert core._compare_domain([f32], [e_f])[0] == _native.CMP_F64
+    assert core._compare_domain([i64], [e_f])[0] == _native.CMP_F64  # numpy rounds int64 to float64 here too
+    assert core._compare_domain([f32], [e_i])[0] == _native.CMP_F64
+    dom, conv, _ = core._compare_domain([i64], [e_i])
+    assert dom == _native.CMP_I64 and conv[0].dtype == np.int64
+    assert core._compare_domain([i32, u8], [e_i, e_i.astype(np.int16)])[0] == _native.CMP_I64
+    assert core._compare_domain([i32, f64], [e_i.astype(np.int32), e_f])[0] == _native.CMP_F64  # small ints are exact in f64
+    with pytest.raises(NotImplementedError):
+        core._compare_domain([i64, f64], [e_i, e_f])
+    t = np.array(["2000-01-01", "2001-01-01"], dtype="datetime64[D]")
+    dom, conv, common = core._compare_domain([np.dtype("datetime64[ns]")], [t])
+    assert dom == _native.CMP_I64 and common[0] == np.dtype("datetime64[ns]")
+    assert conv[0][0] == np.datetime64("2000-01-01", "ns").astype(np.int64)
+    with pytest.raises(TypeError):
+        core._compare_domain([np.dtype(np.complex128)], [e_f])
+    with pytest.raises(TypeError):
+        core._compare_domain([np.dtype("datetime64[ns]")], [e_f])
+    with pytest.raises(NotImplementedError):
+        core._compare_domain([np.dtype(np.uint64)], [e_i.astype(np.uint64)])
+
+
+def test_axis_and_argument_errors_raise_before_compute():
+    x = np.zeros((3, 4))
+    with pytest.raises(AssertionError):
+        core.histogram(x, bins=np.linspace(0, 1, 3), axis=2)
+    with pytest.raises(ValueError):
+        core.histogram(x, bins=None)
+    with pytest.raises(ValueError):
+        core.histogram(x, x, bins=[np.linspace(0, 1, 3)])
+    with pytest.raises(ValueError):
+        core.histogram(x, bins=np.array([0.0, 2.0, 1.0]))
+    with pytest.raises(TypeError):
+        core.histogram(x, bins="auto", weights=np.ones_like(x))
+
+
+def test_default_device_env(monkeypatch):
+    monkeypatch.delenv("XHIST_AMD_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert core.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert core.default_device() == 3
+    monkeypatch.setenv("XHIST_AMD_DEVICE", "5")
+    assert core.default_device() == 5
