@@ -20,7 +20,12 @@ needs = pytest.mark.skipif(not _have_dask_python(), reason="no interpreter with 
 
 
 def _run(mode):
-    r = subprocess.run([PY39, "-W", "ignore", SCRIPT, mode], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    # conda's python ships an older libstdc++ than libamdhip64 needs: let the system one win
+    sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_cxx):
+        env["LD_PRELOAD"] = (sys_cxx + ":" + env["LD_PRELOAD"]) if env.get("LD_PRELOAD") else sys_cxx
+    r = subprocess.run([PY39, "-W", "ignore", SCRIPT, mode], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
 

@@ -107,6 +107,19 @@ def main():
             emit(case="c2w_constant_samples_one_bin", ms=med, gbs=16 * n / med / 1e6)
             del xc
 
+    if "host" in what:
+        import time
+        m = 200_000_000
+        xh_, wh_ = x[:m].cpu().numpy(), w[:m].cpu().numpy()
+        for weighted in (True, False):
+            core.histogram(xh_[:1000], bins=edges)
+            t0 = time.perf_counter()
+            core.histogram(xh_, bins=edges, weights=wh_ if weighted else None)
+            dt = time.perf_counter() - t0
+            emit(case="host_numpy_route_pcie_inclusive", weighted=weighted, samples=m, s=dt, samples_per_s=m / dt,
+                 gbs=(16 if weighted else 8) * m / dt / 1e9)
+        del xh_, wh_
+
     if "c3" in what:
         rng = np.random.default_rng(1)
         def nu(k):
