@@ -89,6 +89,7 @@ struct xhist_plan {
   DimTable dimf[kMaxDims];  // float32-threshold domain (float64 plans only)
   uint64_t* d_tables_f = nullptr;
   int32_t table_words_f = 0;
+  int max_cnt = 0, max_cnt_f = 0;  // most edges sharing one bucket, per domain
   int64_t n_bins = 0;
   int cus = 256;
   size_t lds_max = 64 * 1024;
@@ -140,7 +141,7 @@ extern "C" int xhist_device_info(int device, char* name, size_t name_cap, int* c
 // already converted to the domain's element type; `edges` are the caller's original arrays.
 static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_edges,
                         const std::vector<std::vector<uint64_t>>& words, const void* const* edges, DimTable* dims,
-                        uint64_t** d_blob_out, int32_t* table_words_out) {
+                        uint64_t** d_blob_out, int32_t* table_words_out, int* max_cnt_out) {
   int32_t edge_off = 0;
   int64_t max_e = 0;
   for (int d = 0; d < n_inputs; ++d) {
@@ -231,6 +232,7 @@ static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_e
       total += cnt;
     }
     if (total != (uint64_t)t.n_edges) return cleanup(fail(XHIST_ERR_HIP, "bucket table of dim %d is inconsistent", d));
+    *max_cnt_out = std::max<int>(*max_cnt_out, (int)maxcnt);
     int steps = 0;
     while ((1u << steps) <= maxcnt) ++steps;
     t.steps = steps;
@@ -309,22 +311,27 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     words[d].assign((size_t)E, 0);
     memcpy(words[d].data(), edges[d], (size_t)E * 8);
   }
-  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, n_inputs, n_edges, words, edges, p->dim, &p->d_tables, &p->table_words);
+  // every edge array is followed by 4 sentinels that compare false against any sample (NaN), so
+  // the linear in-bucket count may read up to 4 entries past a bucket's start unconditionally
+  const uint64_t kNaN64 = 0x7ff8000000000000ull;
+  for (int d = 0; d < n_inputs; ++d)
+    for (int k = 0; k < 4; ++k) words[d].push_back(cmp_domain == XHIST_CMP_F64 ? kNaN64 : 0x7fffffffffffffffull);
+  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, n_inputs, n_edges, words, edges, p->dim, &p->d_tables, &p->table_words, &p->max_cnt);
   if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
     for (int d = 0; d < n_inputs; ++d) {
       const int E = (int)n_edges[d];
       const double* e = static_cast<const double*>(edges[d]);
-      std::vector<float> thr((size_t)E + 1, 0.0f);
+      std::vector<float> thr((size_t)E + 6, std::nanf(""));  // >= 4 NaN sentinels after the thresholds
       for (int j = 0; j < E; ++j) {
         float f = (float)e[j];
         if ((double)f < e[j]) f = std::nextafterf(f, INFINITY);
         thr[(size_t)j] = f;
       }
-      words[d].assign(((size_t)E + 1) / 2, 0);
-      memcpy(words[d].data(), thr.data(), (size_t)E * 4);
+      words[d].assign(((size_t)E + 5) / 2, 0);
+      memcpy(words[d].data(), thr.data(), words[d].size() * 8);
     }
-    rc = build_domain(p, 2, n_inputs, n_edges, words, edges, p->dimf, &p->d_tables_f, &p->table_words_f);
+    rc = build_domain(p, 2, n_inputs, n_edges, words, edges, p->dimf, &p->d_tables_f, &p->table_words_f, &p->max_cnt_f);
   }
   if (rc != XHIST_OK) {
     if (p->d_tables) (void)hipFree(p->d_tables);
@@ -415,54 +422,68 @@ extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n
 // ------------------------------------------------------------------------------------------
 typedef void (*kernel_fn)(const Params);
 
-// Samples a lane bins as one branch-free batch = VEC x UNROLL; capped by register pressure
-// (D digitize states per sample must stay in VGPRs: 16 / 8 / 4 samples for D = 1 / 2 / 3).
-constexpr int unroll_for(int D, int vec) {
-  const int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
+// Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
+// sample and dimension the batch keeps the value, its running count and (linear scan) up to
+// SCAN edge values in VGPRs, and 1024-thread workgroups leave 128 VGPRs per lane.
+constexpr int unroll_for(int D, int vec, int scan) {
+  int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
+  if (D >= 2 && scan >= 3) cap /= 2;
+  if (D == 1 && scan >= 3 && vec == 4) cap = 8;
   const int u = cap / vec < 1 ? 1 : cap / vec;
   return u > 4 ? 4 : u;
 }
 
-template <typename ST, typename WT, int D>
+template <typename ST, typename WT, int D, int SCAN>
 static kernel_fn fast_pick(int hist) {
   constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
   constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
-  constexpr int U = unroll_for(D, VEC);
-  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds>;
+  constexpr int U = unroll_for(D, VEC, SCAN);
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
-    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked>;
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
     else return nullptr;
   }
-  return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal>;
+  return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
+}
+
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick_s(int scan, int hist) {
+  switch (scan) {
+    case 1: return fast_pick<ST, WT, D, 1>(hist);
+    case 2: return fast_pick<ST, WT, D, 2>(hist);
+    case 3: return fast_pick<ST, WT, D, 3>(hist);
+    case 4: return fast_pick<ST, WT, D, 4>(hist);
+    default: return fast_pick<ST, WT, D, 0>(hist);
+  }
 }
 
 template <typename ST, typename WT>
-static kernel_fn fast_pick_d(int D, int hist) {
+static kernel_fn fast_pick_d(int D, int scan, int hist) {
   switch (D) {
-    case 1: return fast_pick<ST, WT, 1>(hist);
-    case 2: return fast_pick<ST, WT, 2>(hist);
-    case 3: return fast_pick<ST, WT, 3>(hist);
+    case 1: return fast_pick_s<ST, WT, 1>(scan, hist);
+    case 2: return fast_pick_s<ST, WT, 2>(scan, hist);
+    case 3: return fast_pick_s<ST, WT, 3>(scan, hist);
     default: return nullptr;
   }
 }
 
 template <typename ST>
-static kernel_fn fast_pick_w(int wdt, int D, int hist) {
+static kernel_fn fast_pick_w(int wdt, int D, int scan, int hist) {
   switch (wdt) {
-    case -1: return fast_pick_d<ST, NoWeight>(D, hist);
-    case XHIST_F64: return fast_pick_d<ST, double>(D, hist);
-    case XHIST_F32: return fast_pick_d<ST, float>(D, hist);
+    case -1: return fast_pick_d<ST, NoWeight>(D, scan, hist);
+    case XHIST_F64: return fast_pick_d<ST, double>(D, scan, hist);
+    case XHIST_F32: return fast_pick_d<ST, float>(D, scan, hist);
     default: return nullptr;
   }
 }
 
-static kernel_fn fast_kernel(int sdt, int wdt, int D, int hist, int* vec) {
+static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* vec) {
   const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
   *vec = 16 / std::max(ssz, wsz);
   switch (sdt) {
-    case XHIST_F64: return fast_pick_w<double>(wdt, D, hist);
-    case XHIST_F32: return fast_pick_w<float>(wdt, D, hist);
+    case XHIST_F64: return fast_pick_w<double>(wdt, D, scan, hist);
+    case XHIST_F32: return fast_pick_w<float>(wdt, D, scan, hist);
     default: return nullptr;
   }
 }
@@ -583,15 +604,18 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const bool tables_in_lds = tables_fit;
   const size_t lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
 
+  // linear in-bucket count when no bucket holds more than 4 edges (always for uniform bins)
+  const int mc = use_f32 ? p->max_cnt_f : p->max_cnt;
+  const int scan = (fast && mc >= 1 && mc <= 4) ? mc : 0;
   kernel_fn fn = nullptr;
-  if (fast) fn = fast_kernel(sdt, wdt, D, hist, &vec);
+  if (fast) fn = fast_kernel(sdt, wdt, D, scan, hist, &vec);
   if (!fn) {
     if (hist == kHistPacked) return fail(XHIST_ERR_HIP, "internal: packed histogram without a fast kernel");
     fast = false;
     fn = generic_kernel(p->cmp, weighted, lds_hist);
   }
   const DimTable* dims = use_f32 ? p->dimf : p->dim;
-  const int kUnroll = fast ? unroll_for(D, vec) : 1;
+  const int kUnroll = fast ? unroll_for(D, vec, scan) : 1;
 
   // ---- geometry -----------------------------------------------------------------------------
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
@@ -605,7 +629,10 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
   bpc = std::min<int>(bpc, 2048 / block);
   if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
-  const int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc;
+  // one row: the segs workgroups share the row's tiles round-robin, so exactly one resident wave
+  // of workgroups is balanced by construction.  Many rows: a workgroup is tied to one row, so the
+  // tail is balanced by making 8x more, smaller workgroups (C4 shape: 5.6 -> 6.5 TB/s)
+  const int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc * (n_rows > 1 ? 8 : 1);
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
   const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
   if (lds_bytes > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -665,10 +692,10 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       if (first_launch) {
         snprintf(desc, sizeof desc,
                  "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
-                 "lut_k0=%d steps0=%d weighted=%d D=%d cmp=%s lds_cap=%zu",
+                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu",
                  fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
                  fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
-                 table_bytes, dims[0].lut_k, dims[0].steps, (int)weighted, D,
+                 table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
                  use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : "f64"), lds_cap);
       }
       first_launch = false;

@@ -116,7 +116,7 @@ template <int CMP>
 __device__ __forceinline__ int bucket_of(typename Dom<CMP>::T x, const DimTable& t) {
   if (CMP == 2) {  // all-float32 arithmetic (full-rate VALU); any monotone map is valid
     float tt = (float)Dom<CMP>::offset(x, t) * (float)t.scale;
-    tt = fmaxf(fminf(tt, (float)(t.lut_k - 1)), 0.0f);
+    tt = __builtin_amdgcn_fmed3f(tt, 0.0f, (float)(t.lut_k - 1));  // one-op clamp; NaN -> 0
     return (int)tt;
   }
   double tt = (double)Dom<CMP>::offset(x, t) * t.scale;
@@ -161,6 +161,31 @@ template <int CMP, typename TabPtr>
 __device__ __forceinline__ void digitize_more(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab, DigState& s) {
 #pragma unroll 1
   for (int k = 1; k < t.steps; ++k) upper_bound_step<CMP>(x, t, tab, s);
+}
+
+// Linear form of the in-bucket count for tables whose buckets hold at most SCAN (<= 4) edges —
+// every uniform-bin histogram has SCAN = 1.  Each dimension's edge array is followed by 4 NaN
+// sentinels, and edges past the bucket's own ones lie in HIGHER buckets, hence are > x: so
+//     #{e_j <= x} = start + sum_{k < SCAN} [ e[start + k] <= x ]
+// with no count field, no clamping and no data-dependent control flow: SCAN independent LDS
+// reads at immediate offsets, SCAN compares, SCAN add-with-carry.
+template <int CMP, int SCAN, typename TabPtr>
+__device__ __forceinline__ uint32_t count_le_scan(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
+  using T = typename Dom<CMP>::T;
+  auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
+  const uint32_t start = lut[bucket_of<CMP>(x, t)] & 0xffffu;
+  const T* e = reinterpret_cast<const T*>(tab + t.edge_off) + start;
+  uint32_t lo = start;
+#pragma unroll
+  for (int k = 0; k < SCAN; ++k) lo += (e[k] <= x) ? 1u : 0u;
+  return lo;
+}
+
+// Real-bin index in [0, nb) from lo = #{e_j <= x}, or -1 when the reference drops the sample
+template <int CMP>
+__device__ __forceinline__ int bin_from_count(typename Dom<CMP>::T x, const DimTable& t, uint32_t lo) {
+  const int bin = min((int)lo - 1, t.nb - 1);  // x == e_last counts E edges -> last bin
+  return Dom<CMP>::in_range(x, t) ? bin : -1;
 }
 
 // Real-bin index in [0, nb), or -1 when the reference would drop the sample.
@@ -253,7 +278,8 @@ struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
 //                2^32, so the result is independent of interleaving: no timing assumption.
 constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 
-template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST>
+// SCAN: 1..4 = linear in-bucket count over at most SCAN edges (count_le_scan), 0 = binary search
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
   constexpr int CMP = __is_same(ST, float) ? 2 : 0;
@@ -341,24 +367,38 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
           xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(sp[d] + i));
         if (kWeighted) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + i));
       }
-      // whole tile as one branch-free batch: table reads of all samples are independent
-      DigState st[D][UNROLL][VEC];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-          for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
-      // wave-uniform extra rounds when some bucket holds several edges (non-uniform / duplicate
-      // edges); a round is a no-op for a sample whose bucket is already decided (len == 0)
-#pragma unroll 1
-      for (int k = 1; k < max_steps; ++k) {
+      // whole tile as one branch-free batch: the table reads of all samples are independent
+      uint32_t cnt[D][UNROLL][VEC];  // #{edges <= x} per sample and dimension
+      if constexpr (SCAN > 0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
           for (int v = 0; v < VEC; ++v)
 #pragma unroll
-            for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
+            for (int d = 0; d < D; ++d) cnt[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
+      } else {  // crowded buckets (duplicate / very uneven edges): branch-free binary search
+        DigState st[D][UNROLL][VEC];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
+#pragma unroll 1
+        for (int k = 1; k < max_steps; ++k) {  // a round is a no-op once a sample's bucket is decided
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+              for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cnt[d][u][v] = st[d][u][v].lo;
       }
       bool okv[UNROLL][VEC];
       uint32_t flatv[UNROLL][VEC], oldv[UNROLL][VEC];
@@ -370,9 +410,12 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
           uint32_t flat = 0;
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            const int b = digitize_end(p.dim[d], st[d][u][v]);
+            const int b = bin_from_count<CMP>((CT)xv[d][u][v], p.dim[d], cnt[d][u][v]);
             ok &= (b >= 0);
-            flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
+            // the last dimension has stride 1; n_bins < 2^24 in every LDS mode and < 2^31 always
+            if (d == 0) flat = (uint32_t)b;
+            else if (HIST != kHistGlobal) flat = __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;  // full-rate mad_u24
+            else flat = flat * (uint32_t)p.dim[d].nb + (uint32_t)b;
           }
           if (HIST == kHistPacked) {
             okv[u][v] = ok;
@@ -396,7 +439,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
         for (int d = 0; d < D; ++d) {
           const int b = digitize<CMP>((CT)sp[d][i], p.dim[d], tab);
           ok &= (b >= 0);
-          flat += (uint32_t)b * (uint32_t)p.dim[d].out_stride;
+          flat = (d == 0) ? (uint32_t)b : flat * (uint32_t)p.dim[d].nb + (uint32_t)b;
         }
         if (HIST == kHistPacked) packed_fix(ok, flat, packed_add(ok, flat));
         else scatter(ok, flat, kWeighted ? (double)wp[i] : 0.0);
