@@ -441,3 +441,81 @@ def test_f32_threshold_domain_is_exact_at_edges(xh):
     e3 = np.array([-1e300, -1.0, 1.0, 1e300])
     x3 = np.array([[-np.inf, -3.4e38, -1.0, 0.0, 1.0, 3.4e38, np.inf, np.nan]], dtype=np.float32)
     np.testing.assert_array_equal(_run(xh, [x3], [e3], None, True)[0], onp.bincount_rows([x3], [e3]))
+
+
+def test_more_than_2_32_samples_int64_indexing(xh):
+    """> 2^32 samples in one row (BASELINE C5 is 4e9 in total): 64-bit indexing, uint32 LDS
+    counters flushed per workgroup; known answer from a periodic pattern"""
+    n = (1 << 32) + 12_345_678
+    pat = torch.tensor([-5.0, -3.5, -0.5, 0.5, 0.5, 3.5, 4.0, float("nan")], dtype=torch.float32, device="cuda")
+    x = pat.repeat((n + 7) // 8)[:n]
+    edges = np.array([-4.0, -1.0, 0.0, 1.0, 4.0])
+    h, _ = xh.histogram(x, bins=edges)
+    full, rem = divmod(n, 8)
+    want = np.array([1, 1, 2, 2], dtype=np.int64) * full
+    tail = pat[:rem].cpu().numpy()
+    want += onp.bincount_rows([tail.reshape(1, -1)], [edges])[0]
+    np.testing.assert_array_equal(h.cpu().numpy(), want)
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_leading_axis_reduction_large_device_view(xh):
+    """dim='time' of (time, y, x): columns are strided; must equal the oracle (and not crawl)"""
+    rng = np.random.default_rng(31)
+    t = rng.standard_normal((300, 64, 80)).astype(np.float32)
+    edges = np.linspace(-4, 4, 51)
+    want, _ = onp.histogram(t, bins=edges, axis=0)
+    got, _ = xh.histogram(_dev(t), bins=edges, axis=0)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got, _ = xh.histogram(_dev(t), bins=edges, axis=(0, 2))
+    np.testing.assert_array_equal(got.cpu().numpy(), onp.histogram(t, bins=edges, axis=(0, 2))[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# partitioned multi-pass mode (histograms beyond LDS, BASELINE C5)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n", [5_000_000, 4_194_304 + 777, 1023])
+def test_partitioned_mode_c5_shape(xh, weighted, n):
+    rng = np.random.default_rng(41 + n % 7)
+    x = rng.standard_normal((1, n))
+    y = rng.standard_normal((1, n)) * 1.5
+    x[0, ::1001] = np.nan
+    y[0, 5::997] = 4.0  # right edge of the last bin
+    w = rng.uniform(0, 1, (1, n)) if weighted else None
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    want = onp.bincount_rows([x, y], edges, w)
+    got, desc = _run(xh, [x, y], edges, w, True, partition=1)
+    assert "hist=partitioned" in desc, desc
+    assert_hist_equal(got, want, weighted)
+    got2, desc2 = _run(xh, [x, y], edges, w, True, partition=-1)
+    assert "hist=global" in desc2, desc2
+    assert_hist_equal(got2, want, weighted)
+
+
+def test_partitioned_mode_3d_f32_nonuniform(xh):
+    rng = np.random.default_rng(43)
+    n = 3_000_000
+    s = [rng.standard_normal((1, n)).astype(np.float32) for _ in range(3)]
+    edges = [_nonuniform_edges(rng, 129), np.linspace(-4, 4, 129), _nonuniform_edges(rng, 65)]
+    want = onp.bincount_rows(s, edges)
+    got, desc = _run(xh, s, edges, None, True, partition=1)
+    assert "hist=partitioned" in desc, desc
+    np.testing.assert_array_equal(got, want)
+    w = rng.uniform(0, 2, (1, n)).astype(np.float32)
+    got, desc = _run(xh, s, edges, w, True, partition=1)
+    assert "hist=partitioned" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows(s, edges, w), True)
+
+
+def test_partitioned_mode_skewed_everything_in_one_bin(xh):
+    """worst case for the slot reservation: one partition receives every sample"""
+    n = 6_000_000
+    x = np.full((1, n), 0.123)
+    y = np.full((1, n), -2.5)
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    got, desc = _run(xh, [x, y], edges, None, True, partition=1)
+    assert "hist=partitioned" in desc, desc
+    assert got.sum() == n and got.max() == n
+    np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges))

@@ -3,6 +3,7 @@
 // No CPU compute path exists here on purpose: without a HIP device every compute entry point
 // fails with XHIST_ERR_NO_DEVICE.
 #include "xhist_kernels.hip.h"
+#include "xhist_partition.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -98,6 +99,7 @@ struct xhist_plan {
   int grid_blocks = 0;
   int force_global = 0;
   int force_generic = 0;
+  int partition = 0;  // 0 auto, 1 prefer the partitioned mode whenever it is legal, -1 never
   int lds_copies = 0;
   int profile = 0;
   std::mutex mu;  // guards events + desc
@@ -369,6 +371,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->force_global = value != 0;
   } else if (!strcmp(key, "force_generic")) {
     p->force_generic = value != 0;
+  } else if (!strcmp(key, "partition")) {
+    p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {
     if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
     p->lds_copies = (int)value;
@@ -421,6 +425,9 @@ extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n
 // kernel selection
 // ------------------------------------------------------------------------------------------
 typedef void (*kernel_fn)(const Params);
+typedef void (*kernel_fn_acc)(const uint16_t*, const double*, const uint64_t*, void*, int64_t, int, int);
+typedef void (*kernel_fn_count)(const Params, uint32_t*);
+typedef void (*kernel_fn_scatter)(const uint32_t*, const void*, int64_t, const uint64_t*, uint16_t*, double*, int, int);
 
 // Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
 // sample and dimension the batch keeps the value, its running count and (linear scan) up to
@@ -433,12 +440,17 @@ constexpr int unroll_for(int D, int vec, int scan) {
   return u > 4 ? 4 : u;
 }
 
+// partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
+constexpr int kHistPartCount = 4;
+constexpr int kPartMaxParts = 256;
+
 template <typename ST, typename WT, int D, int SCAN>
 static kernel_fn fast_pick(int hist) {
   constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
   constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, SCAN);
+  if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, SCAN>;
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
     if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
@@ -531,6 +543,125 @@ static const void* advance(const void* base, int dt, int64_t elems) {
   return static_cast<const char*>(base) + elems * dtype_size(dt);
 }
 
+// Partitioned mode (xhist_partition.hip.h): count -> prefix -> scatter -> accumulate, all on
+// `stream`, scratch from the stream-ordered allocator (so concurrent callers never share it).
+static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
+                               hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, int shift, int n_parts, int profile) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  if (n_cols >= ((int64_t)1 << 40)) return XHIST_ERR_UNSUPPORTED;
+  int vec = 1;
+  kernel_fn_count k_count = (kernel_fn_count)fast_kernel(sdt, wdt, D, scan, kHistPartCount, &vec);
+  if (!k_count) return XHIST_ERR_UNSUPPORTED;
+  kernel_fn_scatter k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight>
+                                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double> : (kernel_fn_scatter)part_scatter<float>);
+  const size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  const size_t lds_count = table_bytes + (size_t)(n_parts + 1) * 32 * 4;
+  const size_t lds_scatter = 6144 + (size_t)kPartTile * (weighted ? 16 : 4);
+  const size_t lds_acc = (size_t)(1u << shift) * (weighted ? 8 : 4);
+  if (lds_count > p->lds_max || lds_scatter > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  const int per_cu = std::max<int>(1, std::min<int>(4, (int)(160 * 1024 / std::max(lds_count, lds_scatter))));
+  const int64_t n_tiles = (n_cols + kPartTile - 1) / kPartTile;
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
+  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_cols + 65535) / 65536));
+
+  uint32_t* d_counts = nullptr;
+  uint64_t *d_base = nullptr, *d_offsets = nullptr;
+  uint16_t* d_codes = nullptr;
+  double* d_w = nullptr;
+  uint32_t* d_flat = nullptr;
+  auto release = [&](int rc) {
+    if (d_flat) (void)hipFreeAsync(d_flat, stream);
+    if (d_counts) (void)hipFreeAsync(d_counts, stream);
+    if (d_base) (void)hipFreeAsync(d_base, stream);
+    if (d_offsets) (void)hipFreeAsync(d_offsets, stream);
+    if (d_codes) (void)hipFreeAsync(d_codes, stream);
+    if (d_w) (void)hipFreeAsync(d_w, stream);
+    return rc;
+  };
+#define HIPR(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  HIPR(hipMallocAsync((void**)&d_counts, (size_t)G * n_parts * 4, stream));
+  HIPR(hipMallocAsync((void**)&d_base, (size_t)G * n_parts * 8, stream));
+  HIPR(hipMallocAsync((void**)&d_offsets, (size_t)(n_parts + 1) * 8, stream));
+  HIPR(hipMallocAsync((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
+  HIPR(hipMallocAsync((void**)&d_codes, (size_t)n_cols * 2 + 16, stream));
+  if (weighted) HIPR(hipMallocAsync((void**)&d_w, (size_t)n_cols * 8 + 16, stream));
+
+  Params kp;
+  memset(&kp, 0, sizeof kp);
+  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  for (int d = 0; d < D; ++d) {
+    kp.s_ptr[d] = samples[d].data;
+    kp.s_rs[d] = samples[d].row_stride;
+    kp.s_cs[d] = 1;
+    kp.s_dt[d] = samples[d].dtype;
+    kp.dim[d] = dims[d];
+  }
+  if (weighted) {
+    kp.w_ptr = weights->data;
+    kp.w_rs = weights->row_stride;
+    kp.w_cs = 1;
+    kp.w_dt = weights->dtype;
+  }
+  kp.n_dims = D;
+  kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
+  kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+  kp.tables_in_lds = 1;
+  kp.n_rows = 1;
+  kp.n_cols = n_cols;
+  kp.n_bins = p->n_bins;
+  kp.out = out;
+  kp.segs = G;
+  kp.part_counts = d_counts;
+  kp.part_base = d_base;
+  kp.part_codes = d_codes;
+  kp.part_w = d_w;
+  kp.part_shift = shift;
+  kp.n_parts = n_parts;
+
+  if (lds_count > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+  if (lds_scatter > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
+  kernel_fn_acc k_acc = weighted ? (kernel_fn_acc)part_accumulate<true> : (kernel_fn_acc)part_accumulate<false>;
+  if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+
+  int ring_slot = -1;
+  if (profile) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    ring_slot = (int)(p->n_recorded % profile);
+    HIPR(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
+  }
+  hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, d_offsets, d_base);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
+                     weighted ? weights->data : nullptr, n_cols, (const uint64_t*)d_base, d_codes, d_w, shift, n_parts);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const double*)d_w,
+                     (const uint64_t*)d_offsets, out, p->n_bins, shift, n_parts);
+  HIPR(hipGetLastError());
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (ring_slot >= 0) {
+      HIPR(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
+      ++p->n_recorded;
+    }
+    char desc[384];
+    snprintf(desc, sizeof desc,
+             "family=fast hist=partitioned parts=%d bins_per_part=%d vec=%d tile=%d block=%d grid=%d acc_grid=%d lds_count=%zu "
+             "lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
+             n_parts, 1 << shift, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
+             use_f32 ? "f32thr" : "f64");
+    p->desc = desc;
+  }
+#undef HIPR
+  return release(XHIST_OK);
+}
+
 static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
                           int64_t n_cols, void* out, int accumulate, hipStream_t stream) {
   const int D = p->n_dims;
@@ -539,11 +670,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   if (!accumulate && out_elems > 0) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
   if (out_elems == 0 || n_cols == 0) return XHIST_OK;
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
-    force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile;
+    force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
   }
 
   // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
@@ -615,6 +746,18 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     fn = generic_kernel(p->cmp, weighted, lds_hist);
   }
   const DimTable* dims = use_f32 ? p->dimf : p->dim;
+
+  // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
+  if (fast && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
+    const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
+    const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
+    const bool big_enough = n_cols >= ((int64_t)1 << 22) || partition > 0;
+    if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
+      const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, shift, (int)n_parts,
+                                         profile);
+      if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = fall through to global atomics
+    }
+  }
   const int kUnroll = fast ? unroll_for(D, vec, scan) : 1;
 
   // ---- geometry -----------------------------------------------------------------------------

@@ -68,6 +68,13 @@ struct Params {
   void* out;               // [n_rows, n_bins] uint64 counts or float64 sums
   int32_t copies_log2;     // LDS sub-histogram replication (lane-private banks)
   int32_t segs;            // workgroups cooperating on one row
+  // partitioned mode (histograms too large for LDS), see xhist_partition.hip.h
+  uint32_t* part_counts;        // [grid, n_parts]: samples of each workgroup per bin partition
+  const uint64_t* part_base;    // [grid, n_parts]: first record slot of a workgroup in each partition stream
+  uint16_t* part_codes;         // record stream: bin index inside its partition
+  double* part_w;               // record stream: weight (weighted only)
+  int32_t part_shift;           // bins per partition = 1 << part_shift
+  int32_t n_parts;
 };
 
 // ---------------------------------------------------------------------------------------------
