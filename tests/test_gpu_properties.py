@@ -1,0 +1,138 @@
+"""Property-based GPU parity (the reference's test_chunking_hypotheses.py idea, widened): random
+shapes, axes, dtypes, edge layouts and kernel-family overrides against the oracle; plus
+thread-safety of one plan under concurrent callers (dask's threaded scheduler does this)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import assert_hist_equal
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+hyp = pytest.importorskip("hypothesis")
+from hypothesis import given, settings, HealthCheck  # noqa: E402
+import hypothesis.strategies as st  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def xh():
+    from xhistogram_amd import _native, core
+
+    assert _native.device_count() >= 1
+    return core
+
+
+def _edges(draw, kind, n):
+    if kind == "uniform":
+        lo = draw(st.floats(-5, 0))
+        return np.linspace(lo, lo + draw(st.floats(0.5, 9)), n + 1)
+    if kind == "random":
+        e = np.sort(np.array(draw(st.lists(st.floats(-4, 4, allow_nan=False, width=32), min_size=n + 1, max_size=n + 1))))
+        return e
+    if kind == "duplicates":
+        e = np.sort(np.round(np.array(draw(st.lists(st.floats(-3, 3), min_size=n + 1, max_size=n + 1))), 0))
+        return e
+    # geometric: tiny and huge bins together -> crowded buckets -> binary-search family
+    return np.concatenate([[-4.0], -4.0 + np.cumsum(np.geomspace(1e-9, 4.0, n))])
+
+
+@st.composite
+def cases(draw):
+    d = draw(st.integers(1, 3))
+    ndim = draw(st.integers(1, 3))
+    shape = tuple(draw(st.integers(1, 9)) for _ in range(ndim - 1)) + (draw(st.integers(1, 300)),)
+    axis_choices = [None] + [tuple(c) for r in range(1, ndim + 1) for c in __import__("itertools").combinations(range(ndim), r)]
+    axis = draw(st.sampled_from(axis_choices))
+    dtype = draw(st.sampled_from([np.float64, np.float32, np.int32, np.int64]))
+    kinds = [draw(st.sampled_from(["uniform", "random", "duplicates", "geometric"])) for _ in range(d)]
+    edges = [_edges(draw, k, draw(st.integers(1, 12))) for k in kinds]
+    weighted = draw(st.booleans())
+    wshape = draw(st.sampled_from(["full", "row", "scalar"])) if weighted else None
+    density = draw(st.booleans())
+    seed = draw(st.integers(0, 2**31 - 1))
+    resident = draw(st.booleans())
+    override = draw(st.sampled_from([None, "force_global", "force_generic", "lds_copies"]))
+    return d, shape, axis, dtype, edges, wshape, density, seed, resident, override
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+@given(cases())
+def test_random_cases_match_oracle(xh, case):
+    d, shape, axis, dtype, edges, wshape, density, seed, resident, override = case
+    rng = np.random.default_rng(seed)
+    if np.dtype(dtype).kind == "f":
+        args = [(rng.standard_normal(shape) * 2).astype(dtype) for _ in range(d)]
+        for a in args:
+            flat = a.reshape(-1)
+            flat[rng.integers(0, flat.size, max(1, flat.size // 17))] = rng.choice([np.nan, np.inf, -np.inf, 4.0, -4.0, 0.0])
+    else:
+        args = [rng.integers(-5, 6, shape).astype(dtype) for _ in range(d)]
+    w = None
+    if wshape == "full":
+        w = rng.uniform(0, 2, shape)
+    elif wshape == "row":
+        w = rng.uniform(0, 2, shape[-1:])
+    elif wshape == "scalar":
+        w = np.float64(0.75) * np.ones((1,) * len(shape))
+    kw = dict(bins=edges if d > 1 else edges[0], axis=axis, density=density)
+    try:
+        want, _ = onp.histogram(*args, weights=w, **kw)
+    except NotImplementedError:
+        return
+    if resident:
+        targs = [torch.as_tensor(a).cuda() for a in args]
+        tw = None if w is None else torch.as_tensor(np.asarray(w)).cuda()
+    else:
+        targs, tw = args, w
+    plan = None
+    if override:
+        dts = [xh._np_dtype_of(a) for a in targs]
+        try:
+            dom, conv, _ = xh._compare_domain(dts, edges)
+        except NotImplementedError:
+            return
+        plan = xh._get_plan(conv, dom, 0)
+        plan.set_param(override, 1)
+    try:
+        got, _ = xh.histogram(*targs, weights=tw, **kw)
+    except NotImplementedError:
+        return
+    finally:
+        if plan is not None:
+            plan.set_param(override, 0)
+    got = got.cpu().numpy() if resident else got
+    assert_hist_equal(got, want, weighted=(w is not None) or density)
+
+
+def test_one_plan_many_threads(xh):
+    """ctypes releases the GIL: concurrent executes on one cached plan must not interfere"""
+    rng = np.random.default_rng(77)
+    edges = np.linspace(-4, 4, 41)
+    data = [rng.standard_normal((3, 50_000 + 1000 * i)) for i in range(8)]
+    want = [onp.histogram(a, bins=edges, axis=1)[0] for a in data]
+    results = [None] * len(data)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    h, _ = xh.histogram(torch.as_tensor(data[i]).cuda(), bins=edges, axis=1)
+                    hn, _ = xh.histogram(data[i], bins=edges, axis=1, weights=np.ones_like(data[i]))
+                s.synchronize()
+                results[i] = (h.cpu().numpy(), hn)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(data))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (h, hn), w in zip(results, want):
+        np.testing.assert_array_equal(h, w)
+        np.testing.assert_array_equal(hn, w.astype(np.float64))
