@@ -519,3 +519,88 @@ def test_partitioned_mode_skewed_everything_in_one_bin(xh):
     assert "hist=partitioned" in desc, desc
     assert got.sum() == n and got.max() == n
     np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges))
+
+
+# ---------------------------------------------------------------------------------------------
+# row-per-lane kernels: leading-axis reductions and many short rows
+# ---------------------------------------------------------------------------------------------
+def _describe_last(xh, samples, edges):
+    return _plan_for(xh, samples, edges).describe()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_lanes_leading_axis_reduction(xh, dt, weighted):
+    rng = np.random.default_rng(51)
+    t = (rng.standard_normal((301, 37, 53)) * 1.5).astype(dt)  # rows = 37*53 = 1961 (not a multiple of 256)
+    t[5, 3, 7] = np.nan
+    t[:, 0, 0] = 4.0
+    w = rng.uniform(0, 1, t.shape) if weighted else None
+    edges = np.linspace(-4, 4, 51)
+    want, _ = onp.histogram(t, bins=edges, axis=0, weights=w)
+    got, _ = xh.histogram(_dev(t), bins=edges, axis=0, weights=None if w is None else _dev(w))
+    desc = _describe_last(xh, [_dev(t[0])], [edges])
+    assert "family=lanes" in desc and "transpose=0" in desc, desc
+    assert_hist_equal(got.cpu().numpy(), want, weighted)
+    # weights broadcast along the reduced axis (one weight per kept position) and along kept axes
+    if weighted:
+        for wshape in ((1, 37, 53), (301, 1, 1)):
+            wb = rng.uniform(0, 1, wshape)
+            want, _ = onp.histogram(t, bins=edges, axis=0, weights=wb)
+            got, _ = xh.histogram(_dev(t), bins=edges, axis=0, weights=_dev(wb))
+            assert_hist_equal(got.cpu().numpy(), want, True)
+
+
+@pytest.mark.parametrize("shape", [(5000, 20), (4097, 365), (70_000, 7), (4096, 800), (300_001, 33)])
+def test_lanes_many_short_rows(xh, shape):
+    rng = np.random.default_rng(52)
+    x = rng.standard_normal(shape)
+    edges = np.linspace(-3, 3, 25)
+    want, _ = onp.histogram(x, bins=edges, axis=1)
+    got, _ = xh.histogram(_dev(x), bins=edges, axis=1)
+    desc = _describe_last(xh, [_dev(x[:1])], [edges])
+    assert "family=lanes" in desc and "transpose=fused" in desc, desc  # one pass: load, turn in LDS, count
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    xf = x.astype(np.float32)[:, ::-1].copy()
+    xf[::7, 0] = np.nan
+    np.testing.assert_array_equal(xh.histogram(_dev(xf), bins=edges, axis=1)[0].cpu().numpy(), onp.histogram(xf, bins=edges, axis=1)[0])
+    sl = _dev(x)[:, 1:]  # row stride != number of columns, unaligned row starts
+    np.testing.assert_array_equal(xh.histogram(sl, bins=edges, axis=1)[0].cpu().numpy(), onp.histogram(x[:, 1:], bins=edges, axis=1)[0])
+    w = rng.uniform(0, 1, shape).astype(np.float32)
+    want, _ = onp.histogram(x, bins=edges, axis=1, weights=w, density=True)
+    got, _ = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w), density=True)
+    desc = _describe_last(xh, [_dev(x[:1])], [edges])
+    assert "family=lanes" in desc and "transpose=1" in desc, desc  # weighted: transposed scratch + lanes
+    assert_hist_equal(got.cpu().numpy(), want, True)
+    # host route reaches the same kernels through the staged copy
+    np.testing.assert_array_equal(xh.histogram(x, bins=edges, axis=1)[0], onp.histogram(x, bins=edges, axis=1)[0])
+
+
+def test_lanes_2d_joint_nonuniform_and_binary_search_tables(xh):
+    rng = np.random.default_rng(53)
+    a = rng.standard_normal((6000, 33)).astype(np.float32)
+    b = rng.standard_normal((6000, 33)).astype(np.float32)
+    ea = _nonuniform_edges(rng, 9)
+    eb = np.concatenate([[-4.0], -4.0 + np.cumsum(np.geomspace(1e-9, 4.0, 11))])  # crowded buckets -> SCAN 0
+    want, _ = onp.histogram(a, b, bins=[ea, eb], axis=1)
+    got, _ = xh.histogram(_dev(a), _dev(b), bins=[ea, eb], axis=1)
+    desc = _describe_last(xh, [_dev(a[:1]), _dev(b[:1])], [ea, eb])
+    assert "family=lanes" in desc, desc
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_lanes_few_rows_split_columns_and_accumulate(xh):
+    """few rows: columns are split over workgroups and partial tiles are added atomically"""
+    rng = np.random.default_rng(54)
+    t = rng.standard_normal((50_000, 3, 5))  # reduce axis 0: 15 rows of 50000 strided columns
+    edges = np.linspace(-4, 4, 33)
+    want, _ = onp.histogram(t, bins=edges, axis=0)
+    got, _ = xh.histogram(_dev(t), bins=edges, axis=0)
+    desc = _describe_last(xh, [_dev(t[0])], [edges])
+    assert "family=lanes" in desc and "direct_store=0" in desc, desc
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # block_size row blocking goes through separate launches on the same output
+    x = rng.standard_normal((9000, 40))
+    np.testing.assert_array_equal(
+        xh.histogram(_dev(x), bins=edges, axis=1, block_size=2500)[0].cpu().numpy(), onp.histogram(x, bins=edges, axis=1)[0]
+    )

@@ -166,11 +166,12 @@ def _strided_view(a2d, backend):
     host arrays with a column stride other than 0/1)."""
     if backend == "torch":
         rs, cs = a2d.stride()
-        # The kernels stream along columns.  A large view whose columns are strided (a reduction
-        # over LEADING axes, e.g. dim="time" of (time, lat, lon)) would make every lane touch its
-        # own cache line; one transposing copy on the device (the reference makes the same copy on
-        # the host, core.py:219-226) and the vector-load family is far cheaper than that.
-        if rs < 0 or cs < 0 or (cs > 1 and a2d.shape[1] > 1 and a2d.numel() >= (1 << 16)):
+        # A large view strided in BOTH directions (e.g. a reduction over a middle axis) would make
+        # every lane touch its own cache line; one copy on the device (the reference makes the
+        # same copy on the host, core.py:219-226) and the coalesced kernels is far cheaper.
+        # (row stride 1 = reductions over leading axes: the library's row-per-lane kernels take
+        # those views as they are)
+        if rs < 0 or cs < 0 or (cs > 1 and rs > 1 and a2d.shape[1] > 1 and a2d.numel() >= (1 << 16)):
             a2d = a2d.contiguous()
             rs, cs = a2d.stride()
         if a2d.shape[0] <= 1:

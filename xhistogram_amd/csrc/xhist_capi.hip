@@ -4,6 +4,7 @@
 // fails with XHIST_ERR_NO_DEVICE.
 #include "xhist_kernels.hip.h"
 #include "xhist_partition.hip.h"
+#include "xhist_lanes.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -100,6 +101,7 @@ struct xhist_plan {
   int force_global = 0;
   int force_generic = 0;
   int partition = 0;  // 0 auto, 1 prefer the partitioned mode whenever it is legal, -1 never
+  int lanes = 0;      // 0 auto, 1 prefer the row-per-lane kernels whenever they are legal, -1 never
   int lds_copies = 0;
   int profile = 0;
   std::mutex mu;  // guards events + desc
@@ -373,6 +375,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->force_generic = value != 0;
   } else if (!strcmp(key, "partition")) {
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "lanes")) {
+    p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {
     if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
     p->lds_copies = (int)value;
@@ -427,6 +431,7 @@ extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n
 typedef void (*kernel_fn)(const Params);
 typedef void (*kernel_fn_acc)(const uint16_t*, const double*, const uint64_t*, void*, int64_t, int, int);
 typedef void (*kernel_fn_count)(const Params, uint32_t*);
+typedef void (*kernel_fn_lanes)(const Params, int32_t, int64_t);
 typedef void (*kernel_fn_scatter)(const uint32_t*, const void*, int64_t, const uint64_t*, uint16_t*, double*, int, int);
 
 // Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
@@ -441,7 +446,7 @@ constexpr int unroll_for(int D, int vec, int scan) {
 }
 
 // partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
-constexpr int kHistPartCount = 4;
+constexpr int kHistPartCount = 4, kHistLanes = 6;
 constexpr int kPartMaxParts = 256;
 
 template <typename ST, typename WT, int D, int SCAN>
@@ -451,6 +456,7 @@ static kernel_fn fast_pick(int hist) {
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, SCAN);
   if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, SCAN>;
+  if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4)>;
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
     if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
@@ -498,6 +504,25 @@ static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* v
     case XHIST_F32: return fast_pick_w<float>(wdt, D, scan, hist);
     default: return nullptr;
   }
+}
+
+typedef void (*kernel_fn_rows1)(const Params, int32_t);
+
+template <typename ST>
+static kernel_fn_rows1 rows1_pick(int scan) {
+  switch (scan) {
+    case 1: return (kernel_fn_rows1)hist_lanes_rows1<ST, 1>;
+    case 2: return (kernel_fn_rows1)hist_lanes_rows1<ST, 2>;
+    case 3: return (kernel_fn_rows1)hist_lanes_rows1<ST, 3>;
+    case 4: return (kernel_fn_rows1)hist_lanes_rows1<ST, 4>;
+    default: return (kernel_fn_rows1)hist_lanes_rows1<ST, 0>;
+  }
+}
+
+static kernel_fn_rows1 rows1_kernel(int sdt, int scan) {
+  if (sdt == XHIST_F64) return rows1_pick<double>(scan);
+  if (sdt == XHIST_F32) return rows1_pick<float>(scan);
+  return nullptr;
 }
 
 static kernel_fn generic_kernel(int cmp, bool weighted, bool lds) {
@@ -662,20 +687,216 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   return release(XHIST_OK);
 }
 
+// Row-per-lane mode (xhist_lanes.hip.h).  Takes (a) views whose ROWS are the contiguous direction
+// (row stride 1: reductions over leading axes) as they are, and (b) many short contiguous rows
+// after transposing them into a [cols, rows] scratch.  Returns XHIST_ERR_UNSUPPORTED when the
+// shape is better served by the row-streaming kernels.
+static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows, int64_t n_cols,
+                         void* out, int accumulate, hipStream_t stream, bool prefer, int profile) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  if (p->cmp != XHIST_CMP_F64 || D > 3 || n_cols >= ((int64_t)1 << 31) || p->n_bins >= (1 << 16)) return XHIST_ERR_UNSUPPORTED;
+  const int sdt = samples[0].dtype, wdt = weighted ? weights->dtype : -1;
+  if ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)) return XHIST_ERR_UNSUPPORTED;
+  // shape class of every array: natural (row stride 0/1, any column stride) or needs a transpose
+  // (unit column stride, dense-ish rows)
+  bool all_natural = true, all_rowmajor = true;
+  for (int d = 0; d <= D; ++d) {
+    if (d == D && !weighted) break;
+    const xhist_array& a = d < D ? samples[d] : *weights;
+    if (d < D && a.dtype != sdt) return XHIST_ERR_UNSUPPORTED;
+    const bool bcast = a.row_stride == 0 || a.col_stride == 0;
+    const bool natural = bcast || (a.row_stride == 1 && a.col_stride >= n_rows);
+    const bool rowmajor = bcast || (a.col_stride == 1 && a.row_stride >= n_cols);
+    all_natural &= natural;
+    all_rowmajor &= rowmajor;
+  }
+  const bool use_f32 = sdt == XHIST_F32 && p->d_tables_f != nullptr;
+  const size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
+  if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  bool transpose = false;
+  if (all_natural && (samples[0].row_stride == 1 || prefer)) {
+    // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
+  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 1536 : 800)))) {
+    // many short rows.  Measured crossovers with the row-streaming kernels (profiles/r01_f_shapes.jsonl):
+    // ~2000 columns for the fused kernel (one unweighted input), ~1000 for scratch-transpose + lanes
+    transpose = true;
+  } else {
+    return XHIST_ERR_UNSUPPORTED;
+  }
+
+  const int mc = use_f32 ? p->max_cnt_f : p->max_cnt;
+  const int scan = (mc >= 1 && mc <= 4) ? mc : 0;
+  int vec = 1;
+  kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes, &vec);
+  if (!fn) return XHIST_ERR_UNSUPPORTED;
+
+  // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
+  if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {
+    const int es = dtype_size(sdt);
+    const size_t hist_bytes = (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
+    const size_t lds_f = ((table_bytes + hist_bytes + 15) & ~(size_t)15) + (size_t)kLaneBlock * (128 / es + 1) * es;
+    kernel_fn_rows1 f1 = rows1_kernel(sdt, scan);
+    if (f1 && lds_f <= p->lds_max) {
+      Params kp;
+      memset(&kp, 0, sizeof kp);
+      kp.s_ptr[0] = samples[0].data;
+      kp.s_rs[0] = samples[0].row_stride;
+      kp.s_cs[0] = 1;
+      kp.s_dt[0] = sdt;
+      kp.dim[0] = (use_f32 ? p->dimf : p->dim)[0];
+      kp.n_dims = 1;
+      kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
+      kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+      kp.tables_in_lds = 1;
+      kp.n_rows = n_rows;
+      kp.n_cols = n_cols;
+      kp.n_bins = p->n_bins;
+      kp.out = out;
+      const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
+      if (row_blocks > 2147483647LL) return XHIST_ERR_UNSUPPORTED;
+      const int direct = accumulate ? 0 : 1;
+      int ring_slot = -1;
+      if (profile) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        ring_slot = (int)(p->n_recorded % profile);
+        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
+      }
+      if (lds_f > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      hipLaunchKernelGGL(f1, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_f, stream, kp, (int32_t)direct);
+      HIPC(hipGetLastError());
+      std::lock_guard<std::mutex> lk(p->mu);
+      if (ring_slot >= 0) {
+        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
+        ++p->n_recorded;
+      }
+      char desc[384];
+      snprintf(desc, sizeof desc,
+               "family=lanes hist=lds16 transpose=fused direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=0 D=1 cmp=%s",
+               direct, kLaneBlock, (long long)row_blocks, lds_f, scan, use_f32 ? "f32thr" : "f64");
+      p->desc = desc;
+      return XHIST_OK;
+    }
+  }
+
+  void* scratch[kMaxDims + 1] = {nullptr};
+  auto release = [&](int rc) {
+    for (auto s : scratch)
+      if (s) (void)hipFreeAsync(s, stream);
+    return rc;
+  };
+#define HIPL(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+
+  Params kp;
+  memset(&kp, 0, sizeof kp);
+  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  int ring_slot = -1;
+  if (profile) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    ring_slot = (int)(p->n_recorded % profile);
+    HIPL(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
+  }
+  for (int d = 0; d <= D; ++d) {
+    if (d == D && !weighted) break;
+    const xhist_array& a = d < D ? samples[d] : *weights;
+    const void* ptr = a.data;
+    int64_t rs = a.row_stride, cs = a.col_stride;
+    if (transpose && rs != 0 && cs != 0) {
+      const int es = dtype_size(a.dtype);
+      HIPL(hipMallocAsync(&scratch[d], (size_t)n_rows * n_cols * es, stream));
+      const dim3 grid((unsigned)((n_rows + 63) / 64), (unsigned)((n_cols + 63) / 64));
+      if (es == 8)
+        hipLaunchKernelGGL(transpose_2d<double>, grid, dim3(256), 0, stream, (const double*)a.data, rs, n_rows, n_cols, (double*)scratch[d]);
+      else
+        hipLaunchKernelGGL(transpose_2d<float>, grid, dim3(256), 0, stream, (const float*)a.data, rs, n_rows, n_cols, (float*)scratch[d]);
+      HIPL(hipGetLastError());
+      ptr = scratch[d];
+      rs = 1;
+      cs = n_rows;
+    }
+    if (d < D) {
+      kp.s_ptr[d] = ptr;
+      kp.s_rs[d] = rs;
+      kp.s_cs[d] = cs;
+      kp.s_dt[d] = a.dtype;
+      kp.dim[d] = dims[d];
+    } else {
+      kp.w_ptr = ptr;
+      kp.w_rs = rs;
+      kp.w_cs = cs;
+      kp.w_dt = a.dtype;
+    }
+  }
+  kp.n_dims = D;
+  kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
+  kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+  kp.tables_in_lds = 1;
+  kp.n_rows = n_rows;
+  kp.n_cols = n_cols;
+  kp.n_bins = p->n_bins;
+  kp.out = out;
+
+  const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
+  const int bpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds_bytes));
+  int64_t col_segs = std::max<int64_t>(1, ((int64_t)p->cus * bpc * 2 + row_blocks - 1) / row_blocks);
+  col_segs = std::min<int64_t>(col_segs, std::max<int64_t>(1, n_cols / 64));
+  col_segs = std::min<int64_t>(col_segs, 65535);
+  const int64_t cols_per_seg = (n_cols + col_segs - 1) / col_segs;
+  col_segs = (n_cols + cols_per_seg - 1) / cols_per_seg;
+  const int direct = (col_segs == 1 && !accumulate) ? 1 : 0;
+  if (!direct && !accumulate) HIPL(hipMemsetAsync(out, 0, (size_t)n_rows * p->n_bins * 8, stream));
+  if (row_blocks > 2147483647LL) return release(XHIST_ERR_UNSUPPORTED);
+  if (lds_bytes > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_bytes, stream, kp, (int32_t)direct,
+                     cols_per_seg);
+  HIPL(hipGetLastError());
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (ring_slot >= 0) {
+      HIPL(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
+      ++p->n_recorded;
+    }
+    char desc[384];
+    snprintf(desc, sizeof desc,
+             "family=lanes hist=lds transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
+             (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_bytes, scan, (int)weighted, D,
+             use_f32 ? "f32thr" : "f64");
+    p->desc = desc;
+  }
+#undef HIPL
+  return release(XHIST_OK);
+}
+
 static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
                           int64_t n_cols, void* out, int accumulate, hipStream_t stream) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
   const int64_t out_elems = n_rows * p->n_bins;
-  if (!accumulate && out_elems > 0) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
-  if (out_elems == 0 || n_cols == 0) return XHIST_OK;
+  if (out_elems == 0) return XHIST_OK;
+  if (n_cols == 0) {
+    if (!accumulate) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
+    return XHIST_OK;
+  }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
+    lanes = p->lanes;
   }
+
+  // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
+  if (lanes >= 0 && !force_generic && !force_global) {
+    const int rc = execute_lanes(p, samples, weights, n_rows, n_cols, out, accumulate, stream, lanes > 0, profile);
+    if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = not this shape, fall through
+  }
+  if (!accumulate && out_elems > 0) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
 
   // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
   const size_t lds_cap = p->lds_max;
@@ -686,14 +907,13 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
               (sdt == XHIST_F64 || sdt == XHIST_F32) && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32);
   if (fast) {
     vec = 16 / std::max(dtype_size(sdt), wdt < 0 ? 0 : dtype_size(wdt));
+    // unit column stride is all the vector family needs: gfx950 vector loads take any
+    // element-aligned address (rows of 365 or 3650 samples stay on 16-byte loads)
     for (int d = 0; d < D && fast; ++d) {
       const xhist_array& a = samples[d];
-      fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)(vec * dtype_size(sdt)) == 0) &&
-             (n_rows == 1 || a.row_stride % vec == 0);
+      fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)dtype_size(sdt) == 0);
     }
-    if (fast && weighted)
-      fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)(vec * dtype_size(wdt)) == 0) &&
-             (n_rows == 1 || weights->row_stride % vec == 0);
+    if (fast && weighted) fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
   }
   // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
   bool use_f32 = fast && sdt == XHIST_F32 && p->d_tables_f != nullptr;

@@ -269,8 +269,11 @@ __device__ __forceinline__ const uint64_t* stage_tables(const Params& p) {
 // Work split: workgroups (row, seg); the `segs` workgroups of a row walk its tiles interleaved
 // (tile = seg, seg + segs, ...) so that the whole grid sweeps HBM as one front.
 // ---------------------------------------------------------------------------------------------
+// N-element vectors that may sit at any ELEMENT-aligned address: gfx950 global loads need only
+// dword alignment, so rows whose stride is not a multiple of 16 bytes (C = 365, 3650, ...) still
+// take 16-byte loads.
 template <typename T, int N>
-struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+struct VecOf { typedef T type __attribute__((ext_vector_type(N), aligned(sizeof(T)))); };
 
 // HIST: where a workgroup accumulates
 //   kHistGlobal  device-scope atomics straight into the output (histogram too large for LDS)
@@ -363,9 +366,9 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   const int64_t n_tiles = (p.n_cols + tile_elems - 1) / tile_elems;
   for (int64_t tile = seg; tile < n_tiles; tile += p.segs) {
     const int64_t base = tile * tile_elems;
+    svec xv[D][UNROLL];
+    wvec wv[UNROLL];
     if (base + tile_elems <= p.n_cols) {
-      svec xv[D][UNROLL];
-      wvec wv[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         const int64_t i = base + ((int64_t)u * blockDim.x + tid) * VEC;
@@ -374,6 +377,29 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
           xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(sp[d] + i));
         if (kWeighted) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + i));
       }
+    } else {
+      // ragged last tile (for a short row: the whole row): vectors that fit are loaded whole, the
+      // rest element-wise, and positions past the end become NaN samples, which digitize drops —
+      // so the batch below runs unchanged
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + ((int64_t)u * blockDim.x + tid) * VEC;
+        if (i + VEC <= p.n_cols) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) xv[d][u] = *reinterpret_cast<const svec*>(sp[d] + i);
+          if (kWeighted) wv[u] = *reinterpret_cast<const wvec*>(wp + i);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const bool in = i + v < p.n_cols;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xv[d][u][v] = in ? sp[d][i + v] : (ST)__builtin_nanf("");
+            if (kWeighted) wv[u][v] = in ? wp[i + v] : (wscalar)0;
+          }
+        }
+      }
+    }
+    {
       // whole tile as one branch-free batch: the table reads of all samples are independent
       uint32_t cnt[D][UNROLL][VEC];  // #{edges <= x} per sample and dimension
       if constexpr (SCAN > 0) {
@@ -437,19 +463,6 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) packed_fix(okv[u][v], flatv[u][v], oldv[u][v]);
-      }
-    } else {  // ragged last tile: scalar, bounds-checked
-      for (int64_t i = base + tid; i < p.n_cols; i += blockDim.x) {
-        bool ok = true;
-        uint32_t flat = 0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const int b = digitize<CMP>((CT)sp[d][i], p.dim[d], tab);
-          ok &= (b >= 0);
-          flat = (d == 0) ? (uint32_t)b : flat * (uint32_t)p.dim[d].nb + (uint32_t)b;
-        }
-        if (HIST == kHistPacked) packed_fix(ok, flat, packed_add(ok, flat));
-        else scatter(ok, flat, kWeighted ? (double)wp[i] : 0.0);
       }
     }
   }

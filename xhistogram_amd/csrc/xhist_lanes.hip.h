@@ -1,0 +1,231 @@
+// xhist_lanes.hip.h — "one row per lane" kernels for MANY SHORT ROWS and for reductions over LEADING
+// axes (dim="time" of (time, lat, lon)), the shapes the reference's `block_size` loop exists for
+// (core.py:86-134).
+//
+// hist_fast gives every row its own workgroup(s): perfect for long rows (C4: 10^6 columns), but a
+// row of 20..4000 samples cannot amortise zeroing and flushing an LDS histogram, and when the rows
+// are the contiguous direction (row stride 1, column stride M) its column-wise streaming is
+// uncoalesced.  Here the mapping is transposed:
+//   lane  <-> row r            (256 consecutive rows per workgroup: loads x[r + c * col_stride]
+//                               are coalesced across lanes)
+//   loop  <-> columns c        (UNROLL independent loads in flight per lane)
+//   LDS   <-> hist[bin][lane]  (row pitch 257: lane-private, conflict-free, no cross-lane atomics)
+// and the finished 256 x nbins tile is written out transposed through LDS with coalesced stores.
+// If the rows alone fill the GPU, every output element is written exactly once by plain stores:
+// no memset, no global atomics.  Few rows: the columns are split over blockIdx.y and the partial
+// tiles are added with global atomics.
+//
+// Rows that are contiguous in memory ([M, C] row-major, C small) are first transposed into a
+// [C, M] scratch by transpose_2d (tiled through LDS), then take the same kernel.
+#pragma once
+
+#include "xhist_kernels.hip.h"
+
+namespace xhist {
+
+constexpr int kLaneBlock = 256, kLanePitch = kLaneBlock + 1;
+
+template <typename ST, typename WT, int D, int SCAN, int UNROLL>
+__global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t direct_store, int64_t cols_per_seg) {
+  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  using CT = typename Dom<CMP>::T;
+  constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  using cnt_t = typename std::conditional<kWeighted, double, uint32_t>::type;
+  using out_t = typename std::conditional<kWeighted, double, unsigned long long>::type;
+
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kLaneBlock;
+  const int rows_here = (int)min<int64_t>(kLaneBlock, p.n_rows - r0);
+  const int64_t r = r0 + min(tid, rows_here - 1);  // lanes past the last row shadow it; never written out
+  const uint64_t* tab = stage_tables(p);
+  cnt_t* hist = reinterpret_cast<cnt_t*>(xhist_smem + (size_t)p.table_words * 8);
+  const uint32_t nb = (uint32_t)p.n_bins;
+  for (uint32_t i = tid; i < nb * kLanePitch; i += kLaneBlock) hist[i] = (cnt_t)0;
+  __syncthreads();
+
+  const ST* sp[D];
+  int64_t scs[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + r * p.s_rs[d];
+    scs[d] = p.s_cs[d];
+  }
+  const wscalar* wp = kWeighted ? reinterpret_cast<const wscalar*>(p.w_ptr) + r * p.w_rs : nullptr;
+  int max_steps = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
+
+  const int64_t c_lo = (int64_t)blockIdx.y * cols_per_seg;
+  const int64_t c_hi = min(p.n_cols, c_lo + cols_per_seg);
+  cnt_t* mine = hist + tid;
+
+  auto bin_and_add = [&](const ST (&x)[D], wscalar w) {
+    bool ok = true;
+    uint32_t flat = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      uint32_t cnt;
+      if constexpr (SCAN > 0) {
+        cnt = count_le_scan<CMP, SCAN>((CT)x[d], p.dim[d], tab);
+      } else {
+        DigState s = digitize_begin<CMP>((CT)x[d], p.dim[d], tab);
+        for (int k = 1; k < max_steps; ++k) upper_bound_step<CMP>((CT)x[d], p.dim[d], tab, s);
+        cnt = s.lo;
+      }
+      const int b = bin_from_count<CMP>((CT)x[d], p.dim[d], cnt);
+      ok &= (b >= 0);
+      flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
+    }
+    cnt_t* slot = mine + (ok ? flat : 0u) * kLanePitch;
+    if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(slot), ok ? (double)w : 0.0);
+    else atomicAdd(reinterpret_cast<uint32_t*>(slot), ok ? 1u : 0u);
+  };
+
+  int64_t c = c_lo;
+  for (; c + UNROLL <= c_hi; c += UNROLL) {
+    ST xv[UNROLL][D];
+    wscalar wv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xv[u][d] = __builtin_nontemporal_load(sp[d] + (c + u) * scs[d]);
+      if (kWeighted) wv[u] = __builtin_nontemporal_load(wp + (c + u) * p.w_cs);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) bin_and_add(xv[u], kWeighted ? wv[u] : (wscalar)0);
+  }
+  for (; c < c_hi; ++c) {
+    ST x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = sp[d][c * scs[d]];
+    bin_and_add(x, kWeighted ? wp[c * p.w_cs] : (wscalar)0);
+  }
+
+  // transposed write-out: linear element j of the [rows_here, nb] output tile <- hist[b][row]
+  __syncthreads();
+  out_t* out = reinterpret_cast<out_t*>(p.out) + r0 * nb;
+  const uint32_t total = (uint32_t)rows_here * nb;
+  for (uint32_t j = tid; j < total; j += kLaneBlock) {
+    const uint32_t row = j / nb, b = j - row * nb;
+    const cnt_t v = hist[b * kLanePitch + row];
+    if (direct_store) {
+      out[j] = (out_t)v;
+    } else if (v != (cnt_t)0) {
+      if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(out) + j, (double)v);
+      else atomicAdd(reinterpret_cast<unsigned long long*>(out) + j, (unsigned long long)v);
+    }
+  }
+}
+
+// Fused form for the commonest short-row case (one input, unweighted, rows contiguous in memory,
+// fewer than 65536 columns): the [256 rows x 128 bytes] chunk is loaded coalesced along the rows,
+// turned around in LDS (pitch W+1: conflict-free both ways) and consumed one row per lane, so the
+// data is read from HBM exactly once and no transposed copy exists.  Counters are uint16, two rows
+// per LDS word (a row has < 65536 samples, so they cannot overflow): 50 bins cost 26 KB, not 51.
+template <typename ST, int SCAN>
+__global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, int32_t direct_store) {
+  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  using CT = typename Dom<CMP>::T;
+  constexpr int W = 128 / (int)sizeof(ST);   // columns per chunk: 32 f32 / 16 f64
+  constexpr int VL = 16 / (int)sizeof(ST);   // elements per 16-byte load
+  constexpr int TPR = W / VL;                // 8 lanes cover one row's chunk
+  constexpr int RPP = kLaneBlock / TPR;      // 32 rows per pass
+  constexpr int PASSES = kLaneBlock / RPP;   // 8 passes cover the 256 rows
+  constexpr int PITCH = W + 1;
+  constexpr int HP = kLaneBlock / 2 + 1;     // histogram row pitch in words (2 rows per word)
+  using lvec = typename VecOf<ST, VL>::type;
+
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kLaneBlock;
+  const int rows_here = (int)min<int64_t>(kLaneBlock, p.n_rows - r0);
+  const uint64_t* tab = stage_tables(p);
+  const uint32_t nb = (uint32_t)p.n_bins;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(xhist_smem + (size_t)p.table_words * 8);
+  ST* tile = reinterpret_cast<ST*>(xhist_smem + (((size_t)p.table_words * 8 + (size_t)nb * HP * 4 + 15) & ~(size_t)15));
+  for (uint32_t i = tid; i < nb * HP; i += kLaneBlock) hist[i] = 0u;
+
+  const ST* base = reinterpret_cast<const ST*>(p.s_ptr[0]) + r0 * p.s_rs[0];
+  const int64_t rs = p.s_rs[0];
+  const int lrow = tid / TPR, lcol = (tid % TPR) * VL;
+  const DimTable& t = p.dim[0];
+  uint32_t* myword = hist + (tid >> 1);
+  const uint32_t myinc = 1u << ((tid & 1) << 4);
+
+  auto load_chunk = [&](int64_t c0, lvec (&v)[PASSES]) {
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int row = k * RPP + lrow;
+      const int64_t col = c0 + lcol;
+      const ST* src = base + (int64_t)row * rs + col;
+      if (row < rows_here && col + VL <= p.n_cols) {
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(src));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VL; ++j) v[k][j] = (row < rows_here && col + j < p.n_cols) ? src[j] : (ST)__builtin_nanf("");
+      }
+    }
+  };
+
+  lvec cur[PASSES], nxt[PASSES];
+  load_chunk(0, cur);
+  for (int64_t c0 = 0; c0 < p.n_cols; c0 += W) {
+    if (c0 + W < p.n_cols) load_chunk(c0 + W, nxt);  // in flight across the LDS phases below
+    __syncthreads();                                   // the previous chunk has been consumed
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k)
+#pragma unroll
+      for (int j = 0; j < VL; ++j) tile[(k * RPP + lrow) * PITCH + lcol + j] = cur[k][j];
+    __syncthreads();
+    const ST* mine = tile + tid * PITCH;
+#pragma unroll 8
+    for (int c = 0; c < W; ++c) {
+      const CT x = (CT)mine[c];
+      uint32_t cnt;
+      if constexpr (SCAN > 0) {
+        cnt = count_le_scan<CMP, SCAN>(x, t, tab);
+      } else {
+        DigState s = digitize_begin<CMP>(x, t, tab);
+        for (int k = 1; k < t.steps; ++k) upper_bound_step<CMP>(x, t, tab, s);
+        cnt = s.lo;
+      }
+      const int b = bin_from_count<CMP>(x, t, cnt);
+      atomicAdd(myword + (b >= 0 ? (uint32_t)b : 0u) * HP, b >= 0 ? myinc : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) cur[k] = nxt[k];
+  }
+
+  __syncthreads();
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(p.out) + r0 * nb;
+  const uint32_t total = (uint32_t)rows_here * nb;
+  for (uint32_t j = tid; j < total; j += kLaneBlock) {
+    const uint32_t row = j / nb, b = j - row * nb;
+    const unsigned long long v = (hist[b * HP + (row >> 1)] >> ((row & 1) << 4)) & 0xffffu;
+    if (direct_store) out[j] = v;
+    else if (v) atomicAdd(out + j, v);
+  }
+}
+
+// [n_rows, n_cols] (row stride `rs` elements, unit column stride) -> dense [n_cols, n_rows].
+// 64 x 64 tiles through LDS (pitch 65): coalesced 256-byte reads along rows, writes along columns.
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_2d(const T* __restrict__ in, int64_t rs, int64_t n_rows, int64_t n_cols,
+                                                     T* __restrict__ out) {
+  __shared__ T tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;  // rows on x: up to 2^31 tiles
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t rr = r0 + ty + 4 * k, cc = c0 + tx;
+    if (rr < n_rows && cc < n_cols) tile[ty + 4 * k][tx] = in[rr * rs + cc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t cc = c0 + ty + 4 * k, rr = r0 + tx;
+    if (rr < n_rows && cc < n_cols) out[cc * n_rows + rr] = tile[tx][ty + 4 * k];
+  }
+}
+
+}  // namespace xhist
