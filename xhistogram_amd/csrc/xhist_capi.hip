@@ -81,17 +81,21 @@ static bool dtype_is_int(int dt) { return dt >= XHIST_I64 && dt <= XHIST_BOOL; }
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
+struct TableSet {
+  DimTable dim[kMaxDims];
+  uint64_t* blob = nullptr;  // device: [edges + 4 sentinels per dimension][bucket tables]
+  int32_t words = 0;         // blob size in 8-byte words
+  int max_cnt = 0;           // most edges sharing one bucket
+};
+
 struct xhist_plan {
   int device = 0;
   int n_dims = 0;
   int cmp = 0;
-  DimTable dim[kMaxDims];   // native domain (float64 or int64)
-  uint64_t* d_tables = nullptr;
-  int32_t table_words = 0;
-  DimTable dimf[kMaxDims];  // float32-threshold domain (float64 plans only)
-  uint64_t* d_tables_f = nullptr;
-  int32_t table_words_f = 0;
-  int max_cnt = 0, max_cnt_f = 0;  // most edges sharing one bucket, per domain
+  // table sets: [compare domain: 0 native (float64 / int64), 1 float32 thresholds (float64 plans)]
+  //             [0: (start | cnt << 16) uint32 buckets, 1: uint16 start-only buckets on a 2x finer
+  //                 grid for the linear-scan kernels (float domains only)]
+  TableSet ts[2][2];
   int64_t n_bins = 0;
   int cus = 256;
   size_t lds_max = 64 * 1024;
@@ -143,9 +147,12 @@ extern "C" int xhist_device_info(int device, char* name, size_t name_cap, int* c
 //   [per-dimension edge arrays, 8-byte aligned] [per-dimension bucket tables (uint32 x K)]
 // dom: 0 float64, 1 int64, 2 float32 thresholds.  `words[d]` holds dimension d's edge array
 // already converted to the domain's element type; `edges` are the caller's original arrays.
-static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_edges,
-                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, DimTable* dims,
-                        uint64_t** d_blob_out, int32_t* table_words_out, int* max_cnt_out) {
+static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const int64_t* n_edges,
+                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, TableSet* ts) {
+  DimTable* dims = ts->dim;
+  uint64_t** d_blob_out = &ts->blob;
+  int32_t* table_words_out = &ts->words;
+  int* max_cnt_out = &ts->max_cnt;
   int32_t edge_off = 0;
   int64_t max_e = 0;
   for (int d = 0; d < n_inputs; ++d) {
@@ -178,6 +185,7 @@ static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_e
       range = (double)((float)t.eL_f - (float)t.e0_f);
     }
     int K = std::min(4096, std::max(8, next_pow2(4 * E)));
+    if (lut16) K *= 2;  // 2-byte entries: twice the buckets for the same LDS bytes
     double scale = (double)K / range;
     if (dom == 2) scale = (double)(float)scale;
     if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
@@ -192,12 +200,14 @@ static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_e
     dims[d].out_stride = stride;
     stride *= dims[d].nb;
   }
-  int32_t off4 = 2 * edge_off;
+  // bucket tables follow the edges; lut_off counts table ENTRIES (4-byte, or 2-byte for lut16)
+  int32_t off = (lut16 ? 4 : 2) * edge_off;
   for (int d = 0; d < n_inputs; ++d) {
-    dims[d].lut_off = off4;
-    off4 += dims[d].lut_k;
+    dims[d].lut_off = off;
+    off += dims[d].lut_k;
   }
-  const int32_t table_words = (off4 + 1) / 2;
+  const int32_t per_word = lut16 ? 4 : 2;
+  const int32_t table_words = (off + per_word - 1) / per_word;
   std::vector<uint64_t> blob((size_t)table_words, 0);
   for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + dims[d].edge_off, words[d].data(), words[d].size() * 8);
 
@@ -217,21 +227,30 @@ static int build_domain(xhist_plan* p, int dom, int n_inputs, const int64_t* n_e
   HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
   HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
   for (int d = 0; d < n_inputs; ++d) {
-    if (dom == 0) hipLaunchKernelGGL(build_tables<0>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else if (dom == 1) hipLaunchKernelGGL(build_tables<1>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else hipLaunchKernelGGL(build_tables<2>, dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    if (dom == 0 && !lut16) hipLaunchKernelGGL((build_tables<0, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (dom == 0) hipLaunchKernelGGL((build_tables<0, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (dom == 1) hipLaunchKernelGGL((build_tables<1, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (!lut16) hipLaunchKernelGGL((build_tables<2, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else hipLaunchKernelGGL((build_tables<2, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
     HIPP(hipGetLastError());
     HIPP(hipDeviceSynchronize());
   }
   HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));
 #undef HIPP
   const uint32_t* lut4 = reinterpret_cast<const uint32_t*>(blob.data());
+  const uint16_t* lut2 = reinterpret_cast<const uint16_t*>(blob.data());
   for (int d = 0; d < n_inputs; ++d) {
     DimTable& t = dims[d];
     uint32_t maxcnt = 0;
     uint64_t total = 0;
     for (int b = 0; b < t.lut_k; ++b) {
-      const uint32_t cnt = lut4[t.lut_off + b] >> 16;
+      uint32_t cnt;
+      if (lut16) {
+        const uint32_t next = b + 1 < t.lut_k ? lut2[t.lut_off + b + 1] : (uint32_t)t.n_edges;
+        cnt = next - lut2[t.lut_off + b];
+      } else {
+        cnt = lut4[t.lut_off + b] >> 16;
+      }
       maxcnt = std::max(maxcnt, cnt);
       total += cnt;
     }
@@ -320,7 +339,8 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   const uint64_t kNaN64 = 0x7ff8000000000000ull;
   for (int d = 0; d < n_inputs; ++d)
     for (int k = 0; k < 4; ++k) words[d].push_back(cmp_domain == XHIST_CMP_F64 ? kNaN64 : 0x7fffffffffffffffull);
-  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, n_inputs, n_edges, words, edges, p->dim, &p->d_tables, &p->table_words, &p->max_cnt);
+  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0]);
+  if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
   if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
     for (int d = 0; d < n_inputs; ++d) {
@@ -335,11 +355,13 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
       words[d].assign(((size_t)E + 5) / 2, 0);
       memcpy(words[d].data(), thr.data(), words[d].size() * 8);
     }
-    rc = build_domain(p, 2, n_inputs, n_edges, words, edges, p->dimf, &p->d_tables_f, &p->table_words_f, &p->max_cnt_f);
+    rc = build_domain(p, 2, false, n_inputs, n_edges, words, edges, &p->ts[1][0]);
+    if (rc == XHIST_OK) rc = build_domain(p, 2, true, n_inputs, n_edges, words, edges, &p->ts[1][1]);
   }
   if (rc != XHIST_OK) {
-    if (p->d_tables) (void)hipFree(p->d_tables);
-    if (p->d_tables_f) (void)hipFree(p->d_tables_f);
+    for (auto& dom : p->ts)
+      for (auto& t : dom)
+        if (t.blob) (void)hipFree(t.blob);
     delete p;
     return rc;
   }
@@ -352,8 +374,9 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
   if (!p) return XHIST_OK;
   DeviceGuard g;
   if (g.set(p->device) == XHIST_OK) {
-    if (p->d_tables) (void)hipFree(p->d_tables);
-    if (p->d_tables_f) (void)hipFree(p->d_tables_f);
+    for (auto& dom : p->ts)
+      for (auto& t : dom)
+        if (t.blob) (void)hipFree(t.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   delete p;
@@ -428,6 +451,19 @@ extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n
 // ------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------
+// Tables for the vector / lanes / partition kernels: the finer uint16 set whenever none of its
+// buckets holds more than 4 edges (linear scan, *scan = that maximum), else the uint32
+// (start, cnt) set with the branch-free binary search (*scan = 0).
+static const TableSet& pick_tables(const xhist_plan* p, bool use_f32, int* scan) {
+  const TableSet& fine = p->ts[use_f32 ? 1 : 0][1];
+  if (fine.blob && fine.max_cnt >= 1 && fine.max_cnt <= 4) {
+    *scan = fine.max_cnt;
+    return fine;
+  }
+  *scan = 0;
+  return p->ts[use_f32 ? 1 : 0][0];
+}
+
 typedef void (*kernel_fn)(const Params);
 typedef void (*kernel_fn_acc)(const uint16_t*, const double*, const uint64_t*, void*, int64_t, int, int);
 typedef void (*kernel_fn_count)(const Params, uint32_t*);
@@ -571,7 +607,8 @@ static const void* advance(const void* base, int dt, int64_t elems) {
 // Partitioned mode (xhist_partition.hip.h): count -> prefix -> scatter -> accumulate, all on
 // `stream`, scratch from the stream-ordered allocator (so concurrent callers never share it).
 static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
-                               hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, int shift, int n_parts, int profile) {
+                               hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
+                               int n_parts, int profile) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
   if (n_cols >= ((int64_t)1 << 40)) return XHIST_ERR_UNSUPPORTED;
@@ -580,7 +617,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   if (!k_count) return XHIST_ERR_UNSUPPORTED;
   kernel_fn_scatter k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight>
                                         : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double> : (kernel_fn_scatter)part_scatter<float>);
-  const size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_count = table_bytes + (size_t)(n_parts + 1) * 32 * 4;
   const size_t lds_scatter = 6144 + (size_t)kPartTile * (weighted ? 16 : 4);
   const size_t lds_acc = (size_t)(1u << shift) * (weighted ? 8 : 4);
@@ -618,7 +655,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
 
   Params kp;
   memset(&kp, 0, sizeof kp);
-  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  const DimTable* dims = tset.dim;
   for (int d = 0; d < D; ++d) {
     kp.s_ptr[d] = samples[d].data;
     kp.s_rs[d] = samples[d].row_stride;
@@ -633,8 +670,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
     kp.w_dt = weights->dtype;
   }
   kp.n_dims = D;
-  kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
-  kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+  kp.tables = tset.blob;
+  kp.table_words = tset.words;
   kp.tables_in_lds = 1;
   kp.n_rows = 1;
   kp.n_cols = n_cols;
@@ -711,8 +748,10 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     all_natural &= natural;
     all_rowmajor &= rowmajor;
   }
-  const bool use_f32 = sdt == XHIST_F32 && p->d_tables_f != nullptr;
-  const size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  const bool use_f32 = sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+  int scan = 0;
+  const TableSet& tset = pick_tables(p, use_f32, &scan);
+  const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
   if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   bool transpose = false;
@@ -726,8 +765,6 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     return XHIST_ERR_UNSUPPORTED;
   }
 
-  const int mc = use_f32 ? p->max_cnt_f : p->max_cnt;
-  const int scan = (mc >= 1 && mc <= 4) ? mc : 0;
   int vec = 1;
   kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes, &vec);
   if (!fn) return XHIST_ERR_UNSUPPORTED;
@@ -745,10 +782,10 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       kp.s_rs[0] = samples[0].row_stride;
       kp.s_cs[0] = 1;
       kp.s_dt[0] = sdt;
-      kp.dim[0] = (use_f32 ? p->dimf : p->dim)[0];
+      kp.dim[0] = tset.dim[0];
       kp.n_dims = 1;
-      kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
-      kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+      kp.tables = tset.blob;
+      kp.table_words = tset.words;
       kp.tables_in_lds = 1;
       kp.n_rows = n_rows;
       kp.n_cols = n_cols;
@@ -794,7 +831,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
 
   Params kp;
   memset(&kp, 0, sizeof kp);
-  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  const DimTable* dims = tset.dim;
   int ring_slot = -1;
   if (profile) {
     std::lock_guard<std::mutex> lk(p->mu);
@@ -833,8 +870,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     }
   }
   kp.n_dims = D;
-  kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
-  kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+  kp.tables = tset.blob;
+  kp.table_words = tset.words;
   kp.tables_in_lds = 1;
   kp.n_rows = n_rows;
   kp.n_cols = n_cols;
@@ -916,12 +953,17 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     if (fast && weighted) fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
   }
   // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
-  bool use_f32 = fast && sdt == XHIST_F32 && p->d_tables_f != nullptr;
-  size_t table_bytes = (size_t)(use_f32 ? p->table_words_f : p->table_words) * 8;
+  bool use_f32 = fast && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+  int scan = 0;
+  const TableSet* tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
+  if (fast) tset = &pick_tables(p, use_f32, &scan);
+  size_t table_bytes = (size_t)tset->words * 8;
   if (fast && table_bytes + 1024 > lds_cap) {  // the fast family keeps its tables in LDS
     fast = false;
     use_f32 = false;
-    table_bytes = (size_t)p->table_words * 8;
+    scan = 0;
+    tset = &p->ts[0][0];
+    table_bytes = (size_t)tset->words * 8;
   }
   const bool tables_fit = table_bytes + 1024 <= lds_cap;
 
@@ -955,17 +997,15 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const bool tables_in_lds = tables_fit;
   const size_t lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
 
-  // linear in-bucket count when no bucket holds more than 4 edges (always for uniform bins)
-  const int mc = use_f32 ? p->max_cnt_f : p->max_cnt;
-  const int scan = (fast && mc >= 1 && mc <= 4) ? mc : 0;
+  // (scan > 0: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
   kernel_fn fn = nullptr;
   if (fast) fn = fast_kernel(sdt, wdt, D, scan, hist, &vec);
   if (!fn) {
-    if (hist == kHistPacked) return fail(XHIST_ERR_HIP, "internal: packed histogram without a fast kernel");
+    if (hist == kHistPacked || scan != 0 || use_f32) return fail(XHIST_ERR_HIP, "internal: no vector kernel for this combination");
     fast = false;
     fn = generic_kernel(p->cmp, weighted, lds_hist);
   }
-  const DimTable* dims = use_f32 ? p->dimf : p->dim;
+  const DimTable* dims = tset->dim;
 
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
   if (fast && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
@@ -973,8 +1013,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || partition > 0;
     if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
-      const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, shift, (int)n_parts,
-                                         profile);
+      const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, *tset, shift,
+                                         (int)n_parts, profile);
       if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = fall through to global atomics
     }
   }
@@ -1035,8 +1075,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         kp.w_dt = weights->dtype;
       }
       kp.n_dims = D;
-      kp.tables = use_f32 ? p->d_tables_f : p->d_tables;
-      kp.table_words = use_f32 ? p->table_words_f : p->table_words;
+      kp.tables = tset->blob;
+      kp.table_words = tset->words;
       kp.tables_in_lds = tables_in_lds ? 1 : 0;
       kp.n_rows = nr;
       kp.n_cols = nc;

@@ -171,7 +171,8 @@ __device__ __forceinline__ void digitize_more(typename Dom<CMP>::T x, const DimT
 }
 
 // Linear form of the in-bucket count for tables whose buckets hold at most SCAN (<= 4) edges —
-// every uniform-bin histogram has SCAN = 1.  Each dimension's edge array is followed by 4 NaN
+// every uniform-bin histogram has SCAN = 1.  These kernels use the plan's SECOND table set:
+// uint16 `start` entries (no count is needed) on a grid twice as fine for the same LDS bytes.  Each dimension's edge array is followed by 4 NaN
 // sentinels, and edges past the bucket's own ones lie in HIGHER buckets, hence are > x: so
 //     #{e_j <= x} = start + sum_{k < SCAN} [ e[start + k] <= x ]
 // with no count field, no clamping and no data-dependent control flow: SCAN independent LDS
@@ -179,8 +180,8 @@ __device__ __forceinline__ void digitize_more(typename Dom<CMP>::T x, const DimT
 template <int CMP, int SCAN, typename TabPtr>
 __device__ __forceinline__ uint32_t count_le_scan(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
   using T = typename Dom<CMP>::T;
-  auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
-  const uint32_t start = lut[bucket_of<CMP>(x, t)] & 0xffffu;
+  auto lut = reinterpret_cast<const uint16_t*>(tab) + t.lut_off;  // start-only table, 2-byte entries
+  const uint32_t start = lut[bucket_of<CMP>(x, t)];
   const T* e = reinterpret_cast<const T*>(tab + t.edge_off) + start;
   uint32_t lo = start;
 #pragma unroll
@@ -560,11 +561,12 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
 // bucket-table builder: one workgroup per dimension applies bucket_of to that dimension's edges
 // (scratch[j] = bucket of edge j) and turns the sorted bucket ids into (start | cnt << 16).
 // ---------------------------------------------------------------------------------------------
-template <int CMP>
+template <int CMP, bool LUT16>
 __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* blob, int32_t* scratch) {
   using T = typename Dom<CMP>::T;
   const T* edges = reinterpret_cast<const T*>(blob + t.edge_off);
   uint32_t* lut = reinterpret_cast<uint32_t*>(blob) + t.lut_off;
+  uint16_t* lut16 = reinterpret_cast<uint16_t*>(blob) + t.lut_off;
   for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x) scratch[j] = bucket_of<CMP>(edges[j], t);
   __syncthreads();
   for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
@@ -574,7 +576,8 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
     const int start = lo;
     hi = t.n_edges;
     while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b + 1) lo = m + 1; else hi = m; }
-    lut[b] = (uint32_t)start | ((uint32_t)(lo - start) << 16);
+    if (LUT16) lut16[b] = (uint16_t)start;
+    else lut[b] = (uint32_t)start | ((uint32_t)(lo - start) << 16);
   }
 }
 
