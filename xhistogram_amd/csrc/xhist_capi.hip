@@ -757,9 +757,10 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   bool transpose = false;
   if (all_natural && (samples[0].row_stride == 1 || prefer)) {
     // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
-  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 1536 : 800)))) {
-    // many short rows.  Measured crossovers with the row-streaming kernels (profiles/r01_f_shapes.jsonl):
-    // ~2000 columns for the fused kernel (one unweighted input), ~1000 for scratch-transpose + lanes
+  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 896 : 384)))) {
+    // many short rows.  Measured crossovers with the row-streaming kernels at 64-thread workgroups
+    // (profiles/r01_f_shapes.jsonl): ~900 columns for the fused kernel (one unweighted input),
+    // ~400 for scratch-transpose + lanes
     transpose = true;
   } else {
     return XHIST_ERR_UNSUPPORTED;
@@ -1025,6 +1026,14 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // (profiles/r01_a_sweep.jsonl) the streaming rate peaks at ~64 KiB of outstanding loads per CU
   // (f64+weights: 2 x 256 threads x 128 B; f64: 4 x 256 x 64 B) and falls by 5-10% with more.
   int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? 1024 : 256);
+  if (!block_threads && n_rows > 1 && lds_bytes <= 40 * 1024) {
+    // many rows, one workgroup each: a tile should be ~1/4 of the row or most of the workgroup
+    // idles in the ragged tile (100k rows x 3650: 0.46 -> 0.39 ms; 356k x 1024: 1.3 -> 0.58 ms)
+    const int64_t per_lane = fast ? (int64_t)vec * unroll_for(D, vec, scan) : 4;
+    int64_t want = n_cols / (4 * per_lane);
+    block = 64;
+    while (block < 256 && block * 2 <= want) block *= 2;
+  }
   int64_t lane_bytes = 0;
   for (int d = 0; d < D; ++d) lane_bytes += dtype_size(samples[d].dtype);
   if (weighted) lane_bytes += dtype_size(weights->dtype);
