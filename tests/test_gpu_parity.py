@@ -604,3 +604,22 @@ def test_lanes_few_rows_split_columns_and_accumulate(xh):
     np.testing.assert_array_equal(
         xh.histogram(_dev(x), bins=edges, axis=1, block_size=2500)[0].cpu().numpy(), onp.histogram(x, bins=edges, axis=1)[0]
     )
+
+
+def test_host_route_leading_axis_reduction_is_staged_as_it_lies(xh):
+    """numpy (time, y, x) reduced over time: the [rows, cols] view has row stride 1; the library
+    copies the rectangle untransposed and runs the row-per-lane kernel on the transposed view"""
+    rng = np.random.default_rng(61)
+    t = rng.standard_normal((500, 40, 33)).astype(np.float32)
+    edges = np.linspace(-4, 4, 41)
+    v = xh._rows_cols(t, [0], False)
+    assert v.strides == (4, 40 * 33 * 4) and np.shares_memory(v, t)
+    ptr, tag, rs, cs, keep = xh._strided_view(v, "numpy")
+    assert (rs, cs) == (1, 40 * 33) and ptr == t.ctypes.data  # no host copy
+    np.testing.assert_array_equal(xh.histogram(t, bins=edges, axis=0)[0], onp.histogram(t, bins=edges, axis=0)[0])
+    w = rng.uniform(0, 1, t.shape)
+    assert_hist_equal(xh.histogram(t, bins=edges, axis=0, weights=w)[0], onp.histogram(t, bins=edges, axis=0, weights=w)[0], True)
+    sub = t[:, 3:17, 5:]  # non-contiguous in both kept axes: falls back to a host copy, still exact
+    np.testing.assert_array_equal(xh.histogram(sub, bins=edges, axis=0)[0], onp.histogram(sub, bins=edges, axis=0)[0])
+    big = rng.standard_normal((3, 50_000_000 // 3)).astype(np.float32)  # column chunks of the staged route
+    np.testing.assert_array_equal(xh.histogram(big, bins=edges, axis=0)[0][:5], onp.histogram(big[:, :5], bins=edges, axis=0)[0])

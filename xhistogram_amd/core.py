@@ -163,7 +163,7 @@ def _compare_domain(sample_dtypes, edges):
 def _strided_view(a2d, backend):
     """(pointer, dtype tag, row stride, col stride, keepalive) of a 2-D array, in elements.
     Falls back to a contiguous copy only for layouts the C ABI does not take (negative strides;
-    host arrays with a column stride other than 0/1)."""
+    arrays strided in both directions)."""
     if backend == "torch":
         rs, cs = a2d.stride()
         # A large view strided in BOTH directions (e.g. a reduction over a middle axis) would make
@@ -184,6 +184,8 @@ def _strided_view(a2d, backend):
     ok = rs >= 0 and cs in (0, 1) and all(s % item == 0 for s in a2d.strides) and (rs == 0 or rs >= a2d.shape[1] * cs)
     if a2d.shape[1] <= 1 and rs >= 0:
         ok, cs = True, 1
+    if rs == 1 and cs >= a2d.shape[0] and all(s % item == 0 for s in a2d.strides):
+        ok = True  # rows are the contiguous direction (leading-axis reduction): staged as it lies
     if not ok or not a2d.dtype.isnative:
         a2d = np.ascontiguousarray(a2d, dtype=a2d.dtype.newbyteorder("="))
         rs, cs = a2d.shape[1], 1

@@ -1143,8 +1143,35 @@ struct Staged {
 static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0, int64_t nc, Staged& st, xhist_array* view,
                        hipStream_t stream) {
   const int es = dtype_size(a.dtype);
+  if (a.row_stride == 1 && a.col_stride >= 1 && a.col_stride != 1) {
+    // rows are the contiguous direction (a reduction over leading axes of a C-ordered array):
+    // copy the [nc, nr] rectangle as it lies and hand the device the same transposed view — the
+    // row-per-lane kernels take it; no host-side transposition
+    const size_t need = (size_t)nr * nc * es;
+    if (need > st.cap) {
+      if (st.dptr) (void)hipFree(st.dptr);
+      st.dptr = nullptr;
+      st.cap = 0;
+      HIPC(hipMalloc(&st.dptr, need));
+      st.cap = need;
+    }
+    const char* src = static_cast<const char*>(a.data) + (r0 + c0 * a.col_stride) * es;
+    if (a.col_stride == nr) {
+      HIPC(hipMemcpyAsync(st.dptr, src, need, hipMemcpyHostToDevice, stream));
+    } else {
+      HIPC(hipMemcpy2DAsync(st.dptr, (size_t)nr * es, src, (size_t)a.col_stride * es, (size_t)nr * es, (size_t)nc,
+                            hipMemcpyHostToDevice, stream));
+    }
+    view->data = st.dptr;
+    view->dtype = a.dtype;
+    view->reserved = 0;
+    view->row_stride = 1;
+    view->col_stride = nr;
+    return XHIST_OK;
+  }
   if (a.col_stride != 0 && a.col_stride != 1)
-    return fail(XHIST_ERR_UNSUPPORTED, "host arrays need col_stride 0 or 1 (got %lld); pass a contiguous copy", (long long)a.col_stride);
+    return fail(XHIST_ERR_UNSUPPORTED, "host arrays need a unit row or column stride (got %lld, %lld); pass a contiguous copy",
+                (long long)a.row_stride, (long long)a.col_stride);
   const int64_t rows = a.row_stride == 0 ? 1 : nr;
   const int64_t cols = a.col_stride == 0 ? 1 : nc;
   const size_t need = (size_t)rows * cols * es;
