@@ -623,3 +623,57 @@ def test_host_route_leading_axis_reduction_is_staged_as_it_lies(xh):
     np.testing.assert_array_equal(xh.histogram(sub, bins=edges, axis=0)[0], onp.histogram(sub, bins=edges, axis=0)[0])
     big = rng.standard_normal((3, 50_000_000 // 3)).astype(np.float32)  # column chunks of the staged route
     np.testing.assert_array_equal(xh.histogram(big, bins=edges, axis=0)[0][:5], onp.histogram(big[:, :5], bins=edges, axis=0)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# corner cases of the contract
+# ---------------------------------------------------------------------------------------------
+def test_degenerate_edges_and_values(xh):
+    x = np.array([[0.0, 1.0, -1.0, np.nan, np.inf, -np.inf, 5e-324, -5e-324, 1.7976931348623157e308, 0.5]])
+    cases = [
+        np.array([0.0, 0.0]),                      # zero-width single bin: only x == 0 lands (right edge inclusive)
+        np.array([-np.inf, 0.0, np.inf]),          # infinite outer edges
+        np.array([5e-324, 1e-310, 1.0]),           # denormal edges
+        np.array([-1e308, 1e308]),                 # span overflows to inf
+        np.array([0.0, 0.5, 0.5, 0.5, 1.0]),       # repeated interior edge: empty bins
+        np.array([1.0, 1.0, 1.0]),                 # all edges equal
+        np.linspace(-1, 1, 3),
+    ]
+    for e in cases:
+        want = onp.bincount_rows([x], [e])
+        for resident in (False, True):
+            got, _ = _run(xh, [x], [e], None, resident)
+            np.testing.assert_array_equal(got, want, err_msg=str(e))
+        wts = np.arange(1.0, x.size + 1).reshape(1, -1)
+        got, _ = _run(xh, [x], [e], wts, True)
+        assert_hist_equal(got, onp.bincount_rows([x], [e], wts), True)
+
+
+def test_single_edge_means_zero_bins(xh):
+    x = np.random.default_rng(0).standard_normal((3, 10))
+    got, _ = _run(xh, [x], [np.array([0.0])], None, True)
+    assert got.shape == (3, 0)
+    got, _ = _run(xh, [x, x], [np.array([0.0]), np.linspace(-1, 1, 4)], None, False)
+    assert got.shape == (3, 0, 3)
+
+
+def test_all_samples_dropped_and_all_in_last_bin(xh):
+    edges = [np.linspace(0, 1, 11)]
+    nan = np.full((2, 10_000), np.nan)
+    np.testing.assert_array_equal(_run(xh, [nan], edges, None, True)[0], np.zeros((2, 10), dtype=np.int64))
+    ones = np.ones((2, 10_000))
+    want = np.zeros((2, 10), dtype=np.int64)
+    want[:, -1] = 10_000
+    np.testing.assert_array_equal(_run(xh, [ones], edges, None, True)[0], want)
+    # density of an empty row is NaN, like the reference
+    h, _ = xh.histogram(_dev(nan), bins=edges[0], axis=1, density=True)
+    assert np.isnan(h.cpu().numpy()).all()
+
+
+def test_eight_inputs_is_the_limit(xh):
+    rng = np.random.default_rng(9)
+    s = [rng.standard_normal((2, 500)) for _ in range(8)]
+    e = [np.linspace(-3, 3, 3)] * 8
+    np.testing.assert_array_equal(_run(xh, s, e, None, True)[0], onp.bincount_rows(s, e))
+    with pytest.raises(NotImplementedError):
+        _run(xh, s + [s[0]], e + [e[0]], None, True)
