@@ -677,3 +677,15 @@ def test_eight_inputs_is_the_limit(xh):
     np.testing.assert_array_equal(_run(xh, s, e, None, True)[0], onp.bincount_rows(s, e))
     with pytest.raises(NotImplementedError):
         _run(xh, s + [s[0]], e + [e[0]], None, True)
+
+
+def test_float32_denormal_samples_and_edges(xh):
+    """the float32 threshold domain must compare denormals exactly (no flush-to-zero)"""
+    tiny = np.array([1e-45, 3e-45, 1e-41, 1e-39, 1.1754942e-38, 1.17549435e-38, 0.0, -1e-45, -1e-39], dtype=np.float32)
+    x = np.tile(tiny, 50).reshape(2, -1)
+    for e in (np.array([0.0, 1e-44, 1e-40, 1.17549435e-38, 1.0]), np.array([-1e-40, -1e-45, 0.0, 2e-45, 1e-38]),
+              np.array([1e-45, 2e-45, 3e-45, 4e-45])):
+        want = onp.bincount_rows([x], [e])
+        for resident in (False, True):
+            np.testing.assert_array_equal(_run(xh, [x], [e], None, resident)[0], want, err_msg=str(e))
+        np.testing.assert_array_equal(_run(xh, [x], [e], None, True, force_generic=1)[0], want)
