@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 1
+#define XHIST_ABI_VERSION 2
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -57,15 +57,22 @@ typedef enum {
 typedef enum { XHIST_CMP_F64 = 0, XHIST_CMP_I64 = 1 } xhist_cmp_domain;
 typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1 } xhist_mem_kind;
 
-/* A logical [M, C] array addressed as data[r * row_stride + c * col_stride] (strides in ELEMENTS).
+/* A logical [M, C] array addressed as data[row_offset(r) + c * col_stride] (strides in ELEMENTS):
+ *   row_offset(r) = r * row_stride                                                  if inner_rows == 0
+ *                 = (r / inner_rows) * outer_stride + (r % inner_rows) * row_stride  otherwise.
  * row_stride == 0 or col_stride == 0 express numpy broadcasting without materialising it
- * (core.py:366 broadcast_arrays + 211-229 reshape copy it in the reference). */
+ * (core.py:366 broadcast_arrays).  The grouped form expresses an N-D array whose reduced axes
+ * sit BETWEEN kept axes — (time, LAT, lon) histogrammed over lat: rows = (time, lon) pairs,
+ * inner_rows = n_lon, outer_stride = n_lat * n_lon — so that the reference's moveaxis + reshape
+ * copy (core.py:211-229) is never made. */
 typedef struct {
   const void* data;
   int32_t dtype; /* xhist_dtype */
   int32_t reserved;
   int64_t row_stride;
   int64_t col_stride;
+  int64_t inner_rows;   /* rows per group; 0 = ungrouped */
+  int64_t outer_stride; /* stride between groups of rows */
 } xhist_array;
 
 typedef struct xhist_plan xhist_plan; /* opaque: device-resident edge tables + launch geometry */

@@ -38,7 +38,8 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), "libxhist_amd.so does not export %s" % n
     assert set(_native.EXPORTS) == set(names), "ctypes shim and header disagree"
-    assert lib.xhist_abi_version() == 1
+    abi = int(re.search(r"#define XHIST_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.xhist_abi_version() == abi == _native.ABI_VERSION
 
 
 def test_dtype_tags_match_header():

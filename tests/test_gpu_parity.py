@@ -614,7 +614,7 @@ def test_host_route_leading_axis_reduction_is_staged_as_it_lies(xh):
     edges = np.linspace(-4, 4, 41)
     v = xh._rows_cols(t, [0], False)
     assert v.strides == (4, 40 * 33 * 4) and np.shares_memory(v, t)
-    ptr, tag, rs, cs, keep = xh._strided_view(v, "numpy")
+    ptr, tag, rs, cs, _ir, _os, keep = xh._strided_view(v, "numpy")
     assert (rs, cs) == (1, 40 * 33) and ptr == t.ctypes.data  # no host copy
     np.testing.assert_array_equal(xh.histogram(t, bins=edges, axis=0)[0], onp.histogram(t, bins=edges, axis=0)[0])
     w = rng.uniform(0, 1, t.shape)
@@ -689,3 +689,54 @@ def test_float32_denormal_samples_and_edges(xh):
         for resident in (False, True):
             np.testing.assert_array_equal(_run(xh, [x], [e], None, resident)[0], want, err_msg=str(e))
         np.testing.assert_array_equal(_run(xh, [x], [e], None, True, force_generic=1)[0], want)
+
+
+# ---------------------------------------------------------------------------------------------
+# grouped-row views: reduced axes between kept axes (ABI v2), no moveaxis+reshape copy
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.int32])
+def test_middle_axis_reductions_run_uncopied(xh, dt, resident):
+    rng = np.random.default_rng(71)
+    t = (rng.standard_normal((23, 31, 300)) * 2).astype(dt)  # inner dim 300 >= a wave: lanes coalesce
+    edges = np.linspace(-4, 4, 33)
+    w = rng.uniform(0, 1, t.shape)
+    for axis in ([1], [0], [2], [0, 1], [1, 2]):
+        want, _ = onp.histogram(t, bins=edges, axis=axis)
+        got, _ = xh.histogram(_maybe(t, resident), bins=edges, axis=axis)
+        np.testing.assert_array_equal(_tonp(got), want, err_msg=str(axis))
+        want, _ = onp.histogram(t, bins=edges, axis=axis, weights=w)
+        got, _ = xh.histogram(_maybe(t, resident), bins=edges, axis=axis, weights=_maybe(w, resident))
+        assert_hist_equal(_tonp(got), want, True)
+    if dt != np.int32 and resident:
+        desc = _plan_for(xh, [_dev(t[0])], [edges]).describe()
+        assert "family=" in desc
+
+
+def _maybe(a, resident):
+    return _dev(a) if resident else a
+
+
+def _tonp(a):
+    return a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+
+
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_grouped_rows_4d_two_inputs_broadcast_weights(xh, resident):
+    rng = np.random.default_rng(72)
+    a = rng.standard_normal((5, 7, 11, 70))
+    b = rng.standard_normal((5, 7, 11, 70))
+    ea, eb = np.linspace(-3, 3, 7), _nonuniform_edges(rng, 6)
+    for axis, wshape in (([1, 2], (5, 1, 1, 70)), ([2], (1, 7, 11, 1)), ([1], (5, 7, 11, 70)), ([0, 1, 2], (1, 1, 1, 70))):
+        w = rng.uniform(0, 1, wshape)
+        want, _ = onp.histogram(a, b, bins=[ea, eb], axis=axis, weights=w)
+        got, _ = xh.histogram(_maybe(a, resident), _maybe(b, resident), bins=[ea, eb], axis=axis, weights=_maybe(w, resident))
+        assert_hist_equal(_tonp(got), want, True)
+    # sliced (non-contiguous) inputs: still described by strides
+    sl = a[:, ::2, :, 3:]
+    want, _ = onp.histogram(sl, bins=ea, axis=[1])
+    np.testing.assert_array_equal(_tonp(xh.histogram(_maybe(a, resident)[:, ::2, :, 3:], bins=ea, axis=[1])[0]), want)
+    # second input in a different memory order than the first: pairing of samples must survive
+    bf = np.asfortranarray(b)
+    want, _ = onp.histogram(a, bf, bins=[ea, eb], axis=[1, 2])
+    np.testing.assert_array_equal(_tonp(xh.histogram(a, bf, bins=[ea, eb], axis=[1, 2])[0]), want)

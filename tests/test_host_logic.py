@@ -52,12 +52,12 @@ def test_rows_cols_matches_reference_layout_without_copies():
     w = np.broadcast_to(np.arange(6.0), (3, 4, 5, 6))  # stride-0 weights stay stride-0
     v = core._rows_cols(w, [3], False)
     assert v.shape == (60, 6) and v.strides == (0, 8)
-    ptr, tag, rs, cs, keep = core._strided_view(v, "numpy")
+    ptr, tag, rs, cs, _ir, _os, keep = core._strided_view(v, "numpy")
     assert (tag, rs, cs) == (_native.F64, 0, 1) and ptr == w.ctypes.data
     col = np.broadcast_to(np.arange(5.0)[:, None], (5, 7))  # column broadcast: cs == 0
     assert core._strided_view(col, "numpy")[2:4] == (1, 0)
     neg = x[0, 0][:, ::-1]  # negative stride: one contiguous copy
-    ptr, tag, rs, cs, keep = core._strided_view(neg, "numpy")
+    ptr, tag, rs, cs, _ir, _os, keep = core._strided_view(neg, "numpy")
     assert (rs, cs) == (6, 1) and not np.shares_memory(keep, x)
     np.testing.assert_array_equal(keep, neg)
 
@@ -110,3 +110,36 @@ def test_default_device_env(monkeypatch):
     assert core.default_device() == 3
     monkeypatch.setenv("XHIST_AMD_DEVICE", "5")
     assert core.default_device() == 5
+
+
+def test_collapse_describes_the_reference_layout_by_strides():
+    """_collapse must address exactly the elements of the reference's moveaxis+reshape block
+    (core.py:211-227), row by row; the order inside a row is free (histograms do not care)"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 4, 5, 6))
+    raw = x.reshape(-1)
+    for axis in ([0], [1], [2], [3], [1, 2], [0, 1], [2, 3], [0, 1, 2], [0, 1, 2, 3]):
+        full = len(axis) == 4
+        d = core._collapse(x, axis, full, core._reduced_order(x, axis))
+        assert d is not None, axis
+        m, c, rs, cs, ir, os_ = d
+        r = np.arange(m)
+        off = (r // ir) * os_ + (r % ir) * rs if ir else r * rs
+        got = raw[off[:, None] + np.arange(c)[None, :] * cs]
+        want = onp.to_rows_cols(x, None if full else axis)
+        np.testing.assert_array_equal(np.sort(got, axis=1), np.sort(want, axis=1))
+    assert core._collapse(x, [1], False, [1])[4:] == (30, 120)  # middle axis: grouped rows, no copy
+    for axis in ([0, 3], [1, 3], [0, 2]):  # reduced axes not adjacent in memory: the copying route
+        assert core._collapse(x, axis, False, core._reduced_order(x, axis)) is None
+    w = np.broadcast_to(rng.standard_normal((1, 1, 5, 1)), x.shape)  # broadcast weights stay stride-0
+    assert core._collapse(w, [2], False, [2]) == (72, 5, 0, 1, 0, 0)
+    assert core._collapse(w, [3], False, [3]) == (60, 6, 1, 0, 5, 0)
+    f = np.asfortranarray(x)  # the reduced order follows the FIRST array's memory order
+    assert core._reduced_order(f, [1, 2]) == [2, 1]
+    assert core._collapse(x[:, ::-1], [3], False, [3]) is None  # negative stride
+    v = core._view_of(x, core._collapse(x, [1], False, [1]), "numpy")
+    assert v[0] == x.ctypes.data and v[2:6] == (1, 30, 30, 120)
+    # a 2-stride host view the staging copy cannot take row-by-row is passed as one group
+    y = x[:, :, :, ::2]
+    d = core._collapse(y, [3], False, [3])
+    assert d == (60, 3, 6, 2, 0, 0) and core._view_of(y, d, "numpy")[4:6] == (60, 0)

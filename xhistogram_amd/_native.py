@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -53,6 +53,8 @@ class XhistArray(C.Structure):
         ("reserved", C.c_int32),
         ("row_stride", C.c_int64),
         ("col_stride", C.c_int64),
+        ("inner_rows", C.c_int64),
+        ("outer_stride", C.c_int64),
     ]
 
 
@@ -146,8 +148,10 @@ def require_device(device=0):
         )
 
 
-def make_view(ptr, tag, row_stride, col_stride):
-    return XhistArray(C.c_void_p(ptr), tag, 0, int(row_stride), int(col_stride))
+def make_view(ptr, tag, row_stride, col_stride, inner_rows=0, outer_stride=0):
+    """xhist_array: element (r, c) at ptr[row_offset(r) + c * col_stride], strides in elements;
+    inner_rows > 0 groups the rows (see include/xhist_amd.h)"""
+    return XhistArray(C.c_void_p(ptr), tag, 0, int(row_stride), int(col_stride), int(inner_rows), int(outer_stride))
 
 
 class Plan:

@@ -161,7 +161,7 @@ def _compare_domain(sample_dtypes, edges):
 # L1: the hot path                                                     (core.py:137-194)
 # ---------------------------------------------------------------------------------------------
 def _strided_view(a2d, backend):
-    """(pointer, dtype tag, row stride, col stride, keepalive) of a 2-D array, in elements.
+    """(pointer, dtype tag, row stride, col stride, 0, 0, keepalive) of a 2-D array, in elements.
     Falls back to a contiguous copy only for layouts the C ABI does not take (negative strides;
     arrays strided in both directions)."""
     if backend == "torch":
@@ -176,7 +176,7 @@ def _strided_view(a2d, backend):
             rs, cs = a2d.stride()
         if a2d.shape[0] <= 1:
             rs = 0 if a2d.shape[0] == 0 else rs
-        return a2d.data_ptr(), _torch_tag(a2d.dtype), rs, cs, a2d
+        return a2d.data_ptr(), _torch_tag(a2d.dtype), rs, cs, 0, 0, a2d
     if a2d.dtype.kind in "mM":
         a2d = a2d.view(np.int64)
     item = a2d.dtype.itemsize
@@ -189,7 +189,68 @@ def _strided_view(a2d, backend):
     if not ok or not a2d.dtype.isnative:
         a2d = np.ascontiguousarray(a2d, dtype=a2d.dtype.newbyteorder("="))
         rs, cs = a2d.shape[1], 1
-    return a2d.ctypes.data, _native.dtype_tag(a2d.dtype), rs, cs, a2d
+    return a2d.ctypes.data, _native.dtype_tag(a2d.dtype), rs, cs, 0, 0, a2d
+
+
+def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, like, block_size):
+    """Hand [rows, cols] views (ptr, tag, row stride, col stride, rows per group, group stride,
+    keepalive) to the native library and return the [rows, nb_0, ...] histogram."""
+    cmp_domain, edges, _ = _compare_domain(sample_dtypes, bins)
+    weighted = wview is not None
+    if backend == "numpy":
+        device = default_device()
+        stream = 0
+        mem = _native.MEM_HOST
+    else:
+        torch = _torch()
+        if like.device.type != "cuda":
+            raise RuntimeError("torch inputs must live on an MI355X (device='cuda'); got %s" % like.device)
+        device = like.device.index if like.device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        mem = _native.MEM_DEVICE
+    _native.require_device(device)
+    plan = _get_plan(edges, cmp_domain, device)
+
+    out_shape = (nrows,) + plan.bins_shape
+    if backend == "numpy":
+        out = np.zeros(out_shape, dtype=np.float64 if weighted else np.int64)
+        out_ptr = out.ctypes.data
+        empty = out.size == 0
+    else:
+        out = torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=like.device)
+        out_ptr = out.data_ptr()
+        empty = out.numel() == 0
+    if empty:
+        return out
+
+    grouped = any(v[4] for v in views) or (weighted and wview[4])
+    if block_size in (None, "auto") or grouped:
+        row_blocks = [(0, nrows)]
+    else:
+        if not isinstance(block_size, (int, np.integer)) or isinstance(block_size, bool):
+            raise AssertionError("block_size must be None, 'auto' or an int")  # core.py:116
+        if block_size <= 0:
+            raise ZeroDivisionError("block_size must be positive")  # core.py:117 raises the same
+        row_blocks = [(r, min(r + int(block_size), nrows)) for r in _range(0, nrows, int(block_size))]
+
+    def shifted(view, r0):
+        ptr, tag, rs, cs, ir, os_, _keep = view
+        return _native.make_view(ptr + r0 * rs * np.dtype(_TAG_NP[tag]).itemsize, tag, rs, cs, ir, os_)
+
+    row_bytes = plan.n_bins * 8
+    for r0, r1 in row_blocks:
+        plan.execute(
+            [shifted(v, r0) for v in views],
+            shifted(wview, r0) if weighted else None,
+            r1 - r0,
+            ncols,
+            out_ptr + r0 * row_bytes,
+            weighted,
+            mem,
+            accumulate=False,
+            stream=stream,
+        )
+    return out
 
 
 def _bincount_2d_vectorized(*args, bins=None, weights=None, density=False, right=False, block_size=None):
@@ -214,68 +275,25 @@ def _bincount_2d_vectorized(*args, bins=None, weights=None, density=False, right
     if len(bins) != len(args):
         raise ValueError("one array of bin edges per input array")
     nrows, ncols = (int(s) for s in a0.shape)
+    dtypes = [_np_dtype_of(a) for a in args]
+    args, weights = _prepare_dtypes(list(args), weights, dtypes, bins, backend)
+    views = [_strided_view(a, backend) for a in args]
+    wview = _strided_view(weights, backend) if weights is not None else None
+    return _execute_views(views, wview, nrows, ncols, dtypes, bins, backend, a0, block_size)
 
-    cmp_domain, edges, dt_common = _compare_domain([_np_dtype_of(a) for a in args], bins)
+
+def _prepare_dtypes(args, weights, dtypes, bins, backend):
+    """dtype-level preparation shared by every entry: datetime64 inputs are brought to the unit
+    they share with their edges (and later viewed as int64), complex weights are rejected like
+    numpy's bincount does"""
     if backend == "numpy":
-        args = [a.astype(c) if c is not None and a.dtype != c else a for a, c in zip(args, dt_common)]
+        _, _, common = _compare_domain(dtypes, bins)
+        args = [a.astype(c) if c is not None and a.dtype != c else a for a, c in zip(args, common)]
         if weights is not None and weights.dtype.kind == "c":
             raise TypeError("Cannot cast array data from complex to float64 (weights)")  # numpy bincount
-        device = default_device()
-        stream = 0
-        mem = _native.MEM_HOST
-    else:
-        torch = _torch()
-        if a0.device.type != "cuda":
-            raise RuntimeError("torch inputs must live on an MI355X (device='cuda'); got %s" % a0.device)
-        device = a0.device.index if a0.device.index is not None else torch.cuda.current_device()
-        stream = torch.cuda.current_stream(device).cuda_stream
-        mem = _native.MEM_DEVICE
-        if weights is not None and weights.dtype.is_complex:
-            raise TypeError("complex weights are not supported")
-    _native.require_device(device)
-    plan = _get_plan(edges, cmp_domain, device)
-
-    weighted = weights is not None
-    out_shape = (nrows,) + plan.bins_shape
-    if backend == "numpy":
-        out = np.zeros(out_shape, dtype=np.float64 if weighted else np.int64)
-        out_ptr = out.ctypes.data
-    else:
-        out = torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=a0.device)
-        out_ptr = out.data_ptr()
-    if out.size == 0 if backend == "numpy" else out.numel() == 0:
-        return out
-
-    views = [_strided_view(a, backend) for a in args]
-    wview = _strided_view(weights, backend) if weighted else None
-
-    if block_size in (None, "auto"):
-        row_blocks = [(0, nrows)]
-    else:
-        if not isinstance(block_size, (int, np.integer)) or isinstance(block_size, bool):
-            raise AssertionError("block_size must be None, 'auto' or an int")  # core.py:116
-        if block_size <= 0:
-            raise ZeroDivisionError("block_size must be positive")  # core.py:117 raises the same
-        row_blocks = [(r, min(r + int(block_size), nrows)) for r in _range(0, nrows, int(block_size))]
-
-    def shifted(view, r0):
-        ptr, tag, rs, cs, _ = view
-        return _native.make_view(ptr + r0 * rs * np.dtype(_TAG_NP[tag]).itemsize, tag, rs, cs)
-
-    row_bytes = plan.n_bins * 8
-    for r0, r1 in row_blocks:
-        plan.execute(
-            [shifted(v, r0) for v in views],
-            shifted(wview, r0) if weighted else None,
-            r1 - r0,
-            ncols,
-            out_ptr + r0 * row_bytes,
-            weighted,
-            mem,
-            accumulate=False,
-            stream=stream,
-        )
-    return out
+    elif weights is not None and weights.dtype.is_complex:
+        raise TypeError("complex weights are not supported")
+    return args, weights
 
 
 # ---------------------------------------------------------------------------------------------
@@ -308,22 +326,127 @@ def _rows_cols(a, axis, do_full_array):
         return moved.reshape(m, c)
 
 
+def _elem_strides(a):
+    """(shape, strides in elements) of a numpy array or torch tensor; None if not element-aligned"""
+    if _is_torch(a):
+        return tuple(int(s) for s in a.shape), tuple(int(s) for s in a.stride())
+    item = a.dtype.itemsize
+    if any(st % item for st in a.strides):
+        return None
+    return tuple(a.shape), tuple(st // item for st in a.strides)
+
+
+def _merge_dims(dims):
+    """merge consecutive (size, stride) dims that walk memory like one dim; size-1 dims vanish"""
+    out = []
+    for size, stride in dims:
+        if size == 1:
+            continue
+        if out and (out[-1][1] == stride * size or (out[-1][1] == 0 and stride == 0)):
+            out[-1] = (out[-1][0] * size, stride)
+        else:
+            out.append((size, stride))
+    return out
+
+
+def _collapse(a, axis, do_full_array, reduced_order):
+    """Describe the [kept, reduced] arrangement of an N-D block (core.py:211-227) by strides
+    instead of making it: (rows, cols, row stride, col stride, rows per group, group stride) or None.
+
+    The reduced axes must walk memory as ONE strided dimension (their order inside a row does not
+    matter to a histogram, so ``reduced_order`` — chosen once for all inputs — may permute them);
+    the kept axes as one or two (kept axes on both sides of the reduced ones: grouped rows)."""
+    ss = _elem_strides(a)
+    if ss is None:
+        return None
+    shape, strides = ss
+    if any(st < 0 for st in strides):
+        return None
+    ndim = len(shape)
+    red = list(_range(ndim)) if do_full_array else list(reduced_order)
+    kept = [] if do_full_array else [i for i in _range(ndim) if i not in red]
+    cols = _merge_dims([(shape[i], strides[i]) for i in red])
+    rows = _merge_dims([(shape[i], strides[i]) for i in kept])
+    if len(cols) > 1 or len(rows) > 2:
+        return None
+    m = 1
+    for i in kept:
+        m *= shape[i]
+    c = 1
+    for i in red:
+        c *= shape[i]
+    cs = cols[0][1] if cols else 0
+    if len(rows) == 2:
+        (_, os_), (inner, rs) = rows
+        return m, c, rs, cs, inner, os_
+    rs = rows[0][1] if rows else 0
+    return m, c, rs, cs, 0, 0
+
+
+def _reduced_order(a, axis):
+    """order of the reduced axes that walks ``a`` with decreasing strides (C-like)"""
+    ss = _elem_strides(a)
+    if ss is None:
+        return list(axis)
+    return sorted(axis, key=lambda i: -ss[1][i])
+
+
+def _view_of(a, desc, backend, both_strided_limit=1 << 16):
+    """native view tuple of an array described by _collapse, or None when a copy is the better plan"""
+    m, c, rs, cs, ir, os_ = desc
+    if backend == "torch":
+        if rs > 1 and cs > 1 and m * c >= both_strided_limit:
+            return None  # strided both ways: every lane would touch its own cache line
+        return a.data_ptr(), _torch_tag(a.dtype), rs, cs, ir, os_, a
+    if not a.dtype.isnative:
+        return None
+    if a.dtype.kind in "mM":
+        a = a.view(np.int64)
+    if ir == 0 and not (cs in (0, 1) or rs in (0, 1)):
+        ir, os_ = m, 0  # one group: makes the library stage the bytes as they lie, strides intact
+    return a.ctypes.data, _native.dtype_tag(a.dtype), rs, cs, ir, os_, a
+
+
 def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
     """Block adapter with the reference's contract (core.py:197-247): N-D block(s) in, array of
     shape kept-axes (1 for each reduced axis) + bin dims out.  Called directly for numpy/torch
-    inputs and once per block by the dask branch (core.py:429-437)."""
+    inputs and once per block by the dask branch (core.py:429-437).
+
+    Where the reference moves the reduced axes last and reshapes (a copy for anything but
+    trailing axes), the block is DESCRIBED to the native library as a strided [rows, cols] view —
+    broadcast inputs, leading-axis and middle-axis reductions included — and only layouts no
+    three strides can express fall back to that copy."""
     a0 = all_arrays[0]
     ndim = a0.ndim
+    backend = "torch" if _is_torch(a0) else "numpy"
     do_full_array = (axis is None) or (set(axis) == set(_range(ndim)))
     if do_full_array:
         kept_axes_shape = (1,) * ndim
     else:
         kept_axes_shape = tuple(int(a0.shape[i]) if i not in axis else 1 for i in _range(ndim))
 
-    blocks = [_rows_cols(a, axis, do_full_array) for a in all_arrays]
-    weights_block = blocks.pop() if weights else None
+    arrays = list(all_arrays)
+    w_array = arrays.pop() if weights else None
+    n_inputs = len(arrays)
+    dtypes = [_np_dtype_of(a) for a in arrays]
+    arrays, w_array = _prepare_dtypes(arrays, w_array, dtypes, bins, backend)
 
-    counts = _bincount_2d_vectorized(*blocks, bins=bins, weights=weights_block, density=density, block_size=block_size)
+    counts = None
+    order = _reduced_order(arrays[0], list(_range(ndim)) if do_full_array else axis)
+    descs = [_collapse(a, axis, do_full_array, order) for a in arrays + ([w_array] if weights else [])]
+    if all(d is not None for d in descs) and len({d[:2] for d in descs}) == 1:
+        views = [_view_of(a, d, backend) for a, d in zip(arrays + ([w_array] if weights else []), descs)]
+        if all(v is not None for v in views):
+            m, c = descs[0][:2]
+            try:
+                counts = _execute_views(views[:n_inputs], views[n_inputs] if weights else None, int(m), int(c), dtypes, bins,
+                                        backend, a0, block_size)
+            except NotImplementedError:
+                counts = None  # e.g. a host view spanning > 2^32 elements: take the copying route
+    if counts is None:
+        blocks = [_rows_cols(a, axis, do_full_array) for a in arrays + ([w_array] if weights else [])]
+        weights_block = blocks.pop() if weights else None
+        counts = _bincount_2d_vectorized(*blocks, bins=bins, weights=weights_block, density=density, block_size=block_size)
     return counts.reshape(kept_axes_shape + tuple(counts.shape[1:]))
 
 
@@ -372,7 +495,7 @@ def _device_bin_edges(a, b, r, has_weights):
         if a.numel() == 0:
             return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=None)
         flat = a.reshape(1, -1)
-        ptr, tag, rs, cs, keep = _strided_view(flat, "torch")
+        ptr, tag, rs, cs, _ir, _os, keep = _strided_view(flat, "torch")
         torch = _torch()
         dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
         lo, hi = _native.minmax(

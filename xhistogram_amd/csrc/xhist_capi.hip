@@ -582,7 +582,7 @@ static int validate_arrays(const xhist_plan* p, const xhist_array* samples, cons
   for (int d = 0; d < p->n_dims; ++d) {
     if (!empty && !samples[d].data) return fail(XHIST_ERR_INVALID, "samples[%d].data is NULL", d);
     if (!dtype_size(samples[d].dtype)) return fail(XHIST_ERR_INVALID, "samples[%d] has unknown dtype tag %d", d, samples[d].dtype);
-    if (samples[d].row_stride < 0 || samples[d].col_stride < 0)
+    if (samples[d].row_stride < 0 || samples[d].col_stride < 0 || samples[d].inner_rows < 0 || samples[d].outer_stride < 0)
       return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
     if (p->cmp == XHIST_CMP_I64 && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
       return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", samples[d].dtype);
@@ -590,7 +590,7 @@ static int validate_arrays(const xhist_plan* p, const xhist_array* samples, cons
   if (weights) {
     if (!empty && !weights->data) return fail(XHIST_ERR_INVALID, "weights.data is NULL");
     if (!dtype_size(weights->dtype)) return fail(XHIST_ERR_INVALID, "weights has unknown dtype tag %d", weights->dtype);
-    if (weights->row_stride < 0 || weights->col_stride < 0)
+    if (weights->row_stride < 0 || weights->col_stride < 0 || weights->inner_rows < 0 || weights->outer_stride < 0)
       return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
     if (out_dtype != XHIST_F64) return fail(XHIST_ERR_INVALID, "weighted histograms are float64 (out_dtype XHIST_F64)");
   } else if (out_dtype != XHIST_I64) {
@@ -737,14 +737,15 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   if ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)) return XHIST_ERR_UNSUPPORTED;
   // shape class of every array: natural (row stride 0/1, any column stride) or needs a transpose
   // (unit column stride, dense-ish rows)
-  bool all_natural = true, all_rowmajor = true;
+  bool all_natural = true, all_rowmajor = true, grouped_any = false;
   for (int d = 0; d <= D; ++d) {
     if (d == D && !weighted) break;
     const xhist_array& a = d < D ? samples[d] : *weights;
     if (d < D && a.dtype != sdt) return XHIST_ERR_UNSUPPORTED;
     const bool bcast = a.row_stride == 0 || a.col_stride == 0;
-    const bool natural = bcast || (a.row_stride == 1 && a.col_stride >= n_rows);
+    const bool natural = bcast || (a.row_stride == 1 && (a.inner_rows ? a.col_stride >= 1 : a.col_stride >= n_rows));
     const bool rowmajor = bcast || (a.col_stride == 1 && a.row_stride >= n_cols);
+    grouped_any |= a.inner_rows != 0 && !bcast;
     all_natural &= natural;
     all_rowmajor &= rowmajor;
   }
@@ -770,6 +771,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes, &vec);
   if (!fn) return XHIST_ERR_UNSUPPORTED;
 
+  const bool fused_ok = D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0;
+  if (transpose && grouped_any && !fused_ok) return XHIST_ERR_UNSUPPORTED;  // transpose_2d takes plain row strides only
   // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
   if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {
     const int es = dtype_size(sdt);
@@ -782,6 +785,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       kp.s_ptr[0] = samples[0].data;
       kp.s_rs[0] = samples[0].row_stride;
       kp.s_cs[0] = 1;
+      kp.s_ir[0] = samples[0].inner_rows;
+      kp.s_os[0] = samples[0].outer_stride;
       kp.s_dt[0] = sdt;
       kp.dim[0] = tset.dim[0];
       kp.n_dims = 1;
@@ -843,8 +848,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     if (d == D && !weighted) break;
     const xhist_array& a = d < D ? samples[d] : *weights;
     const void* ptr = a.data;
-    int64_t rs = a.row_stride, cs = a.col_stride;
+    int64_t rs = a.row_stride, cs = a.col_stride, ir = a.inner_rows, os = a.outer_stride;
     if (transpose && rs != 0 && cs != 0) {
+      ir = os = 0;
       const int es = dtype_size(a.dtype);
       HIPL(hipMallocAsync(&scratch[d], (size_t)n_rows * n_cols * es, stream));
       const dim3 grid((unsigned)((n_rows + 63) / 64), (unsigned)((n_cols + 63) / 64));
@@ -861,12 +867,16 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       kp.s_ptr[d] = ptr;
       kp.s_rs[d] = rs;
       kp.s_cs[d] = cs;
+      kp.s_ir[d] = ir;
+      kp.s_os[d] = os;
       kp.s_dt[d] = a.dtype;
       kp.dim[d] = dims[d];
     } else {
       kp.w_ptr = ptr;
       kp.w_rs = rs;
       kp.w_cs = cs;
+      kp.w_ir = ir;
+      kp.w_os = os;
       kp.w_dt = a.dtype;
     }
   }
@@ -1078,18 +1088,23 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       memset(&kp, 0, sizeof kp);
       for (int d = 0; d < D; ++d) {
         const xhist_array& a = samples[d];
-        kp.s_ptr[d] = advance(a.data, a.dtype, r0 * a.row_stride + c0 * a.col_stride);
+        kp.s_ptr[d] = advance(a.data, a.dtype, c0 * a.col_stride);
         kp.s_rs[d] = a.row_stride;
         kp.s_cs[d] = a.col_stride;
+        kp.s_ir[d] = a.inner_rows;
+        kp.s_os[d] = a.outer_stride;
         kp.s_dt[d] = a.dtype;
         kp.dim[d] = dims[d];
       }
       if (weighted) {
-        kp.w_ptr = advance(weights->data, weights->dtype, r0 * weights->row_stride + c0 * weights->col_stride);
+        kp.w_ptr = advance(weights->data, weights->dtype, c0 * weights->col_stride);
         kp.w_rs = weights->row_stride;
         kp.w_cs = weights->col_stride;
+        kp.w_ir = weights->inner_rows;
+        kp.w_os = weights->outer_stride;
         kp.w_dt = weights->dtype;
       }
+      kp.row0 = r0;
       kp.n_dims = D;
       kp.tables = tset->blob;
       kp.table_words = tset->words;
@@ -1167,6 +1182,8 @@ static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0,
     view->reserved = 0;
     view->row_stride = 1;
     view->col_stride = nr;
+    view->inner_rows = 0;
+    view->outer_stride = 0;
     return XHIST_OK;
   }
   if (a.col_stride != 0 && a.col_stride != 1)
@@ -1194,6 +1211,8 @@ static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0,
   view->reserved = 0;
   view->row_stride = a.row_stride == 0 ? 0 : cols;
   view->col_stride = a.col_stride == 0 ? 0 : 1;
+  view->inner_rows = 0;
+  view->outer_stride = 0;
   return XHIST_OK;
 }
 
@@ -1218,11 +1237,41 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
   if (hipMalloc(&d_out, (size_t)out_elems * 8) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
   if (hipMemsetAsync(d_out, 0, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_HIP, "hipMemsetAsync failed"));
 
+  // views with grouped rows (reduced axes between kept axes) are staged whole, strides intact:
+  // the bytes between the first and the last element are copied as they lie
+  bool grouped = false;
+  for (int d = 0; d < D; ++d) grouped |= samples[d].inner_rows != 0;
+  if (weights) grouped |= weights->inner_rows != 0;
+  if (grouped) {
+    xhist_array views[kMaxDims];
+    xhist_array wview;
+    for (int d = 0; d <= D && rc == XHIST_OK; ++d) {
+      if (d == D && !weights) break;
+      const xhist_array& a = d < D ? samples[d] : *weights;
+      const int es = dtype_size(a.dtype);
+      const int64_t last_row = n_rows - 1;
+      const int64_t roff = a.inner_rows ? (last_row / a.inner_rows) * a.outer_stride + (last_row % a.inner_rows) * a.row_stride
+                                        : last_row * a.row_stride;
+      const int64_t extent = roff + (n_cols - 1) * a.col_stride + 1;
+      if (extent > ((int64_t)1 << 32)) { rc = fail(XHIST_ERR_UNSUPPORTED, "grouped host view spans more than 2^32 elements"); break; }
+      Staged& s = st[d < D ? d : kMaxDims];
+      if (hipMalloc(&s.dptr, (size_t)extent * es) != hipSuccess) { rc = fail(XHIST_ERR_NOMEM, "hipMalloc of a staging buffer failed"); break; }
+      s.cap = (size_t)extent * es;
+      if (hipMemcpyAsync(s.dptr, a.data, (size_t)extent * es, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        rc = fail(XHIST_ERR_HIP, "host to device copy failed");
+        break;
+      }
+      xhist_array v = a;
+      v.data = s.dptr;
+      if (d < D) views[d] = v; else wview = v;
+    }
+    if (rc == XHIST_OK) rc = execute_device(p, views, weights ? &wview : nullptr, n_rows, n_cols, d_out, 1, stream);
+  }
   // chunks of <= 2^27 elements per array: whole rows when a row fits, else column spans of one row
   const int64_t kChunk = (int64_t)1 << 27;
   const int64_t rows_per = n_cols <= kChunk ? std::max<int64_t>(1, kChunk / n_cols) : 1;
   const int64_t cols_per = n_cols <= kChunk ? n_cols : kChunk;
-  for (int64_t r0 = 0; r0 < n_rows && rc == XHIST_OK; r0 += rows_per) {
+  for (int64_t r0 = 0; !grouped && r0 < n_rows && rc == XHIST_OK; r0 += rows_per) {
     const int64_t nr = std::min(rows_per, n_rows - r0);
     for (int64_t c0 = 0; c0 < n_cols && rc == XHIST_OK; c0 += cols_per) {
       const int64_t nc = std::min(cols_per, n_cols - c0);
@@ -1343,7 +1392,8 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
     return code;
   };
   if (hipMalloc(&d_part, sizeof(double) * 3 * grid) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc failed"));
-  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, n_rows, n_cols, d_part);
+  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, view.inner_rows,
+                     view.outer_stride, n_rows, n_cols, d_part);
   std::vector<double> part(3 * grid);
   if (hipGetLastError() != hipSuccess ||
       hipMemcpyAsync(part.data(), d_part, sizeof(double) * 3 * grid, hipMemcpyDeviceToHost, s) != hipSuccess ||

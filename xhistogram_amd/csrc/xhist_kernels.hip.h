@@ -51,13 +51,20 @@ struct DimTable {
 };
 
 struct Params {
+  // sample d, logical element (r, c) lives at s_ptr[d][row_offset(r) + c * s_cs[d]] (elements):
+  //   row_offset(r) = r * s_rs[d]                                       when s_ir[d] == 0
+  //                 = (r / s_ir[d]) * s_os[d] + (r % s_ir[d]) * s_rs[d]  otherwise (rows in groups of
+  //                   s_ir: kept axes on both sides of the reduced ones, e.g. (time, LAT, lon) over lat)
   const void* s_ptr[kMaxDims];
   int64_t s_rs[kMaxDims];  // row stride, elements
   int64_t s_cs[kMaxDims];  // col stride, elements
+  int64_t s_ir[kMaxDims];  // rows per group (0 = ungrouped)
+  int64_t s_os[kMaxDims];  // stride between groups, elements
   int32_t s_dt[kMaxDims];
   const void* w_ptr;       // nullptr = unweighted
-  int64_t w_rs, w_cs;
+  int64_t w_rs, w_cs, w_ir, w_os;
   int32_t w_dt;
+  int64_t row0;            // first logical row of this launch (inputs only; `out` is pre-advanced)
   int32_t n_dims;
   DimTable dim[kMaxDims];
   const uint64_t* tables;  // device blob: edges of every dimension, then bucket tables
@@ -76,6 +83,12 @@ struct Params {
   int32_t part_shift;           // bins per partition = 1 << part_shift
   int32_t n_parts;
 };
+
+__device__ __forceinline__ int64_t row_offset(int64_t r, int64_t rs, int64_t ir, int64_t os) {
+  if (ir == 0) return r * rs;
+  const int64_t g = r / ir;
+  return g * os + (r - g * ir) * rs;
+}
 
 // ---------------------------------------------------------------------------------------------
 // compare domains
@@ -325,9 +338,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 
   const ST* sp[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + row * p.s_rs[d];
+  for (int d = 0; d < D; ++d)
+    sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + row_offset(p.row0 + row, p.s_rs[d], p.s_ir[d], p.s_os[d]);
   const wscalar* wp = nullptr;
-  if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row * p.w_rs;
+  if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os);
   out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
 
   auto scatter = [&](bool ok, uint32_t flat, double w) {
@@ -525,18 +539,25 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
 
   out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
   const int nd = p.n_dims;
+  int64_t roff[kMaxDims];
+#pragma unroll
+  for (int d = 0; d < kMaxDims; ++d) roff[d] = d < nd ? row_offset(p.row0 + row, p.s_rs[d], p.s_ir[d], p.s_os[d]) : 0;
+  const int64_t woff = WEIGHTED ? row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os) : 0;
 
   for (int64_t i = (int64_t)seg * blockDim.x + tid; i < p.n_cols; i += (int64_t)p.segs * blockDim.x) {
     bool ok = true;
     int64_t flat = 0;
-    for (int d = 0; d < nd; ++d) {
-      const CT x = load_as<CT>(p.s_ptr[d], p.s_dt[d], row * p.s_rs[d] + i * p.s_cs[d]);
-      const int b = digitize<CMP>(x, p.dim[d], tab);
-      ok &= (b >= 0);
-      flat += (int64_t)b * p.dim[d].out_stride;
+#pragma unroll
+    for (int d = 0; d < kMaxDims; ++d) {
+      if (d < nd) {
+        const CT x = load_as<CT>(p.s_ptr[d], p.s_dt[d], roff[d] + i * p.s_cs[d]);
+        const int b = digitize<CMP>(x, p.dim[d], tab);
+        ok &= (b >= 0);
+        flat += (int64_t)b * p.dim[d].out_stride;
+      }
     }
     double w = 0.0;
-    if (WEIGHTED) w = load_as<double>(p.w_ptr, p.w_dt, row * p.w_rs + i * p.w_cs);
+    if (WEIGHTED) w = load_as<double>(p.w_ptr, p.w_dt, woff + i * p.w_cs);
     if (LDS_HIST) {
       const uint32_t idx = ok ? (((uint32_t)flat << p.copies_log2) + mycopy) : trash;
       A::lds_add(hist, idx, w);
@@ -585,14 +606,14 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
 // min / max with numpy's NaN propagation (feeds np.histogram_bin_edges, core.py:383-388)
 // partial[3*b + {0,1,2}] = {min, max, saw_nan} of workgroup b
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs,
+__global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs, int64_t ir, int64_t os,
                                                        int64_t n_rows, int64_t n_cols, double* partial) {
   double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
   int nan = 0;
   const int64_t total = n_rows * n_cols;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = k / n_cols, c = k - r * n_cols;
-    const double x = load_as<double>(ptr, dt, r * rs + c * cs);
+    const double x = load_as<double>(ptr, dt, row_offset(r, rs, ir, os) + c * cs);
     nan |= (x != x);
     mn = fmin(mn, x);
     mx = fmax(mx, x);

@@ -48,10 +48,11 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   int64_t scs[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + r * p.s_rs[d];
+    sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + row_offset(p.row0 + r, p.s_rs[d], p.s_ir[d], p.s_os[d]);
     scs[d] = p.s_cs[d];
   }
-  const wscalar* wp = kWeighted ? reinterpret_cast<const wscalar*>(p.w_ptr) + r * p.w_rs : nullptr;
+  const wscalar* wp =
+      kWeighted ? reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + r, p.w_rs, p.w_ir, p.w_os) : nullptr;
   int max_steps = 1;
 #pragma unroll
   for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
@@ -145,9 +146,12 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
   ST* tile = reinterpret_cast<ST*>(xhist_smem + (((size_t)p.table_words * 8 + (size_t)nb * HP * 4 + 15) & ~(size_t)15));
   for (uint32_t i = tid; i < nb * HP; i += kLaneBlock) hist[i] = 0u;
 
-  const ST* base = reinterpret_cast<const ST*>(p.s_ptr[0]) + r0 * p.s_rs[0];
-  const int64_t rs = p.s_rs[0];
+  const ST* base = reinterpret_cast<const ST*>(p.s_ptr[0]);
   const int lrow = tid / TPR, lcol = (tid % TPR) * VL;
+  int64_t roff[PASSES];  // element offset of the PASSES rows this lane loads from
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k)
+    roff[k] = row_offset(p.row0 + r0 + min(k * RPP + lrow, rows_here - 1), p.s_rs[0], p.s_ir[0], p.s_os[0]);
   const DimTable& t = p.dim[0];
   uint32_t* myword = hist + (tid >> 1);
   const uint32_t myinc = 1u << ((tid & 1) << 4);
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
     for (int k = 0; k < PASSES; ++k) {
       const int row = k * RPP + lrow;
       const int64_t col = c0 + lcol;
-      const ST* src = base + (int64_t)row * rs + col;
+      const ST* src = base + roff[k] + col;
       if (row < rows_here && col + VL <= p.n_cols) {
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const lvec*>(src));
       } else {

@@ -66,7 +66,7 @@ def _local_extrema(a):
 
             torch = core._torch()
             flat = a.reshape(1, -1)
-            ptr, tag, rs, cs, keep = core._strided_view(flat, "torch")
+            ptr, tag, rs, cs, _ir, _os, keep = core._strided_view(flat, "torch")
             dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
             lo, hi = _native.minmax(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev,
                                     torch.cuda.current_stream(dev).cuda_stream)
