@@ -532,12 +532,40 @@ static kernel_fn fast_pick_w(int wdt, int D, int scan, int hist) {
   }
 }
 
+// Integer and half-precision samples (category ids, sensor counts, packed fields): the same vector
+// kernel with an in-register conversion to double — numpy compares them in float64 against
+// float64 edges too.  Kept to the shapes that matter so the instantiation count stays small:
+// one input, unweighted or float64 weights, LDS or global histogram, uniform-style tables
+// (SCAN 1) or binary search (SCAN 0); everything else takes the generic family.
+template <typename ST>
+static kernel_fn small_pick(int wdt, int D, int scan, int hist) {
+  if (D != 1 || (scan != 0 && scan != 1) || (hist != kHistLds && hist != kHistGlobal)) return nullptr;
+  if (wdt == -1) {
+    constexpr int VEC = 16 / (int)sizeof(ST);
+    constexpr int U0 = unroll_for(1, VEC, 0), U1 = unroll_for(1, VEC, 1);
+    if (hist == kHistLds) return scan ? (kernel_fn)hist_fast<ST, NoWeight, 1, VEC, U1, kHistLds, 1> : (kernel_fn)hist_fast<ST, NoWeight, 1, VEC, U0, kHistLds, 0>;
+    return scan ? (kernel_fn)hist_fast<ST, NoWeight, 1, VEC, U1, kHistGlobal, 1> : (kernel_fn)hist_fast<ST, NoWeight, 1, VEC, U0, kHistGlobal, 0>;
+  }
+  if (wdt == XHIST_F64) {
+    constexpr int VEC = 16 / (sizeof(ST) > 8 ? (int)sizeof(ST) : 8);
+    constexpr int U0 = unroll_for(1, VEC, 0), U1 = unroll_for(1, VEC, 1);
+    if (hist == kHistLds) return scan ? (kernel_fn)hist_fast<ST, double, 1, VEC, U1, kHistLds, 1> : (kernel_fn)hist_fast<ST, double, 1, VEC, U0, kHistLds, 0>;
+    return scan ? (kernel_fn)hist_fast<ST, double, 1, VEC, U1, kHistGlobal, 1> : (kernel_fn)hist_fast<ST, double, 1, VEC, U0, kHistGlobal, 0>;
+  }
+  return nullptr;
+}
+
 static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* vec) {
   const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
   *vec = 16 / std::max(ssz, wsz);
   switch (sdt) {
     case XHIST_F64: return fast_pick_w<double>(wdt, D, scan, hist);
     case XHIST_F32: return fast_pick_w<float>(wdt, D, scan, hist);
+    case XHIST_I32: return small_pick<int32_t>(wdt, D, scan, hist);
+    case XHIST_I64: return small_pick<int64_t>(wdt, D, scan, hist);
+    case XHIST_I16: return small_pick<int16_t>(wdt, D, scan, hist);
+    case XHIST_U8: return small_pick<uint8_t>(wdt, D, scan, hist);
+    case XHIST_F16: return small_pick<_Float16>(wdt, D, scan, hist);
     default: return nullptr;
   }
 }
@@ -951,75 +979,77 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const int sdt = samples[0].dtype;
   const int wdt = weighted ? weights->dtype : -1;
   int vec = 1;
-  bool fast = !force_generic && p->cmp == XHIST_CMP_F64 && D <= 3 && p->n_bins < ((int64_t)1 << 31) &&
-              (sdt == XHIST_F64 || sdt == XHIST_F32) && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32);
-  if (fast) {
-    vec = 16 / std::max(dtype_size(sdt), wdt < 0 ? 0 : dtype_size(wdt));
+  const bool float_samples = sdt == XHIST_F64 || sdt == XHIST_F32;
+  const bool small_samples = sdt == XHIST_I32 || sdt == XHIST_I64 || sdt == XHIST_I16 || sdt == XHIST_U8 || sdt == XHIST_F16;
+  bool fast_ok = !force_generic && p->cmp == XHIST_CMP_F64 && p->n_bins < ((int64_t)1 << 31) &&
+                 ((float_samples && D <= 3 && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32)) ||
+                  (small_samples && D == 1 && (wdt == -1 || wdt == XHIST_F64)));
+  if (fast_ok) {
     // unit column stride is all the vector family needs: gfx950 vector loads take any
     // element-aligned address (rows of 365 or 3650 samples stay on 16-byte loads)
-    for (int d = 0; d < D && fast; ++d) {
+    for (int d = 0; d < D && fast_ok; ++d) {
       const xhist_array& a = samples[d];
-      fast = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)dtype_size(sdt) == 0);
+      fast_ok = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)dtype_size(sdt) == 0);
     }
-    if (fast && weighted) fast = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
+    if (fast_ok && weighted) fast_ok = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
   }
-  // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
-  bool use_f32 = fast && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
-  int scan = 0;
-  const TableSet* tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
-  if (fast) tset = &pick_tables(p, use_f32, &scan);
-  size_t table_bytes = (size_t)tset->words * 8;
-  if (fast && table_bytes + 1024 > lds_cap) {  // the fast family keeps its tables in LDS
-    fast = false;
-    use_f32 = false;
-    scan = 0;
-    tset = &p->ts[0][0];
-    table_bytes = (size_t)tset->words * 8;
-  }
-  const bool tables_fit = table_bytes + 1024 <= lds_cap;
 
-  // ---- histogram placement -------------------------------------------------------------------
-  //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
-  //   packed: unweighted fast family only, uint16 counters packed two per word (exact, see kernel)
-  //   global: device-scope atomics straight into the output
+  // Two attempts: the vector family with its tables, then (if it has no kernel for this
+  // combination, or its tables do not fit LDS) the generic family with the native tables.
+  bool fast = false, use_f32 = false, tables_fit = false, lds_hist = false, tables_in_lds = false;
+  int scan = 0, hist = kHistGlobal, cl2 = 0;
+  const TableSet* tset = nullptr;
+  size_t table_bytes = 0, hist_bytes = 0, lds_bytes = 0;
+  kernel_fn fn = nullptr;
   const int acc_size = weighted ? 8 : 4;
   const int max_cl2 = weighted ? 4 : 5;
-  int hist = kHistGlobal;
-  int cl2 = 0;
-  size_t hist_bytes = 0;
-  if (!force_global && tables_fit && p->n_bins < ((int64_t)1 << 24)) {
-    const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
-    cl2 = max_cl2;
-    if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
-    auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
-    if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
-    while (cl2 > 0 && table_bytes + bytes_at(cl2) > lds_cap) --cl2;
-    if (table_bytes + bytes_at(cl2) <= lds_cap) {
-      hist = kHistLds;
-      hist_bytes = bytes_at(cl2);
-    } else if (fast && !weighted && table_bytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
-      hist = kHistPacked;
-      cl2 = 0;
-      hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
-    }
-  }
-  if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
-  const bool lds_hist = hist == kHistLds;
-  const bool tables_in_lds = tables_fit;
-  const size_t lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
+  for (int attempt = fast_ok ? 0 : 1; attempt < 2 && !fn; ++attempt) {
+    fast = attempt == 0;
+    // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
+    use_f32 = fast && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+    scan = 0;
+    tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
+    if (fast) tset = &pick_tables(p, use_f32, &scan);
+    table_bytes = (size_t)tset->words * 8;
+    if (fast && table_bytes + 1024 > lds_cap) continue;  // the vector family keeps its tables in LDS
+    tables_fit = table_bytes + 1024 <= lds_cap;
 
-  // (scan > 0: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
-  kernel_fn fn = nullptr;
-  if (fast) fn = fast_kernel(sdt, wdt, D, scan, hist, &vec);
-  if (!fn) {
-    if (hist == kHistPacked || scan != 0 || use_f32) return fail(XHIST_ERR_HIP, "internal: no vector kernel for this combination");
-    fast = false;
-    fn = generic_kernel(p->cmp, weighted, lds_hist);
+    // ---- histogram placement -----------------------------------------------------------------
+    //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
+    //   packed: unweighted vector family only, uint16 counters packed two per word (exact, see kernel)
+    //   global: device-scope atomics straight into the output
+    hist = kHistGlobal;
+    cl2 = 0;
+    hist_bytes = 0;
+    if (!force_global && tables_fit && p->n_bins < ((int64_t)1 << 24)) {
+      const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
+      cl2 = max_cl2;
+      if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
+      auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
+      if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
+      while (cl2 > 0 && table_bytes + bytes_at(cl2) > lds_cap) --cl2;
+      if (table_bytes + bytes_at(cl2) <= lds_cap) {
+        hist = kHistLds;
+        hist_bytes = bytes_at(cl2);
+      } else if (fast && float_samples && !weighted && table_bytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
+        hist = kHistPacked;
+        cl2 = 0;
+        hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+      }
+    }
+    if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
+    lds_hist = hist == kHistLds;
+    tables_in_lds = tables_fit;
+    lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
+    // (scan > 0: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
+    fn = fast ? fast_kernel(sdt, wdt, D, scan, hist, &vec) : generic_kernel(p->cmp, weighted, lds_hist);
   }
+  if (!fn) return fail(XHIST_ERR_HIP, "internal: no kernel for this combination");
+  if (!fast) vec = 1;
   const DimTable* dims = tset->dim;
 
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
-  if (fast && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
+  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
     const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || partition > 0;

@@ -308,6 +308,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
   constexpr int CMP = __is_same(ST, float) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
+  // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
+  // integer samples: zero, masked by the past_end bit
+  constexpr bool kFloatSamples = __is_same(ST, float) || __is_same(ST, double) || __is_same(ST, _Float16);
+  const ST kPastEnd = kFloatSamples ? (ST)__builtin_nanf("") : (ST)0;
   using A = Acc<WT>;
   using lds_t = typename A::lds_t;
   using out_t = typename A::out_t;
@@ -383,6 +387,8 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     const int64_t base = tile * tile_elems;
     svec xv[D][UNROLL];
     wvec wv[UNROLL];
+    uint32_t past_end = 0;  // bit (u * VEC + v): that sample lies beyond the row (ragged tile only)
+    static_assert(UNROLL * VEC <= 32, "past_end is a 32-bit mask");
     if (base + tile_elems <= p.n_cols) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
@@ -408,8 +414,9 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
           for (int v = 0; v < VEC; ++v) {
             const bool in = i + v < p.n_cols;
 #pragma unroll
-            for (int d = 0; d < D; ++d) xv[d][u][v] = in ? sp[d][i + v] : (ST)__builtin_nanf("");
+            for (int d = 0; d < D; ++d) xv[d][u][v] = in ? sp[d][i + v] : kPastEnd;
             if (kWeighted) wv[u][v] = in ? wp[i + v] : (wscalar)0;
+            if (!in) past_end |= 1u << (u * VEC + v);  // integer samples have no NaN: masked below
           }
         }
       }
@@ -454,7 +461,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          bool ok = true;
+          bool ok = kFloatSamples || !((past_end >> (u * VEC + v)) & 1u);
           uint32_t flat = 0;
 #pragma unroll
           for (int d = 0; d < D; ++d) {
