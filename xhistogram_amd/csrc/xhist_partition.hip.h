@@ -324,25 +324,44 @@ __global__ void __launch_bounds__(1024) part_accumulate(const uint16_t* codes, c
   while (lo < hi) {
     while (part + 1 < P && offsets[part + 1] <= lo) ++part;
     const uint64_t pend = min(hi, offsets[part + 1]);
-    uint64_t i = lo + tid;
-    constexpr int kInFlight = 8;  // independent record loads per lane
-    for (; i + (uint64_t)(kInFlight - 1) * blockDim.x < pend; i += (uint64_t)kInFlight * blockDim.x) {
-      uint16_t c[kInFlight];
-      double w[kInFlight];
-#pragma unroll
-      for (int k = 0; k < kInFlight; ++k) {
-        c[k] = __builtin_nontemporal_load(codes + i + (uint64_t)k * blockDim.x);
-        if (WEIGHTED) w[k] = __builtin_nontemporal_load(wrec + i + (uint64_t)k * blockDim.x);
-      }
-#pragma unroll
-      for (int k = 0; k < kInFlight; ++k) {
-        if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c[k], w[k]);
-        else atomicAdd(reinterpret_cast<uint32_t*>(hist) + c[k], 1u);
-      }
+    // Records of one partition are contiguous: after a scalar head up to a 4-record boundary
+    // every lane takes 4 consecutive records per load (8-byte code quad, 2 x 16-byte weight
+    // pairs), 2 such groups in flight; a scalar tail finishes the range.
+    uint64_t i = lo;
+    const uint64_t head_end = min(pend, (lo + 3) & ~(uint64_t)3);
+    for (uint64_t j = i + tid; j < head_end; j += blockDim.x) {
+      const uint16_t c = codes[j];
+      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, wrec[j]);
+      else atomicAdd(reinterpret_cast<uint32_t*>(hist) + c, 1u);
     }
-    for (; i < pend; i += blockDim.x) {
-      const uint16_t c = codes[i];
-      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, wrec[i]);
+    i = head_end;
+    typedef uint16_t c4 __attribute__((ext_vector_type(4)));
+    typedef double w2 __attribute__((ext_vector_type(2)));
+    constexpr int kGroups = 2;
+    const uint64_t step = (uint64_t)blockDim.x * 4 * kGroups;
+    for (; i + step <= pend; i += step) {
+      c4 cv[kGroups];
+      w2 wa[kGroups], wb[kGroups];
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const uint64_t j = i + ((uint64_t)g * blockDim.x + tid) * 4;
+        cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + j));
+        if (WEIGHTED) {
+          wa[g] = __builtin_nontemporal_load(reinterpret_cast<const w2*>(wrec + j));
+          wb[g] = __builtin_nontemporal_load(reinterpret_cast<const w2*>(wrec + j + 2));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], k < 2 ? wa[g][k] : wb[g][k - 2]);
+          else atomicAdd(reinterpret_cast<uint32_t*>(hist) + cv[g][k], 1u);
+        }
+    }
+    for (uint64_t j = i + tid; j < pend; j += blockDim.x) {
+      const uint16_t c = codes[j];
+      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, wrec[j]);
       else atomicAdd(reinterpret_cast<uint32_t*>(hist) + c, 1u);
     }
     __syncthreads();
