@@ -740,3 +740,31 @@ def test_grouped_rows_4d_two_inputs_broadcast_weights(xh, resident):
     bf = np.asfortranarray(b)
     want, _ = onp.histogram(a, bf, bins=[ea, eb], axis=[1, 2])
     np.testing.assert_array_equal(_tonp(xh.histogram(a, bf, bins=[ea, eb], axis=[1, 2])[0]), want)
+
+
+def test_int64_samples_round_to_double_like_numpy(xh):
+    """int64 data against float64 edges is compared AFTER rounding to double (numpy's promotion):
+    2^53 + 1 is not representable and lands on the edge 2^53"""
+    big = 2**53
+    x = np.array([[big - 1, big, big + 1, big + 2, big + 3, -big - 1, 2**62, -(2**62)]], dtype=np.int64)
+    e = np.array([-float(2**63), -float(big), float(big), float(big + 2), float(2**63)])
+    want = onp.bincount_rows([x], [e])
+    for resident in (False, True):
+        for params in ({}, {"force_generic": 1}):
+            if params and not resident:
+                continue
+            np.testing.assert_array_equal(_run(xh, [x], [e], None, resident, **params)[0], want)
+    xs = np.tile(x, (1, 4000))  # long enough for the vector kernel's full tiles
+    np.testing.assert_array_equal(_run(xh, [xs], [e], None, True)[0], onp.bincount_rows([xs], [e]))
+    # unsigned bytes and half floats, ragged lengths around the 16- and 8-element vectors
+    rng = np.random.default_rng(81)
+    for n in (1, 15, 16, 17, 4095, 4097, 70001):
+        u = rng.integers(0, 256, (2, n)).astype(np.uint8)
+        eu = np.linspace(0, 255, 18)
+        np.testing.assert_array_equal(_run(xh, [u], [eu], None, True)[0], onp.bincount_rows([u], [eu]))
+        h = (rng.standard_normal((2, n)) * 2).astype(np.float16)
+        h[0, 0] = np.nan
+        eh = np.linspace(-4, 4, 17)
+        np.testing.assert_array_equal(_run(xh, [h], [eh], None, True)[0], onp.bincount_rows([h], [eh]))
+        w = rng.uniform(0, 1, (2, n))
+        assert_hist_equal(_run(xh, [u], [eu], w, True)[0], onp.bincount_rows([u], [eu], w), True)
