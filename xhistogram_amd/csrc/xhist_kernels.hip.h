@@ -289,6 +289,46 @@ __device__ __forceinline__ const uint64_t* stage_tables(const Params& p) {
 template <typename T, int N>
 struct VecOf { typedef T type __attribute__((ext_vector_type(N), aligned(sizeof(T)))); };
 
+// #{edges <= x} for every sample of a register tile, as ONE branch-free batch: the table reads of
+// all VEC x UNROLL x D samples are independent and can be in flight together.  Shared by every
+// vector kernel (hist_fast, part_count).
+template <int CMP, int SCAN, int D, int UNROLL, int VEC, typename XV, typename TabPtr>
+__device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const Params& p, TabPtr tab, int max_steps,
+                                               uint32_t (&cnt)[D][UNROLL][VEC]) {
+  using CT = typename Dom<CMP>::T;
+  if constexpr (SCAN > 0) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int d = 0; d < D; ++d) cnt[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
+  } else {  // crowded buckets (duplicate / very uneven edges): branch-free binary search
+    DigState st[D][UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
+#pragma unroll 1
+    for (int k = 1; k < max_steps; ++k) {  // a round is a no-op once a sample's bucket is decided
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+          for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int d = 0; d < D; ++d) cnt[d][u][v] = st[d][u][v].lo;
+  }
+}
+
 // HIST: where a workgroup accumulates
 //   kHistGlobal  device-scope atomics straight into the output (histogram too large for LDS)
 //   kHistLds     replicated sub-histograms in LDS, one copy per lane bank (uint32 / float64)
@@ -422,39 +462,8 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       }
     }
     {
-      // whole tile as one branch-free batch: the table reads of all samples are independent
       uint32_t cnt[D][UNROLL][VEC];  // #{edges <= x} per sample and dimension
-      if constexpr (SCAN > 0) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int d = 0; d < D; ++d) cnt[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
-      } else {  // crowded buckets (duplicate / very uneven edges): branch-free binary search
-        DigState st[D][UNROLL][VEC];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
-#pragma unroll 1
-        for (int k = 1; k < max_steps; ++k) {  // a round is a no-op once a sample's bucket is decided
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-#pragma unroll
-              for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int d = 0; d < D; ++d) cnt[d][u][v] = st[d][u][v].lo;
-      }
+      count_le_tile<CMP, SCAN, D, UNROLL, VEC>(xv, p, tab, max_steps, cnt);
       bool okv[UNROLL][VEC];
       uint32_t flatv[UNROLL][VEC], oldv[UNROLL][VEC];
 #pragma unroll

@@ -78,39 +78,8 @@ __global__ void __launch_bounds__(kPartBlock) part_count(const Params p, uint32_
         }
     }
 
-    // digitize the whole tile as one branch-free batch (as in hist_fast)
     uint32_t cntle[D][UNROLL][VEC];
-    if constexpr (SCAN > 0) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-          for (int d = 0; d < D; ++d) cntle[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
-    } else {
-      DigState st[D][UNROLL][VEC];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-          for (int d = 0; d < D; ++d) st[d][u][v] = digitize_begin<CMP>((CT)xv[d][u][v], p.dim[d], tab);
-#pragma unroll 1
-      for (int k = 1; k < max_steps; ++k) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int d = 0; d < D; ++d) upper_bound_step<CMP>((CT)xv[d][u][v], p.dim[d], tab, st[d][u][v]);
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-          for (int d = 0; d < D; ++d) cntle[d][u][v] = st[d][u][v].lo;
-    }
+    count_le_tile<CMP, SCAN, D, UNROLL, VEC>(xv, p, tab, max_steps, cntle);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       fvec fo;
