@@ -194,6 +194,12 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
     }
     t.lut_k = K;
     t.scale = scale;
+    if (dom == 2) t.bias = (double)(-(float)t.e0_f * (float)scale);
+    else if (dom == 0) t.bias = -t.e0_f * scale;
+    if (!std::isfinite(t.bias)) {  // e.g. e_0 = -inf with scale 0: keep the map defined (bucket 0)
+      t.bias = 0.0;
+      if (K != 1) { K = 1; t.lut_k = 1; t.scale = 0.0; }
+    }
   }
   int64_t stride = 1;
   for (int d = n_inputs - 1; d >= 0; --d) {

@@ -41,6 +41,7 @@ struct DimTable {
   double e0_f, eL_f;    // first / last edge, float64 domain
   int64_t e0_i, eL_i;   // first / last edge, int64 domain
   double scale;         // lut_k / (e_last - e_0); 0 when the bucket grid is disabled (lut_k == 1)
+  double bias;          // -e_0 * scale: float domains map x -> fma(x, scale, bias) in one instruction
   int32_t n_edges;      // E
   int32_t nb;           // E - 1 real bins
   int32_t lut_k;        // number of buckets K
@@ -134,12 +135,15 @@ struct Dom<2> {  // float32 samples against float64 edges, compared EXACTLY in f
 // edges) and by digitize (on the samples): the two must be the same code.
 template <int CMP>
 __device__ __forceinline__ int bucket_of(typename Dom<CMP>::T x, const DimTable& t) {
-  if (CMP == 2) {  // all-float32 arithmetic (full-rate VALU); any monotone map is valid
-    float tt = (float)Dom<CMP>::offset(x, t) * (float)t.scale;
+  // Any monotone non-decreasing map works (see the header comment); a fused multiply-add is
+  // monotone in x for scale > 0 and is one instruction.  The table builder calls this very
+  // function on the edges, so samples and edges always agree on the map.
+  if (CMP == 2) {  // all-float32 arithmetic (full-rate VALU)
+    float tt = __builtin_fmaf((float)x, (float)t.scale, (float)t.bias);
     tt = __builtin_amdgcn_fmed3f(tt, 0.0f, (float)(t.lut_k - 1));  // one-op clamp; NaN -> 0
     return (int)tt;
   }
-  double tt = (double)Dom<CMP>::offset(x, t) * t.scale;
+  double tt = CMP == 0 ? __builtin_fma((double)x, t.scale, t.bias) : (double)Dom<CMP>::offset(x, t) * t.scale;
   tt = fmax(fmin(tt, (double)(t.lut_k - 1)), 0.0);  // fmin/fmax drop a NaN operand
   return (int)tt;
 }
@@ -388,6 +392,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os);
   out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
 
+  // D == 1 fast scatter (see the tile loop): this lane's copy of bin -1, and its trash slot
+  const uint32_t slot_shift = (uint32_t)p.copies_log2 + (sizeof(lds_t) == 8 ? 3u : 2u);
+  unsigned char* slot_base = reinterpret_cast<unsigned char*>(hist + mycopy) - ((size_t)1 << slot_shift);
+  lds_t* trash_slot = hist + trash;
   auto scatter = [&](bool ok, uint32_t flat, double w) {
     if (LDS_HIST) {
       const uint32_t idx = ok ? ((flat << p.copies_log2) + mycopy) : trash;
@@ -470,6 +478,18 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
+          if constexpr (D == 1 && LDS_HIST) {
+            // one input, LDS histogram: the slot address comes straight from the edge count
+            //   bin = min(cnt, nb) - 1  ->  byte offset (min(cnt, nb) << sh) from a base moved back
+            //   by one bin; out-of-range / NaN / past-the-end samples go to the lane's trash slot
+            const bool ok1 = Dom<CMP>::in_range((CT)xv[0][u][v], p.dim[0]) &
+                             (kFloatSamples || !((past_end >> (u * VEC + v)) & 1u));
+            const uint32_t off = min(cnt[0][u][v], (uint32_t)p.dim[0].nb) << slot_shift;
+            lds_t* slot = ok1 ? reinterpret_cast<lds_t*>(slot_base + off) : trash_slot;
+            if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
+            else atomicAdd(reinterpret_cast<uint32_t*>(slot), 1u);
+            continue;
+          }
           bool ok = kFloatSamples || !((past_end >> (u * VEC + v)) & 1u);
           uint32_t flat = 0;
 #pragma unroll
