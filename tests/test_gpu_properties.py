@@ -136,3 +136,48 @@ def test_one_plan_many_threads(xh):
     for (h, hn), w in zip(results, want):
         np.testing.assert_array_equal(h, w)
         np.testing.assert_array_equal(hn, w.astype(np.float64))
+
+
+@st.composite
+def large_cases(draw):
+    shape = draw(st.sampled_from([(5000, 37), (4100, 300), (7, 9000), (3, 40, 500), (300, 20, 7), (64, 64, 64), (2, 70001), (9000, 3, 5)]))
+    ndim = len(shape)
+    axis_choices = [None] + [tuple(c) for r in range(1, ndim + 1) for c in __import__("itertools").combinations(range(ndim), r)]
+    axis = draw(st.sampled_from(axis_choices))
+    dtype = draw(st.sampled_from([np.float64, np.float32, np.int32, np.uint8, np.float16, np.int64]))
+    d = draw(st.integers(1, 2))
+    kinds = [draw(st.sampled_from(["uniform", "random", "geometric"])) for _ in range(d)]
+    edges = [_edges(draw, k, draw(st.integers(2, 40))) for k in kinds]
+    wkind = draw(st.sampled_from([None, "f64", "f32", "bcast"]))
+    seed = draw(st.integers(0, 2**31 - 1))
+    return shape, axis, dtype, edges, wkind, seed
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
+@given(large_cases())
+def test_random_large_device_cases_match_oracle(xh, case):
+    """bigger blocks: full vector tiles with ragged tails, the row-per-lane kernels (fused and
+    transposing), grouped-row views of middle-axis reductions, integer / half samples"""
+    shape, axis, dtype, edges, wkind, seed = case
+    rng = np.random.default_rng(seed)
+    d = len(edges)
+    if np.dtype(dtype).kind == "f":
+        args = [(rng.standard_normal(shape) * 2).astype(dtype) for _ in range(d)]
+        args[0].reshape(-1)[:: max(1, args[0].size // 13)] = np.nan
+    elif dtype == np.uint8:
+        args = [rng.integers(0, 9, shape).astype(dtype) for _ in range(d)]
+    else:
+        args = [rng.integers(-5, 6, shape).astype(dtype) for _ in range(d)]
+    w = None
+    if wkind == "f64":
+        w = rng.uniform(0, 2, shape)
+    elif wkind == "f32":
+        w = rng.uniform(0, 2, shape).astype(np.float32)
+    elif wkind == "bcast":
+        w = rng.uniform(0, 2, (1,) * (len(shape) - 1) + shape[-1:])
+    kw = dict(bins=edges if d > 1 else edges[0], axis=axis)
+    want, _ = onp.histogram(*args, weights=w, **kw)
+    targs = [torch.as_tensor(a).cuda() for a in args]
+    tw = None if w is None else torch.as_tensor(w).cuda()
+    got, _ = xh.histogram(*targs, weights=tw, **kw)
+    assert_hist_equal(got.cpu().numpy(), want, weighted=w is not None)
