@@ -488,7 +488,7 @@ constexpr int unroll_for(int D, int vec, int scan) {
 }
 
 // partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
-constexpr int kHistPartCount = 4, kHistLanes = 6;
+constexpr int kHistPartCount = 4, kHistLanes = 6, kHistLanes16 = 7;
 constexpr int kPartMaxParts = 256;
 
 template <typename ST, typename WT, int D, int SCAN>
@@ -498,7 +498,11 @@ static kernel_fn fast_pick(int hist) {
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, SCAN);
   if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, SCAN>;
-  if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4)>;
+  if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+  if (hist == kHistLanes16) {
+    if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
+    else return nullptr;
+  }
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
     if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
@@ -924,7 +928,24 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   kp.out = out;
 
   const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
-  const int bpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds_bytes));
+  // unweighted and few enough columns per workgroup: uint16 counters, half the LDS
+  size_t lds_use = lds_bytes;
+  bool packed16 = false;
+  if (!weighted) {
+    const size_t lds16 = table_bytes + (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
+    const int bpc16 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds16));
+    int64_t segs16 = std::max<int64_t>(1, ((int64_t)p->cus * bpc16 * 2 + row_blocks - 1) / row_blocks);
+    segs16 = std::min<int64_t>(std::min<int64_t>(segs16, std::max<int64_t>(1, n_cols / 64)), 65535);
+    if ((n_cols + segs16 - 1) / segs16 <= 65535) {
+      kernel_fn_lanes f16 = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes16, &vec);
+      if (f16) {
+        fn = f16;
+        packed16 = true;
+        lds_use = lds16;
+      }
+    }
+  }
+  const int bpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds_use));
   int64_t col_segs = std::max<int64_t>(1, ((int64_t)p->cus * bpc * 2 + row_blocks - 1) / row_blocks);
   col_segs = std::min<int64_t>(col_segs, std::max<int64_t>(1, n_cols / 64));
   col_segs = std::min<int64_t>(col_segs, 65535);
@@ -933,8 +954,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const int direct = (col_segs == 1 && !accumulate) ? 1 : 0;
   if (!direct && !accumulate) HIPL(hipMemsetAsync(out, 0, (size_t)n_rows * p->n_bins * 8, stream));
   if (row_blocks > 2147483647LL) return release(XHIST_ERR_UNSUPPORTED);
-  if (lds_bytes > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_bytes, stream, kp, (int32_t)direct,
+  if (lds_use > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use));
+  hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_use, stream, kp, (int32_t)direct,
                      cols_per_seg);
   HIPL(hipGetLastError());
   {
@@ -945,8 +966,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     }
     char desc[384];
     snprintf(desc, sizeof desc,
-             "family=lanes hist=lds transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
-             (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_bytes, scan, (int)weighted, D,
+             "family=lanes hist=%s transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
+             packed16 ? "lds16" : "lds", (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_use, scan,
+             (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
     p->desc = desc;
   }

@@ -25,14 +25,18 @@ namespace xhist {
 
 constexpr int kLaneBlock = 256, kLanePitch = kLaneBlock + 1;
 
-template <typename ST, typename WT, int D, int SCAN, int UNROLL>
+// PACKED16 (unweighted, at most 65535 columns per workgroup): uint16 counters, two rows per LDS
+// word — half the LDS, twice the resident workgroups, twice the loads in flight.
+template <typename ST, typename WT, int D, int SCAN, int UNROLL, bool PACKED16>
 __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t direct_store, int64_t cols_per_seg) {
   constexpr int CMP = __is_same(ST, float) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  static_assert(!(PACKED16 && kWeighted), "packed counters count, they do not sum weights");
   using wscalar = typename std::conditional<kWeighted, WT, float>::type;
   using cnt_t = typename std::conditional<kWeighted, double, uint32_t>::type;
   using out_t = typename std::conditional<kWeighted, double, unsigned long long>::type;
+  constexpr int kPitch = PACKED16 ? kLaneBlock / 2 + 1 : kLanePitch;  // LDS words per bin
 
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * kLaneBlock;
@@ -41,7 +45,7 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   const uint64_t* tab = stage_tables(p);
   cnt_t* hist = reinterpret_cast<cnt_t*>(xhist_smem + (size_t)p.table_words * 8);
   const uint32_t nb = (uint32_t)p.n_bins;
-  for (uint32_t i = tid; i < nb * kLanePitch; i += kLaneBlock) hist[i] = (cnt_t)0;
+  for (uint32_t i = tid; i < nb * kPitch; i += kLaneBlock) hist[i] = (cnt_t)0;
   __syncthreads();
 
   const ST* sp[D];
@@ -59,7 +63,8 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
 
   const int64_t c_lo = (int64_t)blockIdx.y * cols_per_seg;
   const int64_t c_hi = min(p.n_cols, c_lo + cols_per_seg);
-  cnt_t* mine = hist + tid;
+  cnt_t* mine = hist + (PACKED16 ? tid >> 1 : tid);
+  const uint32_t my_inc = PACKED16 ? 1u << ((tid & 1) << 4) : 1u;
 
   auto bin_and_add = [&](const ST (&x)[D], wscalar w) {
     bool ok = true;
@@ -78,9 +83,9 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
       ok &= (b >= 0);
       flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
     }
-    cnt_t* slot = mine + (ok ? flat : 0u) * kLanePitch;
+    cnt_t* slot = mine + (ok ? flat : 0u) * kPitch;
     if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(slot), ok ? (double)w : 0.0);
-    else atomicAdd(reinterpret_cast<uint32_t*>(slot), ok ? 1u : 0u);
+    else atomicAdd(reinterpret_cast<uint32_t*>(slot), ok ? my_inc : 0u);
   };
 
   int64_t c = c_lo;
@@ -109,7 +114,9 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   const uint32_t total = (uint32_t)rows_here * nb;
   for (uint32_t j = tid; j < total; j += kLaneBlock) {
     const uint32_t row = j / nb, b = j - row * nb;
-    const cnt_t v = hist[b * kLanePitch + row];
+    cnt_t v;
+    if constexpr (PACKED16) v = (hist[b * kPitch + (row >> 1)] >> ((row & 1) << 4)) & 0xffffu;
+    else v = hist[b * kPitch + row];
     if (direct_store) {
       out[j] = (out_t)v;
     } else if (v != (cnt_t)0) {
