@@ -1,0 +1,37 @@
+"""The C ABI used from plain C (tests/capi_client.c): no Python, no torch on the calling side."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "capi_client")
+    lib = os.path.join(ROOT, "xhistogram_amd")
+    subprocess.run(
+        ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "capi_client.c"), "-o", exe,
+         "-L", lib, "-lxhist_amd", "-Wl,-rpath," + lib, "-lm"],
+        check=True,
+    )
+    return exe
+
+
+def test_c_client_builds_and_refuses_loudly_without_a_gpu(tmp_path):
+    from xhistogram_amd import _native
+
+    exe = _build(tmp_path)
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+    assert "no CPU path" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_matches_scalar_loop_on_gpu(tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("OK")

@@ -768,3 +768,30 @@ def test_int64_samples_round_to_double_like_numpy(xh):
         np.testing.assert_array_equal(_run(xh, [h], [eh], None, True)[0], onp.bincount_rows([h], [eh]))
         w = rng.uniform(0, 1, (2, n))
         assert_hist_equal(_run(xh, [u], [eu], w, True)[0], onp.bincount_rows([u], [eu], w), True)
+
+
+def test_execute_is_hip_graph_capturable(xh):
+    """memset + kernel on the caller's stream: a device-resident execute can be captured into a
+    hipGraph and replayed (eager launches are already ~10 us, so this is a property, not a speed-up)"""
+    from xhistogram_amd import _native
+
+    edges = np.linspace(-4, 4, 101)
+    rng = np.random.default_rng(91)
+    xs = [rng.standard_normal(200_000) for _ in range(2)]
+    x = _dev(xs[0])
+    plan = xh._get_plan([edges], _native.CMP_F64, 0)
+    out = torch.zeros(100, dtype=torch.int64, device="cuda")
+    xv = [_native.make_view(x.data_ptr(), _native.F64, x.numel(), 1)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.execute(xv, None, 1, x.numel(), out.data_ptr(), False, _native.MEM_DEVICE, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        plan.execute(xv, None, 1, x.numel(), out.data_ptr(), False, _native.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    for data in (xs[1], xs[0]):  # replay on new contents of the same buffer
+        x.copy_(_dev(data))
+        out.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), onp.bincount_rows([data.reshape(1, -1)], [edges])[0])

@@ -180,10 +180,14 @@ class Plan:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            load().xhist_plan_destroy(h)
+        if h and _lib is not None:
+            _lib.xhist_plan_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:  # module globals may already be gone at interpreter shutdown
+            self.close()
+        except Exception:
+            pass
 
     def set_param(self, key, value):
         check(load().xhist_plan_set_param(self._h, key.encode(), int(value)))
