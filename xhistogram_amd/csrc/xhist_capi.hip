@@ -638,6 +638,15 @@ static int validate_arrays(const xhist_plan* p, const xhist_array* samples, cons
   return XHIST_OK;
 }
 
+// zero n 8-byte output words on `stream` (see zero_words)
+static int zero_output(void* out, int64_t n_words, hipStream_t stream) {
+  if (n_words <= 0) return XHIST_OK;
+  const int grid = (int)std::min<int64_t>(2048, (n_words + 255) / 256);
+  hipLaunchKernelGGL(zero_words, dim3(grid), dim3(256), 0, stream, static_cast<unsigned long long*>(out), n_words);
+  HIPC(hipGetLastError());
+  return XHIST_OK;
+}
+
 static const void* advance(const void* base, int dt, int64_t elems) {
   return static_cast<const char*>(base) + elems * dtype_size(dt);
 }
@@ -952,7 +961,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const int64_t cols_per_seg = (n_cols + col_segs - 1) / col_segs;
   col_segs = (n_cols + cols_per_seg - 1) / cols_per_seg;
   const int direct = (col_segs == 1 && !accumulate) ? 1 : 0;
-  if (!direct && !accumulate) HIPL(hipMemsetAsync(out, 0, (size_t)n_rows * p->n_bins * 8, stream));
+  if (!direct && !accumulate)
+    if (int zrc = zero_output(out, n_rows * p->n_bins, stream)) return release(zrc);
   if (row_blocks > 2147483647LL) return release(XHIST_ERR_UNSUPPORTED);
   if (lds_use > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use));
   hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_use, stream, kp, (int32_t)direct,
@@ -983,7 +993,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const int64_t out_elems = n_rows * p->n_bins;
   if (out_elems == 0) return XHIST_OK;
   if (n_cols == 0) {
-    if (!accumulate) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
+    if (!accumulate)
+      if (int zrc = zero_output(out, out_elems, stream)) return zrc;
     return XHIST_OK;
   }
 
@@ -1000,7 +1011,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const int rc = execute_lanes(p, samples, weights, n_rows, n_cols, out, accumulate, stream, lanes > 0, profile);
     if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = not this shape, fall through
   }
-  if (!accumulate && out_elems > 0) HIPC(hipMemsetAsync(out, 0, (size_t)out_elems * 8, stream));
+  if (!accumulate)
+    if (int zrc = zero_output(out, out_elems, stream)) return zrc;
 
   // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
   const size_t lds_cap = p->lds_max;
@@ -1293,7 +1305,7 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
     return code;
   };
   if (hipMalloc(&d_out, (size_t)out_elems * 8) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
-  if (hipMemsetAsync(d_out, 0, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_HIP, "hipMemsetAsync failed"));
+  if (int zrc = zero_output(d_out, out_elems, stream)) return done(zrc);
 
   // views with grouped rows (reduced axes between kept axes) are staged whole, strides intact:
   // the bytes between the first and the last element are copied as they lie

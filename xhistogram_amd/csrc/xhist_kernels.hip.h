@@ -614,6 +614,13 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
   }
 }
 
+// Output zeroing as a kernel of this library rather than hipMemsetAsync: a memset node captured
+// into a hipGraph was observed (ROCm 7.0 runtime under torch) to replay with a garbage fill
+// value; a kernel node replays exactly.
+__global__ void __launch_bounds__(256) zero_words(unsigned long long* p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+
 // ---------------------------------------------------------------------------------------------
 // bucket-table builder: one workgroup per dimension applies bucket_of to that dimension's edges
 // (scratch[j] = bucket of edge j) and turns the sorted bucket ids into (start | cnt << 16).
