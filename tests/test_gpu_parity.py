@@ -795,3 +795,21 @@ def test_execute_is_hip_graph_capturable(xh):
         g.replay()
         torch.cuda.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy(), onp.bincount_rows([data.reshape(1, -1)], [edges])[0])
+
+
+def test_counts_do_not_depend_on_launch_geometry(xh):
+    """any lost or duplicated atomic would show as a count mismatch between geometries
+    (the determinism check that stands in for a race detector)"""
+    from xhistogram_amd import _native
+
+    rng = np.random.default_rng(95)
+    n = 3_000_017
+    x = rng.standard_normal((1, n))
+    y = rng.standard_normal((1, n))
+    for samples, edges in (([x], [np.linspace(-4, 4, 101)]), ([x, y], [np.linspace(-4, 4, 65), _nonuniform_edges(rng, 49)])):
+        want = onp.bincount_rows(samples, edges)
+        for block in (64, 256, 1024):
+            for grid in (1, 7, 256, 5000):
+                for copies in (0, 1, 8):
+                    got, _ = _run(xh, samples, edges, None, True, block_threads=block, grid_blocks=grid, lds_copies=copies)
+                    np.testing.assert_array_equal(got, want, err_msg="block=%d grid=%d copies=%d" % (block, grid, copies))
