@@ -15,7 +15,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxhist_amd.so")
+# $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
+LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
 ABI_VERSION = 2
 MAX_DIMS = 8
