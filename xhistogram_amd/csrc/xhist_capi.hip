@@ -470,6 +470,31 @@ static const TableSet& pick_tables(const xhist_plan* p, bool use_f32, int* scan)
   return p->ts[use_f32 ? 1 : 0][0];
 }
 
+// HIP-event pair around the kernels of one execute ("profile" plan parameter) + the launch
+// description kept for xhist_plan_describe.  begin() before the first launch, end() after the last.
+struct LaunchRecord {
+  xhist_plan* p;
+  hipStream_t stream;
+  int slot = -1;
+  LaunchRecord(xhist_plan* plan, hipStream_t s) : p(plan), stream(s) {}
+  int begin(int profile) {
+    if (!profile) return XHIST_OK;
+    std::lock_guard<std::mutex> lk(p->mu);
+    slot = (int)(p->n_recorded % profile);
+    HIPC(hipEventRecord(p->ring[(size_t)slot].first, stream));
+    return XHIST_OK;
+  }
+  int end(const char* desc) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->desc = desc;
+    if (slot >= 0) {
+      HIPC(hipEventRecord(p->ring[(size_t)slot].second, stream));
+      ++p->n_recorded;
+    }
+    return XHIST_OK;
+  }
+};
+
 typedef void (*kernel_fn)(const Params);
 typedef void (*kernel_fn_acc)(const uint16_t*, const double*, const uint64_t*, void*, int64_t, int, int);
 typedef void (*kernel_fn_count)(const Params, uint32_t*);
@@ -737,12 +762,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   kernel_fn_acc k_acc = weighted ? (kernel_fn_acc)part_accumulate<true> : (kernel_fn_acc)part_accumulate<false>;
   if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
 
-  int ring_slot = -1;
-  if (profile) {
-    std::lock_guard<std::mutex> lk(p->mu);
-    ring_slot = (int)(p->n_recorded % profile);
-    HIPR(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
-  }
+  LaunchRecord rec(p, stream);
+  if (int rrc = rec.begin(profile)) return release(rrc);
   hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, d_offsets, d_base);
@@ -754,18 +775,13 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
                      (const uint64_t*)d_offsets, out, p->n_bins, shift, n_parts);
   HIPR(hipGetLastError());
   {
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (ring_slot >= 0) {
-      HIPR(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
-      ++p->n_recorded;
-    }
     char desc[384];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned parts=%d bins_per_part=%d vec=%d tile=%d block=%d grid=%d acc_grid=%d lds_count=%zu "
              "lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
              n_parts, 1 << shift, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
-    p->desc = desc;
+    if (int rrc = rec.end(desc)) return release(rrc);
   }
 #undef HIPR
   return release(XHIST_OK);
@@ -847,26 +863,16 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
       if (row_blocks > 2147483647LL) return XHIST_ERR_UNSUPPORTED;
       const int direct = accumulate ? 0 : 1;
-      int ring_slot = -1;
-      if (profile) {
-        std::lock_guard<std::mutex> lk(p->mu);
-        ring_slot = (int)(p->n_recorded % profile);
-        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
-      }
+      LaunchRecord rec(p, stream);
+      if (int rrc = rec.begin(profile)) return rrc;
       if (lds_f > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       hipLaunchKernelGGL(f1, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_f, stream, kp, (int32_t)direct);
       HIPC(hipGetLastError());
-      std::lock_guard<std::mutex> lk(p->mu);
-      if (ring_slot >= 0) {
-        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
-        ++p->n_recorded;
-      }
       char desc[384];
       snprintf(desc, sizeof desc,
                "family=lanes hist=lds16 transpose=fused direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=0 D=1 cmp=%s",
                direct, kLaneBlock, (long long)row_blocks, lds_f, scan, use_f32 ? "f32thr" : "f64");
-      p->desc = desc;
-      return XHIST_OK;
+      return rec.end(desc);
     }
   }
 
@@ -885,12 +891,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   Params kp;
   memset(&kp, 0, sizeof kp);
   const DimTable* dims = tset.dim;
-  int ring_slot = -1;
-  if (profile) {
-    std::lock_guard<std::mutex> lk(p->mu);
-    ring_slot = (int)(p->n_recorded % profile);
-    HIPL(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
-  }
+  LaunchRecord rec(p, stream);
+  if (int rrc = rec.begin(profile)) return release(rrc);
   for (int d = 0; d <= D; ++d) {
     if (d == D && !weighted) break;
     const xhist_array& a = d < D ? samples[d] : *weights;
@@ -969,18 +971,13 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
                      cols_per_seg);
   HIPL(hipGetLastError());
   {
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (ring_slot >= 0) {
-      HIPL(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
-      ++p->n_recorded;
-    }
     char desc[384];
     snprintf(desc, sizeof desc,
              "family=lanes hist=%s transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
              packed16 ? "lds16" : "lds", (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_use, scan,
              (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
-    p->desc = desc;
+    if (int rrc = rec.end(desc)) return release(rrc);
   }
 #undef HIPL
   return release(XHIST_OK);
@@ -1146,7 +1143,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     if (per_wg >= ((int64_t)1 << 31)) col_chunk = segs_full * (((int64_t)1 << 30) / tile) * tile;
   }
   bool first_launch = true;
-  int ring_slot = -1;
+  LaunchRecord rec(p, stream);
   char desc[384];
   for (int64_t c0 = 0; c0 < n_cols; c0 += col_chunk) {
     const int64_t nc = std::min(col_chunk, n_cols - c0);
@@ -1186,11 +1183,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       kp.copies_log2 = cl2;
       kp.segs = (int32_t)segs;
       const dim3 grid((unsigned)(nr * segs));
-      if (profile && first_launch) {
-        std::lock_guard<std::mutex> lk(p->mu);
-        ring_slot = (int)(p->n_recorded % profile);
-        HIPC(hipEventRecord(p->ring[(size_t)ring_slot].first, stream));
-      }
+      if (first_launch)
+        if (int rrc = rec.begin(profile)) return rrc;
       hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
       HIPC(hipGetLastError());
       if (first_launch) {
@@ -1206,15 +1200,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       r0 += nr;
     }
   }
-  {
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (ring_slot >= 0) {
-      HIPC(hipEventRecord(p->ring[(size_t)ring_slot].second, stream));
-      ++p->n_recorded;
-    }
-    p->desc = desc;
-  }
-  return XHIST_OK;
+  return rec.end(desc);
 }
 
 // ------------------------------------------------------------------------------------------
