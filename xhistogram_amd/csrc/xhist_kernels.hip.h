@@ -580,7 +580,62 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
   for (int d = 0; d < kMaxDims; ++d) roff[d] = d < nd ? row_offset(p.row0 + row, p.s_rs[d], p.s_ir[d], p.s_os[d]) : 0;
   const int64_t woff = WEIGHTED ? row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os) : 0;
 
-  for (int64_t i = (int64_t)seg * blockDim.x + tid; i < p.n_cols; i += (int64_t)p.segs * blockDim.x) {
+  auto scatter = [&](bool ok, int64_t flat, double w) {
+    if (LDS_HIST) {
+      const uint32_t idx = ok ? (((uint32_t)flat << p.copies_log2) + mycopy) : trash;
+      A::lds_add(hist, idx, w);
+    } else if (ok) {
+      if (WEIGHTED) A::out_add(out, flat, w);
+      else A::out_add(out, flat, 1);
+    }
+  };
+  const int64_t stride = (int64_t)p.segs * blockDim.x;
+  int64_t i = (int64_t)seg * blockDim.x + tid;
+  if (nd <= 2) {
+    // one or two inputs (nearly every call): 4 samples per lane and step as one batch, so the
+    // dependent table reads of a sample overlap with those of the other three
+    constexpr int B = 4;
+    int max_steps = max(p.dim[0].steps, nd > 1 ? p.dim[1].steps : 1);
+    for (; i + (B - 1) * stride < p.n_cols; i += B * stride) {
+      CT x[B][2];
+      double w[B];
+      DigState st[B][2];
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          if (d < nd) x[k][d] = load_as<CT>(p.s_ptr[d], p.s_dt[d], roff[d] + (i + k * stride) * p.s_cs[d]);
+        w[k] = WEIGHTED ? load_as<double>(p.w_ptr, p.w_dt, woff + (i + k * stride) * p.w_cs) : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          if (d < nd) st[k][d] = digitize_begin<CMP>(x[k][d], p.dim[d], tab);
+#pragma unroll 1
+      for (int r = 1; r < max_steps; ++r) {
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            if (d < nd) upper_bound_step<CMP>(x[k][d], p.dim[d], tab, st[k][d]);
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        bool ok = true;
+        int64_t flat = 0;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          if (d < nd) {
+            const int b = digitize_end(p.dim[d], st[k][d]);
+            ok &= (b >= 0);
+            flat += (int64_t)b * p.dim[d].out_stride;
+          }
+        scatter(ok, flat, w[k]);
+      }
+    }
+  }
+  for (; i < p.n_cols; i += stride) {
     bool ok = true;
     int64_t flat = 0;
 #pragma unroll
@@ -594,13 +649,7 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
     }
     double w = 0.0;
     if (WEIGHTED) w = load_as<double>(p.w_ptr, p.w_dt, woff + i * p.w_cs);
-    if (LDS_HIST) {
-      const uint32_t idx = ok ? (((uint32_t)flat << p.copies_log2) + mycopy) : trash;
-      A::lds_add(hist, idx, w);
-    } else if (ok) {
-      if (WEIGHTED) A::out_add(out, flat, w);
-      else A::out_add(out, flat, 1);
-    }
+    scatter(ok, flat, w);
   }
 
   if (LDS_HIST) {
