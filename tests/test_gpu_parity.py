@@ -813,3 +813,18 @@ def test_counts_do_not_depend_on_launch_geometry(xh):
                 for copies in (0, 1, 8):
                     got, _ = _run(xh, samples, edges, None, True, block_threads=block, grid_blocks=grid, lds_copies=copies)
                     np.testing.assert_array_equal(got, want, err_msg="block=%d grid=%d copies=%d" % (block, grid, copies))
+
+
+def test_tables_too_large_for_lds_are_read_through_l2(xh):
+    """50001 edges (400 KB of tables): the generic family reads the tables from global memory and
+    accumulates with global atomics; 65536+ edges per dimension are refused with a clear message"""
+    rng = np.random.default_rng(97)
+    x = rng.standard_normal((2, 300_000)) * 2
+    e = np.linspace(-5, 5, 50_001)
+    got, desc = _run(xh, [x], [e], None, True)
+    assert "family=generic" in desc and "hist=global" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x], [e]))
+    w = rng.uniform(0, 1, x.shape)
+    assert_hist_equal(_run(xh, [x], [e], w, False)[0], onp.bincount_rows([x], [e], w), True)
+    with pytest.raises(NotImplementedError, match="65535"):
+        _run(xh, [x], [np.linspace(-5, 5, 70_000)], None, True)
