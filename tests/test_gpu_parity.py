@@ -521,6 +521,36 @@ def test_partitioned_mode_skewed_everything_in_one_bin(xh):
     np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges))
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_partitioned_mode_more_than_128_partitions(xh, weighted):
+    """> 128 partitions: records leave the scatter pass in groups of 4 instead of 8"""
+    rng = np.random.default_rng(47)
+    n = 2_500_003
+    nb = 1500 if weighted else 2100  # 2.25 M float64 bins / 4.41 M uint32 bins = 138 / 135 partitions
+    x = rng.standard_normal((1, n))
+    y = rng.uniform(-4.2, 4.2, (1, n))
+    w = rng.uniform(-1, 1, (1, n)) if weighted else None
+    edges = [np.linspace(-4, 4, nb + 1), np.linspace(-4, 4, nb + 1)]
+    want = onp.bincount_rows([x, y], edges, w)
+    got, desc = _run(xh, [x, y], edges, w, True, partition=1)
+    assert "hist=partitioned" in desc and "group=4" in desc, desc
+    assert_hist_equal(got, want, weighted)
+
+
+def test_partitioned_mode_tiny_and_ragged_inputs(xh):
+    """forced partitioned mode on inputs of a few records: carried records and padding only"""
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    rng = np.random.default_rng(48)
+    for n in (4, 5, 7, 8, 9, 8191, 8192, 8193, 16389):
+        x = rng.standard_normal((1, n))
+        y = rng.standard_normal((1, n))
+        w = rng.uniform(0, 1, (1, n))
+        for ww in (None, w):
+            got, desc = _run(xh, [x, y], edges, ww, True, partition=1)
+            assert "hist=partitioned" in desc, desc
+            assert_hist_equal(got, onp.bincount_rows([x, y], edges, ww), ww is not None)
+
+
 # ---------------------------------------------------------------------------------------------
 # row-per-lane kernels: leading-axis reductions and many short rows
 # ---------------------------------------------------------------------------------------------

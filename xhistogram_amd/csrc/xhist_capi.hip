@@ -687,13 +687,21 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   int vec = 1;
   kernel_fn_count k_count = (kernel_fn_count)fast_kernel(sdt, wdt, D, scan, kHistPartCount, &vec);
   if (!k_count) return XHIST_ERR_UNSUPPORTED;
-  kernel_fn_scatter k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight>
-                                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double> : (kernel_fn_scatter)part_scatter<float>);
+  // records leave part_scatter in aligned groups: 8 (one 16-byte code store) while the carried
+  // records of all partitions fit LDS next to the tile, else 4
+  const int grp = n_parts <= 128 ? 8 : 4;
+  kernel_fn_scatter k_scatter;
+  if (grp == 8)
+    k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight, 8>
+                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double, 8> : (kernel_fn_scatter)part_scatter<float, 8>);
+  else
+    k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight, 4>
+                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double, 4> : (kernel_fn_scatter)part_scatter<float, 4>);
   const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_count = table_bytes + (size_t)(n_parts + 1) * 32 * 4;
-  const size_t lds_scatter = 6144 + (size_t)kPartTile * (weighted ? 16 : 4);
-  const size_t lds_acc = (size_t)(1u << shift) * (weighted ? 8 : 4);
-  if (lds_count > p->lds_max || lds_scatter > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  const size_t lds_scatter = part_scatter_lds(n_parts, grp, weighted);
+  const size_t lds_acc = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);  // + the trash slot of padding records
+  if (lds_count > p->lds_max || lds_scatter > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   const int per_cu = std::max<int>(1, std::min<int>(4, (int)(160 * 1024 / std::max(lds_count, lds_scatter))));
   const int64_t n_tiles = (n_cols + kPartTile - 1) / kPartTile;
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
@@ -722,8 +730,9 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   HIPR(hipMallocAsync((void**)&d_base, (size_t)G * n_parts * 8, stream));
   HIPR(hipMallocAsync((void**)&d_offsets, (size_t)(n_parts + 1) * 8, stream));
   HIPR(hipMallocAsync((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
-  HIPR(hipMallocAsync((void**)&d_codes, (size_t)n_cols * 2 + 16, stream));
-  if (weighted) HIPR(hipMallocAsync((void**)&d_w, (size_t)n_cols * 8 + 16, stream));
+  const size_t n_rec = (size_t)n_cols + (size_t)G * n_parts * grp;  // every slice rounded up to whole groups
+  HIPR(hipMallocAsync((void**)&d_codes, n_rec * 2 + 16, stream));
+  if (weighted) HIPR(hipMallocAsync((void**)&d_w, n_rec * 8 + 16, stream));
 
   Params kp;
   memset(&kp, 0, sizeof kp);
@@ -766,7 +775,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   if (int rrc = rec.begin(profile)) return release(rrc);
   hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
   HIPR(hipGetLastError());
-  hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, d_offsets, d_base);
+  hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, grp, d_offsets, d_base);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
                      weighted ? weights->data : nullptr, n_cols, (const uint64_t*)d_base, d_codes, d_w, shift, n_parts);
@@ -777,9 +786,9 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   {
     char desc[384];
     snprintf(desc, sizeof desc,
-             "family=fast hist=partitioned parts=%d bins_per_part=%d vec=%d tile=%d block=%d grid=%d acc_grid=%d lds_count=%zu "
-             "lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
-             n_parts, 1 << shift, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
+             "family=fast hist=partitioned parts=%d bins_per_part=%d group=%d vec=%d tile=%d block=%d grid=%d acc_grid=%d "
+             "lds_count=%zu lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
+             n_parts, 1 << shift, grp, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
     if (int rrc = rec.end(desc)) return release(rrc);
   }
@@ -1089,7 +1098,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
     const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
-    const bool big_enough = n_cols >= ((int64_t)1 << 22) || partition > 0;
+    const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
     if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
       const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, *tset, shift,
                                          (int)n_parts, profile);
