@@ -129,7 +129,7 @@ def main():
         out = torch.zeros(256 * 256, dtype=torch.int64, device=dev)
         y = w * 8.0 - 4.0
         v3 = [_native.make_view(x.data_ptr(), _native.F64, n, 1), _native.make_view(y.data_ptr(), _native.F64, n, 1)]
-        for block in (256, 1024):
+        for block in (0, 512, 768, 1024):
             p3.set_param("block_threads", block)
             med, mn = timed(p3, v3, None, 1, n, out, False, stream, 3, _native)
             emit(case="c3_2d_256x256_nonuniform", block=block, ms=med, gbs=16 * n / med / 1e6, frac=16 * n / med / 1e6 / 8000, desc=p3.describe())

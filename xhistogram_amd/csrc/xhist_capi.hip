@@ -1111,7 +1111,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
   // (profiles/r01_a_sweep.jsonl) the streaming rate peaks at ~64 KiB of outstanding loads per CU
   // (f64+weights: 2 x 256 threads x 128 B; f64: 4 x 256 x 64 B) and falls by 5-10% with more.
-  int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? 1024 : 256);
+  // big LDS footprints leave room for one or two workgroups per CU; within-box sweeps: 512 threads
+  // for the replicated/plain LDS histograms (2.43-2.47 ms against 2.50-2.55 at 1024 for 10^9 x 2
+  // f64), 768 = three wavefronts per SIMD for the packed-uint16 one (C3: 2.45 against 2.54 at 1024,
+  // 2.86 at 512)
+  int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? (hist == kHistPacked ? 768 : 512) : 256);
   if (!block_threads && n_rows > 1 && lds_bytes <= 40 * 1024) {
     // many rows, one workgroup each: a tile should be ~1/4 of the row or most of the workgroup
     // idles in the ragged tile (100k rows x 3650: 0.46 -> 0.39 ms; 356k x 1024: 1.3 -> 0.58 ms)

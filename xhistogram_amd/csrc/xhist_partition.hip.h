@@ -1,9 +1,10 @@
 // xhist_partition.hip.h — partitioned mode for histograms that do not fit the 160 KiB LDS of a CU
 // (BASELINE C5: 1024 x 1024 float64 bins = 8 MiB).
 //
-// Why: device-scope atomics on MI355X execute at the memory side and serialise per cache line
-// (~12 ns each; measured 2.4e10 atomics/s for C5's distribution), a hard ceiling ~15x below what
-// the sample stream could feed.  LDS atomics have no such ceiling, so the bins are cut into
+// Why: global atomics on MI355X run at a flat ~2.4e10 (f64) / 2.7e10 (u32) per second for the whole
+// chip — whatever the scope (agent, workgroup, wavefront), whether the table is 64 KiB or 8 MiB,
+// one copy or one per XCD (tools/ubench/l2atomic.hip, profiles/r01_l_l2atomic_scopes.jsonl) — a
+// hard ceiling ~15x below what the sample stream could feed.  LDS atomics have no such ceiling, so the bins are cut into
 // partitions of 2^shift bins that DO fit LDS, and the samples are routed to their partition first:
 //
 //   pass 0  part_count          digitize; count samples per (workgroup, partition); spill   reads samples,
@@ -18,7 +19,8 @@
 //
 // No global atomics on the sample path (pass A's slots come from pass 0's counts, so the record
 // order is deterministic); HBM traffic for C5 = 16+4 | 4+8+10 | 10 = 52 B/sample instead of 24, which
-// bounds this mode at ~0.46 of the streaming rate — against 0.07 for global atomics.
+// bounds this mode at ~0.46 of the streaming rate — against 0.07 for global atomics.  Passes 0 and A
+// mix reads and writes and run at 5.3 and 4.7 TB/s (a pure read stream reaches 7.0).
 // Same tile->workgroup assignment in pass 0 and pass A (same grid, 8192-sample tiles) is what
 // makes the counts valid slot reservations.
 #pragma once
