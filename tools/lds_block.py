@@ -1,5 +1,6 @@
+"""Development tool: block-size sweep for histograms with a large LDS footprint."""
 import os, sys, json, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from xhistogram_amd import _native, core

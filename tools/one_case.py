@@ -1,5 +1,6 @@
+"""Development tool: time one 1-D case:  python tools/one_case.py <n_bins> <weighted 0|1>"""
 import os, sys, json, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from xhistogram_amd import _native, core
