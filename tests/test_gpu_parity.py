@@ -552,6 +552,122 @@ def test_partitioned_mode_tiny_and_ragged_inputs(xh):
 
 
 # ---------------------------------------------------------------------------------------------
+# arithmetic edges (bins=int / np.linspace): table-free digitize when the edge tables would not fit
+# ---------------------------------------------------------------------------------------------
+def _edge_torture(edges, rng, n_random, dtype=np.float64):
+    """samples that sit on, just below and just above every edge, plus the usual specials"""
+    e = np.asarray(edges, dtype=np.float64)
+    parts = [e, np.nextafter(e, -np.inf), np.nextafter(e, np.inf), rng.uniform(e[0] - 1, e[-1] + 1, n_random),
+             np.array([np.nan, np.inf, -np.inf, e[0], e[-1], 0.0, -0.0])]
+    if dtype == np.float32:  # float32 neighbours of the float32-rounded edges
+        f = e.astype(np.float32)
+        parts += [f.astype(np.float64), np.nextafter(f, np.float32(-np.inf)).astype(np.float64),
+                  np.nextafter(f, np.float32(np.inf)).astype(np.float64)]
+    x = np.concatenate(parts).astype(dtype)
+    rng.shuffle(x)
+    return x.reshape(1, -1)
+
+
+@pytest.mark.parametrize("nb,weighted,dt,want_hist", [
+    (30000, False, np.float64, "hist=lds"),       # 120 KB of uint32 counters; the edge table alone would be 240 KB
+    (60000, False, np.float64, "hist=packed16"),  # uint16 counters, table-free
+    (12000, True, np.float64, "hist=lds"),        # 96 KB of float64 sums + 96 KB of edges would not fit together
+    (20000, False, np.float32, "hist=lds"),       # float32 samples compared in float64 (the tables would fit, with 3 edges per bucket)
+    (15000, True, np.float32, "hist=lds"),        # 120 KB of float64 sums + 60 KB of float32 thresholds would not fit
+])
+def test_arithmetic_edges_large_1d(xh, nb, weighted, dt, want_hist):
+    rng = np.random.default_rng(61 + nb)
+    edges = [np.linspace(-3.7, 5.1, nb + 1)]
+    x = _edge_torture(edges[0], rng, 400_000, dt)
+    w = rng.uniform(-1, 2, x.shape) if weighted else None
+    got, desc = _run(xh, [x], edges, w, True)
+    assert "family=fast" in desc and "scan=5" in desc and want_hist in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
+    got, desc = _run(xh, [x], edges, w, False)  # host route
+    assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
+
+
+@pytest.mark.parametrize("lo,hi", [(-4.0, 4.0), (0.0, 1.0), (-1e-300, 3e-300), (-1e300, 1e300), (1e6, 1e6 + 1.0),
+                                   (-123.456, -123.0), (0.1, 0.7), (2.0 ** -1074 * 64, 2.0 ** -1074 * 64000)])
+@pytest.mark.parametrize("nb", [1, 2, 7, 100, 1001])
+def test_arithmetic_digitize_forced_small_bin_counts(xh, lo, hi, nb):
+    """the table-free digitize on shapes where it is not the automatic choice: every edge, its two
+    neighbours, out-of-range values and specials, for several magnitudes of e_0 and step"""
+    rng = np.random.default_rng(nb)
+    edges = [np.linspace(lo, hi, nb + 1)]
+    if np.any(np.diff(edges[0]) < 0):
+        pytest.skip("np.linspace itself is not monotone here (subnormal step)")
+    x = _edge_torture(edges[0], rng, 0)
+    x = np.concatenate([x, rng.uniform(lo - (hi - lo) * 0.1, hi + (hi - lo) * 0.1, (1, 5000))], axis=1)
+    want = onp.bincount_rows([x], edges)
+    got, desc = _run(xh, [x], edges, None, True, arith=1)
+    np.testing.assert_array_equal(got, want, err_msg=desc)
+    if (lo, hi) == (-4.0, 4.0):
+        assert "scan=5" in desc, desc
+    w = rng.uniform(0, 1, x.shape)
+    assert_hist_equal(_run(xh, [x], edges, w, True, arith=1)[0], onp.bincount_rows([x], edges, w), True)
+
+
+def test_arithmetic_digitize_forced_2d_3d_f32(xh):
+    rng = np.random.default_rng(71)
+    n = 200_000
+    e2 = [np.linspace(-3, 3, 41), np.linspace(0, 10, 1001)]
+    x = rng.standard_normal((1, n))
+    y = _edge_torture(e2[1], rng, n - 3 * 1001 - 7)
+    got, desc = _run(xh, [x, y], e2, None, True, arith=1)
+    assert "scan=5" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x, y], e2))
+    e3 = [np.linspace(-3, 3, 13), np.linspace(-3, 3, 9), np.linspace(-3, 3, 17)]
+    s3 = [rng.standard_normal((4, n // 4)).astype(np.float32) for _ in range(3)]
+    w = rng.uniform(0, 1, s3[0].shape).astype(np.float32)
+    got, desc = _run(xh, s3, e3, w, True, arith=1)
+    assert "scan=5" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows(s3, e3, w), True)
+
+
+def test_arithmetic_edges_partitioned_count_pass(xh):
+    """60000 weighted bins: histogram and edge tables both beyond LDS -> partitioned, table-free count pass"""
+    rng = np.random.default_rng(67)
+    edges = [np.linspace(0.0, 1.0, 60001)]
+    x = _edge_torture(edges[0], rng, 600_000)
+    w = rng.uniform(0, 1, x.shape)
+    got, desc = _run(xh, [x], edges, w, True, partition=1)
+    assert "hist=partitioned" in desc and "scan=5" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([x], edges, w), True)
+
+
+def test_arithmetic_edges_not_assumed(xh):
+    """edges that only LOOK uniform keep the table path (and stay exact)"""
+    rng = np.random.default_rng(68)
+    cases = {
+        "cumsum": np.cumsum(np.full(30001, 0.1)) - 7.0,            # accumulated rounding: not j*step + e_0
+        "perturbed": np.linspace(-4, 4, 30001),
+        "coarse_ulp": np.linspace(1e15, 1e15 + 3000.0, 30001),     # step 0.1 vs ulp 0.125: not resolved
+    }
+    cases["perturbed"] = cases["perturbed"].copy()
+    cases["perturbed"][12345] = np.nextafter(cases["perturbed"][12345], np.inf)
+    for name, e in cases.items():
+        e = np.maximum.accumulate(e)
+        x = _edge_torture(e, rng, 50_000)
+        got, desc = _run(xh, [x], [e], None, True)
+        assert "scan=5" not in desc, (name, desc)
+        np.testing.assert_array_equal(got, onp.bincount_rows([x], [e]), err_msg=name)
+
+
+def test_arithmetic_edges_2d_beyond_lds_tables(xh):
+    """two inputs whose edge tables (2 x 6000 edges = 96 KB + bucket tables) crowd the histogram out of LDS"""
+    rng = np.random.default_rng(69)
+    edges = [np.linspace(-2, 2, 9), np.linspace(-4, 4, 6001)]
+    n = 300_000
+    x = rng.standard_normal((1, n))
+    y = _edge_torture(edges[1], rng, n - 3 * 6001 - 7)
+    assert y.shape == x.shape
+    got, desc = _run(xh, [x, y], edges, None, True)
+    assert "family=fast" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges))
+
+
+# ---------------------------------------------------------------------------------------------
 # row-per-lane kernels: leading-axis reductions and many short rows
 # ---------------------------------------------------------------------------------------------
 def _describe_last(xh, samples, edges):
@@ -846,11 +962,17 @@ def test_counts_do_not_depend_on_launch_geometry(xh):
 
 
 def test_tables_too_large_for_lds_are_read_through_l2(xh):
-    """50001 edges (400 KB of tables): the generic family reads the tables from global memory and
-    accumulates with global atomics; 65536+ edges per dimension are refused with a clear message"""
+    """50001 edges (400 KB of tables) that are NOT arithmetic: the generic family reads the tables
+    from global memory and accumulates with global atomics (np.linspace edges of that size take the
+    table-free vector kernel); 65536+ edges per dimension are refused with a clear message"""
     rng = np.random.default_rng(97)
     x = rng.standard_normal((2, 300_000)) * 2
     e = np.linspace(-5, 5, 50_001)
+    got, desc = _run(xh, [x], [e], None, True)
+    assert "family=fast" in desc and "scan=5" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x], [e]))
+    e = e.copy()
+    e[777] = np.nextafter(e[777], np.inf)
     got, desc = _run(xh, [x], [e], None, True)
     assert "family=generic" in desc and "hist=global" in desc, desc
     np.testing.assert_array_equal(got, onp.bincount_rows([x], [e]))

@@ -96,6 +96,7 @@ struct xhist_plan {
   //             [0: (start | cnt << 16) uint32 buckets, 1: uint16 start-only buckets on a 2x finer
   //                 grid for the linear-scan kernels (float domains only)]
   TableSet ts[2][2];
+  bool arith = false;  // every dimension has arithmetic (numpy.linspace) edges: table-free digitize available
   int64_t n_bins = 0;
   int cus = 256;
   size_t lds_max = 64 * 1024;
@@ -105,6 +106,7 @@ struct xhist_plan {
   int force_global = 0;
   int force_generic = 0;
   int partition = 0;  // 0 auto, 1 prefer the partitioned mode whenever it is legal, -1 never
+  int arith_pref = 0;  // 0 auto, 1 table-free digitize whenever the edges are arithmetic, -1 never
   int lanes = 0;      // 0 auto, 1 prefer the row-per-lane kernels whenever they are legal, -1 never
   int lds_copies = 0;
   int profile = 0;
@@ -371,6 +373,38 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     delete p;
     return rc;
   }
+  // ---- arithmetic edges: e_j == fl(fl(j * step) + e_0) for every j < nb, step = (e_nb - e_0) / nb ----
+  // (what numpy.linspace / histogram_bin_edges produce for `bins=int`).  Checked edge by edge with the
+  // two roundings kept apart (volatile product: no fma contraction), and only when bins are well
+  // resolved (step >= 4 ulp of the largest magnitude) — the bound count_le_arith's guess relies on.
+  if (cmp_domain == XHIST_CMP_F64) {
+    bool all = true;
+    for (int d = 0; d < n_inputs && all; ++d) {
+      const double* e = static_cast<const double*>(edges[d]);
+      const int nb = (int)n_edges[d] - 1;
+      bool ok = nb >= 1 && std::isfinite(e[0]) && std::isfinite(e[nb]);
+      double step = 0.0;
+      if (ok) {
+        step = (e[nb] - e[0]) / (double)nb;
+        const double mag = std::max(std::max(std::fabs(e[0]), std::fabs(e[nb])), e[nb] - e[0]);
+        const double ulp = std::nextafter(mag, INFINITY) - mag;
+        ok = std::isfinite(step) && step > 0.0 && step >= 4.0 * ulp && std::isfinite(1.0 / step);
+      }
+      for (int j = 0; j < nb && ok; ++j) {
+        volatile double m = (double)j * step;
+        ok = (m + e[0]) == e[j];
+      }
+      if (ok) ok = e[nb] >= e[nb - 1];
+      all = ok;
+      if (ok)
+        for (auto& dom : p->ts[0]) {
+          dom.dim[d].step = step;
+          dom.dim[d].inv_step = 1.0 / step;
+          dom.dim[d].arith = 1;
+        }
+    }
+    p->arith = all;
+  }
   *out_plan = p;
   return XHIST_OK;
 }
@@ -406,6 +440,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lanes")) {
     p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "arith")) {
+    p->arith_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {
     if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
     p->lds_copies = (int)value;
@@ -536,9 +572,27 @@ static kernel_fn fast_pick(int hist) {
   return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
 }
 
+// table-free digitize (arithmetic edges): only the kernels that mode is selected for
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick_arith(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  constexpr int U = unroll_for(D, VEC, kScanArith);
+  if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, kScanArith>;
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, kScanArith>;
+    else return nullptr;
+  }
+  if (hist == kHistGlobal) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, kScanArith>;
+  return nullptr;
+}
+
 template <typename ST, typename WT, int D>
 static kernel_fn fast_pick_s(int scan, int hist) {
   switch (scan) {
+    case kScanArith: return fast_pick_arith<ST, WT, D>(hist);
     case 1: return fast_pick<ST, WT, D, 1>(hist);
     case 2: return fast_pick<ST, WT, D, 2>(hist);
     case 3: return fast_pick<ST, WT, D, 3>(hist);
@@ -697,7 +751,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   else
     k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight, 4>
                         : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double, 4> : (kernel_fn_scatter)part_scatter<float, 4>);
-  const size_t table_bytes = (size_t)tset.words * 8;
+  const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
+  const size_t table_bytes = (size_t)table_words * 8;
   const size_t lds_count = table_bytes + (size_t)(n_parts + 1) * 32 * 4;
   const size_t lds_scatter = part_scatter_lds(n_parts, grp, weighted);
   const size_t lds_acc = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);  // + the trash slot of padding records
@@ -752,7 +807,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   }
   kp.n_dims = D;
   kp.tables = tset.blob;
-  kp.table_words = tset.words;
+  kp.table_words = table_words;
   kp.tables_in_lds = 1;
   kp.n_rows = 1;
   kp.n_cols = n_cols;
@@ -1004,12 +1059,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     return XHIST_OK;
   }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
-    lanes = p->lanes;
+    lanes = p->lanes; arith_pref = p->arith_pref;
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
@@ -1049,6 +1104,32 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   kernel_fn fn = nullptr;
   const int acc_size = weighted ? 8 : 4;
   const int max_cl2 = weighted ? 4 : 5;
+  // histogram placement for a given table footprint:
+  //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
+  //   packed: unweighted vector family only, uint16 counters packed two per word (exact, see kernel)
+  //   global: device-scope atomics straight into the output
+  auto place = [&](size_t tbytes, bool vector_family) {
+    hist = kHistGlobal;
+    cl2 = 0;
+    hist_bytes = 0;
+    if (!force_global && tbytes + 1024 <= lds_cap && p->n_bins < ((int64_t)1 << 24)) {
+      const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
+      cl2 = max_cl2;
+      if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
+      auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
+      if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
+      while (cl2 > 0 && tbytes + bytes_at(cl2) > lds_cap) --cl2;
+      if (tbytes + bytes_at(cl2) <= lds_cap) {
+        hist = kHistLds;
+        hist_bytes = bytes_at(cl2);
+      } else if (vector_family && float_samples && !weighted && tbytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
+        hist = kHistPacked;
+        cl2 = 0;
+        hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+      }
+    }
+    if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
+  };
   for (int attempt = fast_ok ? 0 : 1; attempt < 2 && !fn; ++attempt) {
     fast = attempt == 0;
     // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
@@ -1057,37 +1138,33 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
     if (fast) tset = &pick_tables(p, use_f32, &scan);
     table_bytes = (size_t)tset->words * 8;
-    if (fast && table_bytes + 1024 > lds_cap) continue;  // the vector family keeps its tables in LDS
     tables_fit = table_bytes + 1024 <= lds_cap;
-
-    // ---- histogram placement -----------------------------------------------------------------
-    //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
-    //   packed: unweighted vector family only, uint16 counters packed two per word (exact, see kernel)
-    //   global: device-scope atomics straight into the output
-    hist = kHistGlobal;
-    cl2 = 0;
-    hist_bytes = 0;
-    if (!force_global && tables_fit && p->n_bins < ((int64_t)1 << 24)) {
-      const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
-      cl2 = max_cl2;
-      if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
-      auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
-      if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
-      while (cl2 > 0 && table_bytes + bytes_at(cl2) > lds_cap) --cl2;
-      if (table_bytes + bytes_at(cl2) <= lds_cap) {
-        hist = kHistLds;
-        hist_bytes = bytes_at(cl2);
-      } else if (fast && float_samples && !weighted && table_bytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
-        hist = kHistPacked;
-        cl2 = 0;
-        hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+    if (tables_fit || !fast) place(table_bytes, fast);
+    // Arithmetic edges (bins=int, np.linspace): when the edge tables are what keeps the histogram
+    // out of LDS — or do not fit LDS at all — digitize without tables (count_le_arith): 30000
+    // uniform bins stay on the streaming kernels instead of 43 ms/10^9 samples of global atomics.
+    // Also when the tables fit but only with 3-4 edges per bucket (float32, 20000 bins: 1.17 against 1.39 ms);
+    // with 1-2 edges per bucket the tables win (C2: 2.28 against 2.40 ms, float32 50 bins: 0.69 against 1.12).
+    if (fast && float_samples && p->arith && arith_pref >= 0 &&
+        (!tables_fit || hist == kHistGlobal || scan == 0 || scan >= 3 || arith_pref > 0)) {
+      const int h0 = hist, c0 = cl2;
+      const size_t b0 = hist_bytes;
+      place(0, true);
+      if (hist != kHistGlobal || !tables_fit || arith_pref > 0) {
+        scan = kScanArith;
+        use_f32 = false;
+        tset = &p->ts[0][0];  // float64-domain DimTable (e_0, e_last, step); its tables are not read
+        table_bytes = 0;
+        tables_fit = true;
+      } else {
+        hist = h0; cl2 = c0; hist_bytes = b0;
       }
     }
-    if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
+    if (fast && !tables_fit) continue;  // the vector family keeps its tables in LDS
     lds_hist = hist == kHistLds;
     tables_in_lds = tables_fit;
     lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
-    // (scan > 0: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
+    // (scan 1..4: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
     fn = fast ? fast_kernel(sdt, wdt, D, scan, hist, &vec) : generic_kernel(p->cmp, weighted, lds_hist);
   }
   if (!fn) return fail(XHIST_ERR_HIP, "internal: no kernel for this combination");
@@ -1187,7 +1264,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       kp.row0 = r0;
       kp.n_dims = D;
       kp.tables = tset->blob;
-      kp.table_words = tset->words;
+      kp.table_words = scan == kScanArith ? 0 : tset->words;  // arithmetic edges: nothing to stage
       kp.tables_in_lds = tables_in_lds ? 1 : 0;
       kp.n_rows = nr;
       kp.n_cols = nc;

@@ -49,6 +49,10 @@ struct DimTable {
   int32_t edge_off;     // offset of this dimension's edges in the table blob, in 8-byte words
   int32_t lut_off;      // offset of this dimension's bucket table in the blob, in 4-byte words
   int64_t out_stride;   // stride of this dimension in the flat real-bin index (C order)
+  // arithmetic edges (numpy.linspace: e_j = fl(fl(j * step) + e_0) for j < nb, e_nb given), verified
+  // edge by edge at plan creation: digitize needs no table at all (count_le_scan<.., kScanArith>)
+  double step, inv_step;
+  int32_t arith, pad_;
 };
 
 struct Params {
@@ -194,9 +198,34 @@ __device__ __forceinline__ void digitize_more(typename Dom<CMP>::T x, const DimT
 //     #{e_j <= x} = start + sum_{k < SCAN} [ e[start + k] <= x ]
 // with no count field, no clamping and no data-dependent control flow: SCAN independent LDS
 // reads at immediate offsets, SCAN compares, SCAN add-with-carry.
+constexpr int kScanArith = 5;
+
+// #{e_j <= x} for arithmetic edges, float64 domain, no table.  g = floor((x - e_0) / step) clamped
+// to [0, nb-1] is within one of the answer (plan creation admits only step >= 4 ulp of the largest
+// edge magnitude, so an edge sits within 3/8 of a bin of e_0 + j step and the guess within 1e-8 of
+// (x - e_0) / step); the two edges around the guess are RECOMPUTED with numpy's own two roundings
+// (the empty asm keeps the product from being contracted into an fma) and compared exactly:
+//     count = g + [e_g <= x] + [e_{g+1} <= x]
+// NaN compares false twice and is dropped by the caller's range test.
+__device__ __forceinline__ uint32_t count_le_arith(double x, const DimTable& t) {
+  double tt = (x - t.e0_f) * t.inv_step;
+  tt = fmax(fmin(tt, (double)(t.nb - 1)), 0.0);
+  const double gd = __builtin_floor(tt);
+  double m0 = gd * t.step, m1 = (gd + 1.0) * t.step;
+  asm volatile("" : "+v"(m0), "+v"(m1));
+  const double e_g = m0 + t.e0_f;
+  const uint32_t g = (uint32_t)(int)gd;
+  const double e_g1 = (int)g + 1 == t.nb ? t.eL_f : m1 + t.e0_f;
+  return g + (e_g <= x ? 1u : 0u) + (e_g1 <= x ? 1u : 0u);
+}
+
 template <int CMP, int SCAN, typename TabPtr>
 __device__ __forceinline__ uint32_t count_le_scan(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
   using T = typename Dom<CMP>::T;
+  if constexpr (SCAN == kScanArith) {
+    static_assert(CMP == 0, "arithmetic edges are compared in float64");
+    return count_le_arith(x, t);
+  }
   auto lut = reinterpret_cast<const uint16_t*>(tab) + t.lut_off;  // start-only table, 2-byte entries
   const uint32_t start = lut[bucket_of<CMP>(x, t)];
   const T* e = reinterpret_cast<const T*>(tab + t.edge_off) + start;
@@ -350,7 +379,8 @@ constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
-  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
+  constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
   // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
   // integer samples: zero, masked by the past_end bit

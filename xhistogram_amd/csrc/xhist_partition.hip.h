@@ -38,7 +38,7 @@ constexpr int kPartBlock = 1024, kPartTile = 8192;
 template <typename ST, int D, int VEC, int SCAN>
 __global__ void __launch_bounds__(kPartBlock) part_count(const Params p, uint32_t* __restrict__ flat_out) {
   constexpr int UNROLL = kPartTile / kPartBlock / VEC;
-  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
   using svec = typename VecOf<ST, VEC>::type;
   using fvec = typename VecOf<uint32_t, VEC>::type;
