@@ -67,7 +67,7 @@ def test_argument_validation_before_any_device_work(lib):
     nan = np.array([0.0, np.nan, 1.0])
     ptrs = (C.c_void_p * 1)(nan.ctypes.data)
     assert lib.xhist_plan_create(0, 1, ptrs, lens, 0, C.byref(h)) == _native.ERR_EDGES
-    big = (C.c_int64 * 1)(70000)
+    big = (C.c_int64 * 1)((1 << 30) + 1)  # refused before any edge is read
     assert lib.xhist_plan_create(0, 1, ptrs, big, 0, C.byref(h)) == _native.ERR_UNSUPPORTED
     assert lib.xhist_plan_destroy(None) == 0
     with pytest.raises(ValueError):

@@ -978,5 +978,35 @@ def test_tables_too_large_for_lds_are_read_through_l2(xh):
     np.testing.assert_array_equal(got, onp.bincount_rows([x], [e]))
     w = rng.uniform(0, 1, x.shape)
     assert_hist_equal(_run(xh, [x], [e], w, False)[0], onp.bincount_rows([x], [e], w), True)
-    with pytest.raises(NotImplementedError, match="65535"):
-        _run(xh, [x], [np.linspace(-5, 5, 70_000)], None, True)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_more_than_65535_edges_per_dimension(xh, weighted):
+    """no 16-bit table fields any more: arithmetic edges run table-free on the vector kernels
+    (global atomics below 4 M samples, the partitioned mode when forced), anything else binary-searches
+    the whole edge array in the generic family"""
+    rng = np.random.default_rng(98)
+    e = np.linspace(-5, 5, 100_001)
+    x = np.concatenate([rng.standard_normal((1, 200_000)) * 2, e[None, ::7], np.nextafter(e, -np.inf)[None, ::11],
+                        np.array([[np.nan, np.inf, -np.inf, -5.0, 5.0]])], axis=1)
+    w = rng.uniform(0, 1, x.shape) if weighted else None
+    want = onp.bincount_rows([x], [e], w)
+    got, desc = _run(xh, [x], [e], w, True)
+    assert "family=fast" in desc and "scan=5" in desc and "hist=global" in desc, desc
+    assert_hist_equal(got, want, weighted)
+    got, desc = _run(xh, [x], [e], w, True, partition=1)
+    assert "hist=partitioned" in desc and "scan=5" in desc, desc
+    assert_hist_equal(got, want, weighted)
+    assert_hist_equal(_run(xh, [x], [e], w, False)[0], want, weighted)  # host route
+    # not arithmetic: generic family, binary search over 70001 edges read through L2
+    e2 = np.sort(rng.uniform(-5, 5, 70_001))
+    x2 = np.concatenate([rng.standard_normal((3, 20_000)) * 2, np.tile(e2[None, ::4][:, :5000], (3, 1))], axis=1)
+    w2 = rng.uniform(0, 1, x2.shape) if weighted else None
+    got, desc = _run(xh, [x2], [e2], w2, True)
+    assert "family=generic" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([x2], [e2], w2), weighted)
+    # two inputs, one of them with a huge edge array
+    e3 = [np.linspace(0, 1, 4), e2]
+    y2 = rng.uniform(-0.1, 1.1, x2.shape)
+    got, desc = _run(xh, [y2, x2], e3, w2, True)
+    assert_hist_equal(got, onp.bincount_rows([y2, x2], e3, w2), weighted)

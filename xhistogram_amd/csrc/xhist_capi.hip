@@ -96,6 +96,7 @@ struct xhist_plan {
   //             [0: (start | cnt << 16) uint32 buckets, 1: uint16 start-only buckets on a 2x finer
   //                 grid for the linear-scan kernels (float domains only)]
   TableSet ts[2][2];
+  bool huge = false;   // some dimension has more than 65535 edges: no bucket tables (lut_k = 0)
   bool arith = false;  // every dimension has arithmetic (numpy.linspace) edges: table-free digitize available
   int64_t n_bins = 0;
   int cus = 256;
@@ -186,21 +187,26 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
       t.eL_f = (double)last;
       range = (double)((float)t.eL_f - (float)t.e0_f);
     }
-    int K = std::min(4096, std::max(8, next_pow2(4 * E)));
+    int K = std::min(4096, std::max(8, next_pow2((int)std::min<int64_t>(4 * (int64_t)E, 1 << 20))));
     if (lut16) K *= 2;  // 2-byte entries: twice the buckets for the same LDS bytes
+    // more than 65535 edges: `start` no longer fits the 16-bit table fields — no bucket table at
+    // all (lut_k = 0): digitize is a plain binary search over the edge array (generic family), or
+    // table-free when the edges are arithmetic
+    const bool no_lut = E > 65535;
     double scale = (double)K / range;
     if (dom == 2) scale = (double)(float)scale;
     if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
       K = 1;  // degenerate span: one bucket holding every edge, pure binary search
       scale = 0.0;
     }
+    if (no_lut) { K = 0; scale = 0.0; }
     t.lut_k = K;
     t.scale = scale;
     if (dom == 2) t.bias = (double)(-(float)t.e0_f * (float)scale);
     else if (dom == 0) t.bias = -t.e0_f * scale;
     if (!std::isfinite(t.bias)) {  // e.g. e_0 = -inf with scale 0: keep the map defined (bucket 0)
       t.bias = 0.0;
-      if (K != 1) { K = 1; t.lut_k = 1; t.scale = 0.0; }
+      if (K > 1) { K = 1; t.lut_k = 1; t.scale = 0.0; }
     }
   }
   int64_t stride = 1;
@@ -235,6 +241,7 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
   HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
   HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
   for (int d = 0; d < n_inputs; ++d) {
+    if (dims[d].lut_k == 0) continue;
     if (dom == 0 && !lut16) hipLaunchKernelGGL((build_tables<0, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
     else if (dom == 0) hipLaunchKernelGGL((build_tables<0, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
     else if (dom == 1) hipLaunchKernelGGL((build_tables<1, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
@@ -251,6 +258,7 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
     DimTable& t = dims[d];
     uint32_t maxcnt = 0;
     uint64_t total = 0;
+    if (t.lut_k == 0) { maxcnt = (uint32_t)t.n_edges; total = (uint64_t)t.n_edges; }
     for (int b = 0; b < t.lut_k; ++b) {
       uint32_t cnt;
       if (lut16) {
@@ -287,8 +295,8 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   for (int d = 0; d < n_inputs; ++d) {
     if (!edges[d]) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL", d);
     if (n_edges[d] < 1) return fail(XHIST_ERR_INVALID, "edges[%d] needs at least one edge", d);
-    if (n_edges[d] > 65535)
-      return fail(XHIST_ERR_UNSUPPORTED, "edges[%d] has %lld edges; this build supports at most 65535 per dimension", d,
+    if (n_edges[d] > ((int64_t)1 << 30))
+      return fail(XHIST_ERR_UNSUPPORTED, "edges[%d] has %lld edges; this build supports at most 2^30 per dimension", d,
                   (long long)n_edges[d]);
     max_e = std::max(max_e, n_edges[d]);
     if (cmp_domain == XHIST_CMP_F64) {
@@ -347,9 +355,13 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   const uint64_t kNaN64 = 0x7ff8000000000000ull;
   for (int d = 0; d < n_inputs; ++d)
     for (int k = 0; k < 4; ++k) words[d].push_back(cmp_domain == XHIST_CMP_F64 ? kNaN64 : 0x7fffffffffffffffull);
+  // more than 65535 edges in some dimension: only the native set, without bucket tables (the vector
+  // family then runs table-free on arithmetic edges, everything else takes the generic family)
+  p->huge = max_e > 65535;
+  const bool vector_sets = cmp_domain == XHIST_CMP_F64 && !p->huge;
   int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0]);
-  if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
-  if (rc == XHIST_OK && cmp_domain == XHIST_CMP_F64) {
+  if (rc == XHIST_OK && vector_sets) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
+  if (rc == XHIST_OK && vector_sets) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
     for (int d = 0; d < n_inputs; ++d) {
       const int E = (int)n_edges[d];
@@ -859,7 +871,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
                          void* out, int accumulate, hipStream_t stream, bool prefer, int profile) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
-  if (p->cmp != XHIST_CMP_F64 || D > 3 || n_cols >= ((int64_t)1 << 31) || p->n_bins >= (1 << 16)) return XHIST_ERR_UNSUPPORTED;
+  if (p->cmp != XHIST_CMP_F64 || D > 3 || n_cols >= ((int64_t)1 << 31) || p->n_bins >= (1 << 16) || p->huge) return XHIST_ERR_UNSUPPORTED;
   const int sdt = samples[0].dtype, wdt = weighted ? weights->dtype : -1;
   if ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)) return XHIST_ERR_UNSUPPORTED;
   // shape class of every array: natural (row stride 0/1, any column stride) or needs a transpose
@@ -1138,7 +1150,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
     if (fast) tset = &pick_tables(p, use_f32, &scan);
     table_bytes = (size_t)tset->words * 8;
-    tables_fit = table_bytes + 1024 <= lds_cap;
+    tables_fit = table_bytes + 1024 <= lds_cap && !(fast && p->huge);  // no bucket tables: not for the vector family
     if (tables_fit || !fast) place(table_bytes, fast);
     // Arithmetic edges (bins=int, np.linspace): when the edge tables are what keeps the histogram
     // out of LDS — or do not fit LDS at all — digitize without tables (count_le_arith): 30000

@@ -178,9 +178,14 @@ __device__ __forceinline__ DigState digitize_begin(typename Dom<CMP>::T x, const
   auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
   DigState s;
   s.ok = Dom<CMP>::in_range(x, t);
-  const uint32_t ent = lut[bucket_of<CMP>(x, t)];
-  s.lo = ent & 0xffffu;  // edges below x's bucket: certainly <= x
-  s.len = ent >> 16;     // edges sharing the bucket: compared explicitly
+  if (t.lut_k == 0) {  // more than 65535 edges: no bucket table, binary search over all of them
+    s.lo = 0u;
+    s.len = (uint32_t)t.n_edges;
+  } else {
+    const uint32_t ent = lut[bucket_of<CMP>(x, t)];
+    s.lo = ent & 0xffffu;  // edges below x's bucket: certainly <= x
+    s.len = ent >> 16;     // edges sharing the bucket: compared explicitly
+  }
   upper_bound_step<CMP>(x, t, tab, s);
   return s;
 }
