@@ -113,8 +113,10 @@ def build_workload(cfg, args, torch, dev, rank):
     w = torch.empty(n, dtype=f64, device=dev).uniform_(generator=g)
     return dict(
         arrays=[x, y], weights=w, edges=[np.linspace(-4.0, 4.0, 1025)] * 2, rows=1, cols=n, reduce="allreduce",
-        metric="samples/s binned (2 x f64 + f64 weights), 2D 1024x1024 bins, 5*10^8 samples per GPU",
-        workload="C5: 2-D weighted histogram, %d samples per GPU (4*10^9 over 8), 1024x1024 uniform bins (beyond LDS: partitioned multi-pass)" % n,
+        density=True,
+        metric="samples/s binned (2 x f64 + f64 weights), 2D weighted density, 1024x1024 bins, 5*10^8 samples per GPU",
+        workload="C5: 2-D weighted density histogram, %d samples per GPU (4*10^9 over 8), 1024x1024 uniform bins (beyond LDS: "
+                 "partitioned multi-pass); density epilogue (core.py:444-462) on the reduced result of every step" % n,
         dtype="f64", data="synthetic (two N(0,1) arrays + U[0,1) weights, generated on device)")
 
 
@@ -156,24 +158,32 @@ def main():
     xv = [_native.make_view(a.data_ptr(), tag[a.dtype], n_cols, 1) for a in arrays]
     wv = _native.make_view(w.data_ptr(), tag[w.dtype], n_cols, 1) if weighted else None
     reduce_partials = use_dist and wl["reduce"] == "allreduce"
+    density = bool(wl.get("density"))
+    dens = [None]
     counter = [0]
+
+    def finish(k):
+        """what follows a step's kernel once its all-reduce is done: the density epilogue (C5)"""
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+            if density:
+                dens[0] = core._density(outs[k], edges, len(edges))
 
     def step():
         k = counter[0] & 1
         counter[0] += 1
-        if pending[k] is not None:  # the reduction that last used this buffer must be done
-            pending[k].wait()
-            pending[k] = None
+        finish(k)  # the reduction that last used this buffer must be done
         out = outs[k]
         plan.execute(xv, wv, n_rows, n_cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False, stream=stream)
         if reduce_partials:
             pending[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
+        elif density:
+            dens[0] = core._density(out, edges, len(edges))
 
     def fence():
         for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+            finish(k)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)

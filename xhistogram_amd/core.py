@@ -510,15 +510,19 @@ def _density(counts, bins, n_inputs):
     ``np.prod(np.ix_(...))`` for three or more inputs (core.py:454) fails on numpy >= 1.24, the
     outer product is what it was meant to compute (and what np.histogramdd does)."""
     widths = [np.diff(b) for b in bins]
+    bin_axes = tuple(_range(-n_inputs, 0))
+    if _is_torch(counts):
+        # the outer product is formed on the device (same float64 products): only the widths travel
+        torch = _torch()
+        areas_t = None
+        for w in widths:
+            wt = torch.as_tensor(np.asarray(w, dtype=np.float64), device=counts.device)
+            areas_t = wt if areas_t is None else areas_t[..., None] * wt
+        sums = counts.sum(dim=bin_axes, keepdim=True)
+        return counts / areas_t / sums
     areas = widths[0]
     for w in widths[1:]:
         areas = np.multiply.outer(areas, w)
-    bin_axes = tuple(_range(-n_inputs, 0))
-    if _is_torch(counts):
-        torch = _torch()
-        areas_t = torch.as_tensor(np.asarray(areas, dtype=np.float64), device=counts.device)
-        sums = counts.sum(dim=bin_axes, keepdim=True)
-        return counts / areas_t / sums
     if _is_dask(counts):
         sums = counts.sum(axis=bin_axes)
         return counts / areas / sums.reshape(sums.shape + n_inputs * (1,))
