@@ -1,0 +1,609 @@
+// xhist_exec_device.hip.h — host side: execution on device-resident arrays — partitioned mode, row-per-lane mode, streaming kernels
+// Part of the single translation unit xhist_capi.hip (included there, in order).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// device-resident execute
+// ------------------------------------------------------------------------------------------
+static int validate_arrays(const xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
+                           int64_t n_cols, const void* out, int out_dtype) {
+  if (!p) return fail(XHIST_ERR_INVALID, "plan is NULL");
+  if (!samples) return fail(XHIST_ERR_INVALID, "samples is NULL");
+  if (n_rows < 0 || n_cols < 0) return fail(XHIST_ERR_INVALID, "negative shape");
+  const bool empty = n_rows == 0 || n_cols == 0;
+  for (int d = 0; d < p->n_dims; ++d) {
+    if (!empty && !samples[d].data) return fail(XHIST_ERR_INVALID, "samples[%d].data is NULL", d);
+    if (!dtype_size(samples[d].dtype)) return fail(XHIST_ERR_INVALID, "samples[%d] has unknown dtype tag %d", d, samples[d].dtype);
+    if (samples[d].row_stride < 0 || samples[d].col_stride < 0 || samples[d].inner_rows < 0 || samples[d].outer_stride < 0)
+      return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
+    if (p->cmp == XHIST_CMP_I64 && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
+      return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", samples[d].dtype);
+  }
+  if (weights) {
+    if (!empty && !weights->data) return fail(XHIST_ERR_INVALID, "weights.data is NULL");
+    if (!dtype_size(weights->dtype)) return fail(XHIST_ERR_INVALID, "weights has unknown dtype tag %d", weights->dtype);
+    if (weights->row_stride < 0 || weights->col_stride < 0 || weights->inner_rows < 0 || weights->outer_stride < 0)
+      return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
+    if (out_dtype != XHIST_F64) return fail(XHIST_ERR_INVALID, "weighted histograms are float64 (out_dtype XHIST_F64)");
+  } else if (out_dtype != XHIST_I64) {
+    return fail(XHIST_ERR_INVALID, "unweighted histograms are int64 (out_dtype XHIST_I64)");
+  }
+  if (!out && n_rows * p->n_bins > 0) return fail(XHIST_ERR_INVALID, "out is NULL");
+  return XHIST_OK;
+}
+
+// zero n 8-byte output words on `stream` (see zero_words)
+static int zero_output(void* out, int64_t n_words, hipStream_t stream) {
+  if (n_words <= 0) return XHIST_OK;
+  const int grid = (int)std::min<int64_t>(2048, (n_words + 255) / 256);
+  hipLaunchKernelGGL(zero_words, dim3(grid), dim3(256), 0, stream, static_cast<unsigned long long*>(out), n_words);
+  HIPC(hipGetLastError());
+  return XHIST_OK;
+}
+
+static const void* advance(const void* base, int dt, int64_t elems) {
+  return static_cast<const char*>(base) + elems * dtype_size(dt);
+}
+
+// Partitioned mode (xhist_partition.hip.h): count -> prefix -> scatter -> accumulate, all on
+// `stream`, scratch from the stream-ordered allocator (so concurrent callers never share it).
+static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
+                               hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
+                               int n_parts, int profile) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  if (n_cols >= ((int64_t)1 << 40)) return XHIST_ERR_UNSUPPORTED;
+  int vec = 1;
+  kernel_fn_count k_count = (kernel_fn_count)fast_kernel(sdt, wdt, D, scan, kHistPartCount, &vec);
+  if (!k_count) return XHIST_ERR_UNSUPPORTED;
+  // records leave part_scatter in aligned groups: 8 (one 16-byte code store) while the carried
+  // records of all partitions fit LDS next to the tile, else 4
+  const int grp = n_parts <= 128 ? 8 : 4;
+  kernel_fn_scatter k_scatter;
+  if (grp == 8)
+    k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight, 8>
+                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double, 8> : (kernel_fn_scatter)part_scatter<float, 8>);
+  else
+    k_scatter = wdt < 0 ? (kernel_fn_scatter)part_scatter<NoWeight, 4>
+                        : (wdt == XHIST_F64 ? (kernel_fn_scatter)part_scatter<double, 4> : (kernel_fn_scatter)part_scatter<float, 4>);
+  const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
+  const size_t table_bytes = (size_t)table_words * 8;
+  const size_t lds_count = table_bytes + (size_t)(n_parts + 1) * 32 * 4;
+  const size_t lds_scatter = part_scatter_lds(n_parts, grp, weighted);
+  const size_t lds_acc = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);  // + the trash slot of padding records
+  if (lds_count > p->lds_max || lds_scatter > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  const int per_cu = std::max<int>(1, std::min<int>(4, (int)(160 * 1024 / std::max(lds_count, lds_scatter))));
+  const int64_t n_tiles = (n_cols + kPartTile - 1) / kPartTile;
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
+  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_cols + 65535) / 65536));
+
+  uint32_t* d_counts = nullptr;
+  uint64_t *d_base = nullptr, *d_offsets = nullptr;
+  uint16_t* d_codes = nullptr;
+  double* d_w = nullptr;
+  uint32_t* d_flat = nullptr;
+  auto release = [&](int rc) {
+    if (d_flat) (void)hipFreeAsync(d_flat, stream);
+    if (d_counts) (void)hipFreeAsync(d_counts, stream);
+    if (d_base) (void)hipFreeAsync(d_base, stream);
+    if (d_offsets) (void)hipFreeAsync(d_offsets, stream);
+    if (d_codes) (void)hipFreeAsync(d_codes, stream);
+    if (d_w) (void)hipFreeAsync(d_w, stream);
+    return rc;
+  };
+#define HIPR(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  HIPR(hipMallocAsync((void**)&d_counts, (size_t)G * n_parts * 4, stream));
+  HIPR(hipMallocAsync((void**)&d_base, (size_t)G * n_parts * 8, stream));
+  HIPR(hipMallocAsync((void**)&d_offsets, (size_t)(n_parts + 1) * 8, stream));
+  HIPR(hipMallocAsync((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
+  const size_t n_rec = (size_t)n_cols + (size_t)G * n_parts * grp;  // every slice rounded up to whole groups
+  HIPR(hipMallocAsync((void**)&d_codes, n_rec * 2 + 16, stream));
+  if (weighted) HIPR(hipMallocAsync((void**)&d_w, n_rec * 8 + 16, stream));
+
+  Params kp;
+  memset(&kp, 0, sizeof kp);
+  const DimTable* dims = tset.dim;
+  for (int d = 0; d < D; ++d) {
+    kp.s_ptr[d] = samples[d].data;
+    kp.s_rs[d] = samples[d].row_stride;
+    kp.s_cs[d] = 1;
+    kp.s_dt[d] = samples[d].dtype;
+    kp.dim[d] = dims[d];
+  }
+  if (weighted) {
+    kp.w_ptr = weights->data;
+    kp.w_rs = weights->row_stride;
+    kp.w_cs = 1;
+    kp.w_dt = weights->dtype;
+  }
+  kp.n_dims = D;
+  kp.tables = tset.blob;
+  kp.table_words = table_words;
+  kp.tables_in_lds = 1;
+  kp.n_rows = 1;
+  kp.n_cols = n_cols;
+  kp.n_bins = p->n_bins;
+  kp.out = out;
+  kp.segs = G;
+  kp.part_counts = d_counts;
+  kp.part_base = d_base;
+  kp.part_codes = d_codes;
+  kp.part_w = d_w;
+  kp.part_shift = shift;
+  kp.n_parts = n_parts;
+
+  if (lds_count > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+  if (lds_scatter > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
+  kernel_fn_acc k_acc = weighted ? (kernel_fn_acc)part_accumulate<true> : (kernel_fn_acc)part_accumulate<false>;
+  if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+
+  LaunchRecord rec(p, stream);
+  if (int rrc = rec.begin(profile)) return release(rrc);
+  hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, grp, d_offsets, d_base);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
+                     weighted ? weights->data : nullptr, n_cols, (const uint64_t*)d_base, d_codes, d_w, shift, n_parts);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const double*)d_w,
+                     (const uint64_t*)d_offsets, out, p->n_bins, shift, n_parts);
+  HIPR(hipGetLastError());
+  {
+    char desc[384];
+    snprintf(desc, sizeof desc,
+             "family=fast hist=partitioned parts=%d bins_per_part=%d group=%d vec=%d tile=%d block=%d grid=%d acc_grid=%d "
+             "lds_count=%zu lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
+             n_parts, 1 << shift, grp, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
+             use_f32 ? "f32thr" : "f64");
+    if (int rrc = rec.end(desc)) return release(rrc);
+  }
+#undef HIPR
+  return release(XHIST_OK);
+}
+
+// Row-per-lane mode (xhist_lanes.hip.h).  Takes (a) views whose ROWS are the contiguous direction
+// (row stride 1: reductions over leading axes) as they are, and (b) many short contiguous rows
+// after transposing them into a [cols, rows] scratch.  Returns XHIST_ERR_UNSUPPORTED when the
+// shape is better served by the row-streaming kernels.
+static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows, int64_t n_cols,
+                         void* out, int accumulate, hipStream_t stream, bool prefer, int profile) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  if (p->cmp != XHIST_CMP_F64 || D > 3 || n_cols >= ((int64_t)1 << 31) || p->n_bins >= (1 << 16) || p->huge) return XHIST_ERR_UNSUPPORTED;
+  const int sdt = samples[0].dtype, wdt = weighted ? weights->dtype : -1;
+  if ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)) return XHIST_ERR_UNSUPPORTED;
+  // shape class of every array: natural (row stride 0/1, any column stride) or needs a transpose
+  // (unit column stride, dense-ish rows)
+  bool all_natural = true, all_rowmajor = true, grouped_any = false;
+  for (int d = 0; d <= D; ++d) {
+    if (d == D && !weighted) break;
+    const xhist_array& a = d < D ? samples[d] : *weights;
+    if (d < D && a.dtype != sdt) return XHIST_ERR_UNSUPPORTED;
+    const bool bcast = a.row_stride == 0 || a.col_stride == 0;
+    const bool natural = bcast || (a.row_stride == 1 && (a.inner_rows ? a.col_stride >= 1 : a.col_stride >= n_rows));
+    const bool rowmajor = bcast || (a.col_stride == 1 && a.row_stride >= n_cols);
+    grouped_any |= a.inner_rows != 0 && !bcast;
+    all_natural &= natural;
+    all_rowmajor &= rowmajor;
+  }
+  const bool use_f32 = sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+  int scan = 0;
+  const TableSet& tset = pick_tables(p, use_f32, &scan);
+  const size_t table_bytes = (size_t)tset.words * 8;
+  const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
+  if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  bool transpose = false;
+  if (all_natural && (samples[0].row_stride == 1 || prefer)) {
+    // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
+  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 896 : 384)))) {
+    // many short rows.  Measured crossovers with the row-streaming kernels at 64-thread workgroups
+    // (profiles/r01_f_shapes.jsonl): ~900 columns for the fused kernel (one unweighted input),
+    // ~400 for scratch-transpose + lanes
+    transpose = true;
+  } else {
+    return XHIST_ERR_UNSUPPORTED;
+  }
+
+  int vec = 1;
+  kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes, &vec);
+  if (!fn) return XHIST_ERR_UNSUPPORTED;
+
+  const bool fused_ok = D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0;
+  if (transpose && grouped_any && !fused_ok) return XHIST_ERR_UNSUPPORTED;  // transpose_2d takes plain row strides only
+  // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
+  if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {
+    const int es = dtype_size(sdt);
+    const size_t hist_bytes = (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
+    const size_t lds_f = ((table_bytes + hist_bytes + 15) & ~(size_t)15) + (size_t)kLaneBlock * (128 / es + 1) * es;
+    kernel_fn_rows1 f1 = rows1_kernel(sdt, scan);
+    if (f1 && lds_f <= p->lds_max) {
+      Params kp;
+      memset(&kp, 0, sizeof kp);
+      kp.s_ptr[0] = samples[0].data;
+      kp.s_rs[0] = samples[0].row_stride;
+      kp.s_cs[0] = 1;
+      kp.s_ir[0] = samples[0].inner_rows;
+      kp.s_os[0] = samples[0].outer_stride;
+      kp.s_dt[0] = sdt;
+      kp.dim[0] = tset.dim[0];
+      kp.n_dims = 1;
+      kp.tables = tset.blob;
+      kp.table_words = tset.words;
+      kp.tables_in_lds = 1;
+      kp.n_rows = n_rows;
+      kp.n_cols = n_cols;
+      kp.n_bins = p->n_bins;
+      kp.out = out;
+      const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
+      if (row_blocks > 2147483647LL) return XHIST_ERR_UNSUPPORTED;
+      const int direct = accumulate ? 0 : 1;
+      LaunchRecord rec(p, stream);
+      if (int rrc = rec.begin(profile)) return rrc;
+      if (lds_f > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      hipLaunchKernelGGL(f1, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_f, stream, kp, (int32_t)direct);
+      HIPC(hipGetLastError());
+      char desc[384];
+      snprintf(desc, sizeof desc,
+               "family=lanes hist=lds16 transpose=fused direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=0 D=1 cmp=%s",
+               direct, kLaneBlock, (long long)row_blocks, lds_f, scan, use_f32 ? "f32thr" : "f64");
+      return rec.end(desc);
+    }
+  }
+
+  void* scratch[kMaxDims + 1] = {nullptr};
+  auto release = [&](int rc) {
+    for (auto s : scratch)
+      if (s) (void)hipFreeAsync(s, stream);
+    return rc;
+  };
+#define HIPL(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+
+  Params kp;
+  memset(&kp, 0, sizeof kp);
+  const DimTable* dims = tset.dim;
+  LaunchRecord rec(p, stream);
+  if (int rrc = rec.begin(profile)) return release(rrc);
+  for (int d = 0; d <= D; ++d) {
+    if (d == D && !weighted) break;
+    const xhist_array& a = d < D ? samples[d] : *weights;
+    const void* ptr = a.data;
+    int64_t rs = a.row_stride, cs = a.col_stride, ir = a.inner_rows, os = a.outer_stride;
+    if (transpose && rs != 0 && cs != 0) {
+      ir = os = 0;
+      const int es = dtype_size(a.dtype);
+      HIPL(hipMallocAsync(&scratch[d], (size_t)n_rows * n_cols * es, stream));
+      const dim3 grid((unsigned)((n_rows + 63) / 64), (unsigned)((n_cols + 63) / 64));
+      if (es == 8)
+        hipLaunchKernelGGL(transpose_2d<double>, grid, dim3(256), 0, stream, (const double*)a.data, rs, n_rows, n_cols, (double*)scratch[d]);
+      else
+        hipLaunchKernelGGL(transpose_2d<float>, grid, dim3(256), 0, stream, (const float*)a.data, rs, n_rows, n_cols, (float*)scratch[d]);
+      HIPL(hipGetLastError());
+      ptr = scratch[d];
+      rs = 1;
+      cs = n_rows;
+    }
+    if (d < D) {
+      kp.s_ptr[d] = ptr;
+      kp.s_rs[d] = rs;
+      kp.s_cs[d] = cs;
+      kp.s_ir[d] = ir;
+      kp.s_os[d] = os;
+      kp.s_dt[d] = a.dtype;
+      kp.dim[d] = dims[d];
+    } else {
+      kp.w_ptr = ptr;
+      kp.w_rs = rs;
+      kp.w_cs = cs;
+      kp.w_ir = ir;
+      kp.w_os = os;
+      kp.w_dt = a.dtype;
+    }
+  }
+  kp.n_dims = D;
+  kp.tables = tset.blob;
+  kp.table_words = tset.words;
+  kp.tables_in_lds = 1;
+  kp.n_rows = n_rows;
+  kp.n_cols = n_cols;
+  kp.n_bins = p->n_bins;
+  kp.out = out;
+
+  const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
+  // unweighted and few enough columns per workgroup: uint16 counters, half the LDS
+  size_t lds_use = lds_bytes;
+  bool packed16 = false;
+  if (!weighted) {
+    const size_t lds16 = table_bytes + (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
+    const int bpc16 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds16));
+    int64_t segs16 = std::max<int64_t>(1, ((int64_t)p->cus * bpc16 * 2 + row_blocks - 1) / row_blocks);
+    segs16 = std::min<int64_t>(std::min<int64_t>(segs16, std::max<int64_t>(1, n_cols / 64)), 65535);
+    if ((n_cols + segs16 - 1) / segs16 <= 65535) {
+      kernel_fn_lanes f16 = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes16, &vec);
+      if (f16) {
+        fn = f16;
+        packed16 = true;
+        lds_use = lds16;
+      }
+    }
+  }
+  const int bpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds_use));
+  int64_t col_segs = std::max<int64_t>(1, ((int64_t)p->cus * bpc * 2 + row_blocks - 1) / row_blocks);
+  col_segs = std::min<int64_t>(col_segs, std::max<int64_t>(1, n_cols / 64));
+  col_segs = std::min<int64_t>(col_segs, 65535);
+  const int64_t cols_per_seg = (n_cols + col_segs - 1) / col_segs;
+  col_segs = (n_cols + cols_per_seg - 1) / cols_per_seg;
+  const int direct = (col_segs == 1 && !accumulate) ? 1 : 0;
+  if (!direct && !accumulate)
+    if (int zrc = zero_output(out, n_rows * p->n_bins, stream)) return release(zrc);
+  if (row_blocks > 2147483647LL) return release(XHIST_ERR_UNSUPPORTED);
+  if (lds_use > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use));
+  hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_use, stream, kp, (int32_t)direct,
+                     cols_per_seg);
+  HIPL(hipGetLastError());
+  {
+    char desc[384];
+    snprintf(desc, sizeof desc,
+             "family=lanes hist=%s transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
+             packed16 ? "lds16" : "lds", (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_use, scan,
+             (int)weighted, D,
+             use_f32 ? "f32thr" : "f64");
+    if (int rrc = rec.end(desc)) return release(rrc);
+  }
+#undef HIPL
+  return release(XHIST_OK);
+}
+
+static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
+                          int64_t n_cols, void* out, int accumulate, hipStream_t stream) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  const int64_t out_elems = n_rows * p->n_bins;
+  if (out_elems == 0) return XHIST_OK;
+  if (n_cols == 0) {
+    if (!accumulate)
+      if (int zrc = zero_output(out, out_elems, stream)) return zrc;
+    return XHIST_OK;
+  }
+
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
+    force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
+    lanes = p->lanes; arith_pref = p->arith_pref;
+  }
+
+  // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
+  if (lanes >= 0 && !force_generic && !force_global) {
+    const int rc = execute_lanes(p, samples, weights, n_rows, n_cols, out, accumulate, stream, lanes > 0, profile);
+    if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = not this shape, fall through
+  }
+  if (!accumulate)
+    if (int zrc = zero_output(out, out_elems, stream)) return zrc;
+
+  // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
+  const size_t lds_cap = p->lds_max;
+  const int sdt = samples[0].dtype;
+  const int wdt = weighted ? weights->dtype : -1;
+  int vec = 1;
+  const bool float_samples = sdt == XHIST_F64 || sdt == XHIST_F32;
+  const bool small_samples = sdt == XHIST_I32 || sdt == XHIST_I64 || sdt == XHIST_I16 || sdt == XHIST_U8 || sdt == XHIST_F16;
+  bool fast_ok = !force_generic && p->cmp == XHIST_CMP_F64 && p->n_bins < ((int64_t)1 << 31) &&
+                 ((float_samples && D <= 3 && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32)) ||
+                  (small_samples && D == 1 && (wdt == -1 || wdt == XHIST_F64)));
+  if (fast_ok) {
+    // unit column stride is all the vector family needs: gfx950 vector loads take any
+    // element-aligned address (rows of 365 or 3650 samples stay on 16-byte loads)
+    for (int d = 0; d < D && fast_ok; ++d) {
+      const xhist_array& a = samples[d];
+      fast_ok = a.dtype == sdt && a.col_stride == 1 && ((uintptr_t)a.data % (size_t)dtype_size(sdt) == 0);
+    }
+    if (fast_ok && weighted) fast_ok = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
+  }
+
+  // Two attempts: the vector family with its tables, then (if it has no kernel for this
+  // combination, or its tables do not fit LDS) the generic family with the native tables.
+  bool fast = false, use_f32 = false, tables_fit = false, lds_hist = false, tables_in_lds = false;
+  int scan = 0, hist = kHistGlobal, cl2 = 0;
+  const TableSet* tset = nullptr;
+  size_t table_bytes = 0, hist_bytes = 0, lds_bytes = 0;
+  kernel_fn fn = nullptr;
+  const int acc_size = weighted ? 8 : 4;
+  const int max_cl2 = weighted ? 4 : 5;
+  // histogram placement for a given table footprint:
+  //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
+  //   packed: unweighted vector family only, uint16 counters packed two per word (exact, see kernel)
+  //   global: device-scope atomics straight into the output
+  auto place = [&](size_t tbytes, bool vector_family) {
+    hist = kHistGlobal;
+    cl2 = 0;
+    hist_bytes = 0;
+    if (!force_global && tbytes + 1024 <= lds_cap && p->n_bins < ((int64_t)1 << 24)) {
+      const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
+      cl2 = max_cl2;
+      if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
+      auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
+      if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
+      while (cl2 > 0 && tbytes + bytes_at(cl2) > lds_cap) --cl2;
+      if (tbytes + bytes_at(cl2) <= lds_cap) {
+        hist = kHistLds;
+        hist_bytes = bytes_at(cl2);
+      } else if (vector_family && float_samples && !weighted && tbytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
+        hist = kHistPacked;
+        cl2 = 0;
+        hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+      }
+    }
+    if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
+  };
+  for (int attempt = fast_ok ? 0 : 1; attempt < 2 && !fn; ++attempt) {
+    fast = attempt == 0;
+    // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
+    use_f32 = fast && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+    scan = 0;
+    tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
+    if (fast) tset = &pick_tables(p, use_f32, &scan);
+    table_bytes = (size_t)tset->words * 8;
+    tables_fit = table_bytes + 1024 <= lds_cap && !(fast && p->huge);  // no bucket tables: not for the vector family
+    if (tables_fit || !fast) place(table_bytes, fast);
+    // Arithmetic edges (bins=int, np.linspace): when the edge tables are what keeps the histogram
+    // out of LDS — or do not fit LDS at all — digitize without tables (count_le_arith): 30000
+    // uniform bins stay on the streaming kernels instead of 43 ms/10^9 samples of global atomics.
+    // Also when the tables fit but only with 3-4 edges per bucket (float32, 20000 bins: 1.17 against 1.39 ms);
+    // with 1-2 edges per bucket the tables win (C2: 2.28 against 2.40 ms, float32 50 bins: 0.69 against 1.12).
+    if (fast && float_samples && p->arith && arith_pref >= 0 &&
+        (!tables_fit || hist == kHistGlobal || scan == 0 || scan >= 3 || arith_pref > 0)) {
+      const int h0 = hist, c0 = cl2;
+      const size_t b0 = hist_bytes;
+      place(0, true);
+      if (hist != kHistGlobal || !tables_fit || arith_pref > 0) {
+        scan = kScanArith;
+        use_f32 = false;
+        tset = &p->ts[0][0];  // float64-domain DimTable (e_0, e_last, step); its tables are not read
+        table_bytes = 0;
+        tables_fit = true;
+      } else {
+        hist = h0; cl2 = c0; hist_bytes = b0;
+      }
+    }
+    if (fast && !tables_fit) continue;  // the vector family keeps its tables in LDS
+    lds_hist = hist == kHistLds;
+    tables_in_lds = tables_fit;
+    lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
+    // (scan 1..4: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
+    fn = fast ? fast_kernel(sdt, wdt, D, scan, hist, &vec) : generic_kernel(p->cmp, weighted, lds_hist);
+  }
+  if (!fn) return fail(XHIST_ERR_HIP, "internal: no kernel for this combination");
+  if (!fast) vec = 1;
+  const DimTable* dims = tset->dim;
+
+  // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
+  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
+    const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
+    const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
+    const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
+    if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
+      const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, *tset, shift,
+                                         (int)n_parts, profile);
+      if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = fall through to global atomics
+    }
+  }
+  const int kUnroll = fast ? unroll_for(D, vec, scan) : 1;
+
+  // ---- geometry -----------------------------------------------------------------------------
+  // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
+  // (profiles/r01_a_sweep.jsonl) the streaming rate peaks at ~64 KiB of outstanding loads per CU
+  // (f64+weights: 2 x 256 threads x 128 B; f64: 4 x 256 x 64 B) and falls by 5-10% with more.
+  // big LDS footprints leave room for one or two workgroups per CU; within-box sweeps: 512 threads
+  // for the replicated/plain LDS histograms (2.43-2.47 ms against 2.50-2.55 at 1024 for 10^9 x 2
+  // f64), 768 = three wavefronts per SIMD for the packed-uint16 one (C3: 2.45 against 2.54 at 1024,
+  // 2.86 at 512)
+  int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? (hist == kHistPacked ? 768 : 512) : 256);
+  if (!block_threads && n_rows > 1 && lds_bytes <= 40 * 1024) {
+    // many rows, one workgroup each: a tile should be ~1/4 of the row or most of the workgroup
+    // idles in the ragged tile (100k rows x 3650: 0.46 -> 0.39 ms; 356k x 1024: 1.3 -> 0.58 ms)
+    const int64_t per_lane = fast ? (int64_t)vec * unroll_for(D, vec, scan) : 4;
+    int64_t want = n_cols / (4 * per_lane);
+    block = 64;
+    while (block < 256 && block * 2 <= want) block *= 2;
+  }
+  int64_t lane_bytes = 0;
+  for (int d = 0; d < D; ++d) lane_bytes += dtype_size(samples[d].dtype);
+  if (weighted) lane_bytes += dtype_size(weights->dtype);
+  lane_bytes *= fast ? (int64_t)vec * kUnroll : 4;
+  int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
+  bpc = std::min<int>(bpc, 2048 / block);
+  if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
+  // one row: the segs workgroups share the row's tiles round-robin, so exactly one resident wave
+  // of workgroups is balanced by construction.  Many rows: a workgroup is tied to one row, so the
+  // tail is balanced by making 8x more, smaller workgroups (C4 shape: 5.6 -> 6.5 TB/s)
+  int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc * (n_rows > 1 ? 8 : 1);
+  if (!grid_blocks && n_rows == 1) {
+    // small inputs: every workgroup ends with one global atomic per non-empty bin, and atomics on
+    // one address serialise at ~12 ns; streaming gains ~25 GB/s per workgroup.  The sum of the
+    // two is minimal at sqrt(bytes / (25 GB/s * 12 ns)) workgroups (10^6 f64 samples: 18 -> 9 us)
+    const double bytes = (double)n_cols * (double)(lane_bytes / (fast ? (int64_t)vec * kUnroll : 4));
+    target = std::max<int64_t>(1, std::min<int64_t>(target, (int64_t)std::sqrt(bytes / 300.0)));
+  }
+  const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
+  const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
+  if (lds_bytes > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+
+  // rows per launch bounded by the grid limit; columns per launch bounded so that no workgroup
+  // can overflow a uint32 LDS counter (< 2^31 samples per workgroup per launch)
+  const int64_t kMaxGrid = ((int64_t)1 << 31) - 1;
+  int64_t col_chunk = n_cols;
+  {
+    int64_t segs_full = std::max<int64_t>(1, std::min<int64_t>(tiles_per_row, (target + n_rows - 1) / n_rows));
+    const int64_t per_wg = ((tiles_per_row + segs_full - 1) / segs_full) * tile;
+    if (per_wg >= ((int64_t)1 << 31)) col_chunk = segs_full * (((int64_t)1 << 30) / tile) * tile;
+  }
+  bool first_launch = true;
+  LaunchRecord rec(p, stream);
+  char desc[384];
+  for (int64_t c0 = 0; c0 < n_cols; c0 += col_chunk) {
+    const int64_t nc = std::min(col_chunk, n_cols - c0);
+    const int64_t tpr = (nc + tile - 1) / tile;
+    for (int64_t r0 = 0; r0 < n_rows;) {
+      int64_t segs = std::max<int64_t>(1, std::min<int64_t>(tpr, (target + (n_rows - r0) - 1) / (n_rows - r0)));
+      const int64_t nr = std::min<int64_t>(n_rows - r0, kMaxGrid / segs);
+      Params kp;
+      memset(&kp, 0, sizeof kp);
+      for (int d = 0; d < D; ++d) {
+        const xhist_array& a = samples[d];
+        kp.s_ptr[d] = advance(a.data, a.dtype, c0 * a.col_stride);
+        kp.s_rs[d] = a.row_stride;
+        kp.s_cs[d] = a.col_stride;
+        kp.s_ir[d] = a.inner_rows;
+        kp.s_os[d] = a.outer_stride;
+        kp.s_dt[d] = a.dtype;
+        kp.dim[d] = dims[d];
+      }
+      if (weighted) {
+        kp.w_ptr = advance(weights->data, weights->dtype, c0 * weights->col_stride);
+        kp.w_rs = weights->row_stride;
+        kp.w_cs = weights->col_stride;
+        kp.w_ir = weights->inner_rows;
+        kp.w_os = weights->outer_stride;
+        kp.w_dt = weights->dtype;
+      }
+      kp.row0 = r0;
+      kp.n_dims = D;
+      kp.tables = tset->blob;
+      kp.table_words = scan == kScanArith ? 0 : tset->words;  // arithmetic edges: nothing to stage
+      kp.tables_in_lds = tables_in_lds ? 1 : 0;
+      kp.n_rows = nr;
+      kp.n_cols = nc;
+      kp.n_bins = p->n_bins;
+      kp.out = static_cast<char*>(out) + (size_t)r0 * p->n_bins * 8;
+      kp.copies_log2 = cl2;
+      kp.segs = (int32_t)segs;
+      const dim3 grid((unsigned)(nr * segs));
+      if (first_launch)
+        if (int rrc = rec.begin(profile)) return rrc;
+      hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
+      HIPC(hipGetLastError());
+      if (first_launch) {
+        snprintf(desc, sizeof desc,
+                 "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
+                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu",
+                 fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
+                 fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
+                 table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
+                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : "f64"), lds_cap);
+      }
+      first_launch = false;
+      r0 += nr;
+    }
+  }
+  return rec.end(desc);
+}

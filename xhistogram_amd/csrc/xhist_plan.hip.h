@@ -1,0 +1,359 @@
+// xhist_plan.hip.h — host side: edge tables of a plan (build on device, verify on host), plan create / destroy / parameters
+// Part of the single translation unit xhist_capi.hip (included there, in order).
+#pragma once
+
+// Build the device table blob of one compare domain:
+//   [per-dimension edge arrays, 8-byte aligned] [per-dimension bucket tables (uint32 x K)]
+// dom: 0 float64, 1 int64, 2 float32 thresholds.  `words[d]` holds dimension d's edge array
+// already converted to the domain's element type; `edges` are the caller's original arrays.
+static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const int64_t* n_edges,
+                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, TableSet* ts) {
+  DimTable* dims = ts->dim;
+  uint64_t** d_blob_out = &ts->blob;
+  int32_t* table_words_out = &ts->words;
+  int* max_cnt_out = &ts->max_cnt;
+  int32_t edge_off = 0;
+  int64_t max_e = 0;
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = dims[d];
+    memset(&t, 0, sizeof t);
+    const int E = (int)n_edges[d];
+    max_e = std::max<int64_t>(max_e, E);
+    t.n_edges = E;
+    t.nb = E - 1;
+    t.edge_off = edge_off;
+    edge_off += (int32_t)words[d].size();
+    double range;
+    if (dom == 0) {
+      const double* e = static_cast<const double*>(edges[d]);
+      t.e0_f = e[0];
+      t.eL_f = e[E - 1];
+      range = t.eL_f - t.e0_f;
+    } else if (dom == 1) {
+      const int64_t* e = static_cast<const int64_t*>(edges[d]);
+      t.e0_i = e[0];
+      t.eL_i = e[E - 1];
+      range = (double)((uint64_t)t.eL_i - (uint64_t)t.e0_i);
+    } else {
+      const double* e = static_cast<const double*>(edges[d]);
+      const float* thr = reinterpret_cast<const float*>(words[d].data());
+      float last = (float)e[E - 1];  // largest float32 <= e_last
+      if ((double)last > e[E - 1]) last = std::nextafterf(last, -INFINITY);
+      t.e0_f = (double)thr[0];
+      t.eL_f = (double)last;
+      range = (double)((float)t.eL_f - (float)t.e0_f);
+    }
+    int K = std::min(4096, std::max(8, next_pow2((int)std::min<int64_t>(4 * (int64_t)E, 1 << 20))));
+    if (lut16) K *= 2;  // 2-byte entries: twice the buckets for the same LDS bytes
+    // more than 65535 edges: `start` no longer fits the 16-bit table fields — no bucket table at
+    // all (lut_k = 0): digitize is a plain binary search over the edge array (generic family), or
+    // table-free when the edges are arithmetic
+    const bool no_lut = E > 65535;
+    double scale = (double)K / range;
+    if (dom == 2) scale = (double)(float)scale;
+    if (!(range > 0.0) || !std::isfinite(range) || !std::isfinite(scale) || !(scale > 0.0)) {
+      K = 1;  // degenerate span: one bucket holding every edge, pure binary search
+      scale = 0.0;
+    }
+    if (no_lut) { K = 0; scale = 0.0; }
+    t.lut_k = K;
+    t.scale = scale;
+    if (dom == 2) t.bias = (double)(-(float)t.e0_f * (float)scale);
+    else if (dom == 0) t.bias = -t.e0_f * scale;
+    if (!std::isfinite(t.bias)) {  // e.g. e_0 = -inf with scale 0: keep the map defined (bucket 0)
+      t.bias = 0.0;
+      if (K > 1) { K = 1; t.lut_k = 1; t.scale = 0.0; }
+    }
+  }
+  int64_t stride = 1;
+  for (int d = n_inputs - 1; d >= 0; --d) {
+    dims[d].out_stride = stride;
+    stride *= dims[d].nb;
+  }
+  // bucket tables follow the edges; lut_off counts table ENTRIES (4-byte, or 2-byte for lut16)
+  int32_t off = (lut16 ? 4 : 2) * edge_off;
+  for (int d = 0; d < n_inputs; ++d) {
+    dims[d].lut_off = off;
+    off += dims[d].lut_k;
+  }
+  const int32_t per_word = lut16 ? 4 : 2;
+  const int32_t table_words = (off + per_word - 1) / per_word;
+  std::vector<uint64_t> blob((size_t)table_words, 0);
+  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + dims[d].edge_off, words[d].data(), words[d].size() * 8);
+
+  uint64_t* d_blob = nullptr;
+  int32_t* d_scratch = nullptr;
+  auto cleanup = [&](int rc) {
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (rc != XHIST_OK && d_blob) (void)hipFree(d_blob);
+    return rc;
+  };
+#define HIPP(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  HIPP(hipMalloc(&d_blob, blob.size() * 8));
+  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
+  HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+  for (int d = 0; d < n_inputs; ++d) {
+    if (dims[d].lut_k == 0) continue;
+    if (dom == 0 && !lut16) hipLaunchKernelGGL((build_tables<0, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (dom == 0) hipLaunchKernelGGL((build_tables<0, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (dom == 1) hipLaunchKernelGGL((build_tables<1, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else if (!lut16) hipLaunchKernelGGL((build_tables<2, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    else hipLaunchKernelGGL((build_tables<2, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
+    HIPP(hipGetLastError());
+    HIPP(hipDeviceSynchronize());
+  }
+  HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));
+#undef HIPP
+  const uint32_t* lut4 = reinterpret_cast<const uint32_t*>(blob.data());
+  const uint16_t* lut2 = reinterpret_cast<const uint16_t*>(blob.data());
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = dims[d];
+    uint32_t maxcnt = 0;
+    uint64_t total = 0;
+    if (t.lut_k == 0) { maxcnt = (uint32_t)t.n_edges; total = (uint64_t)t.n_edges; }
+    for (int b = 0; b < t.lut_k; ++b) {
+      uint32_t cnt;
+      if (lut16) {
+        const uint32_t next = b + 1 < t.lut_k ? lut2[t.lut_off + b + 1] : (uint32_t)t.n_edges;
+        cnt = next - lut2[t.lut_off + b];
+      } else {
+        cnt = lut4[t.lut_off + b] >> 16;
+      }
+      maxcnt = std::max(maxcnt, cnt);
+      total += cnt;
+    }
+    if (total != (uint64_t)t.n_edges) return cleanup(fail(XHIST_ERR_HIP, "bucket table of dim %d is inconsistent", d));
+    *max_cnt_out = std::max<int>(*max_cnt_out, (int)maxcnt);
+    int steps = 0;
+    while ((1u << steps) <= maxcnt) ++steps;
+    t.steps = steps;
+  }
+  (void)p;
+  *d_blob_out = d_blob;
+  *table_words_out = table_words;
+  return cleanup(XHIST_OK);
+}
+
+extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
+                                 int cmp_domain, xhist_plan** out_plan) {
+  if (!out_plan) return fail(XHIST_ERR_INVALID, "plan out-pointer is NULL");
+  *out_plan = nullptr;
+  if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS)
+    return fail(XHIST_ERR_INVALID, "n_inputs must be in [1, %d], got %d", XHIST_MAX_DIMS, n_inputs);
+  if (!edges || !n_edges) return fail(XHIST_ERR_INVALID, "edges / n_edges is NULL");
+  if (cmp_domain != XHIST_CMP_F64 && cmp_domain != XHIST_CMP_I64)
+    return fail(XHIST_ERR_INVALID, "unknown compare domain %d", cmp_domain);
+  int64_t max_e = 0;
+  for (int d = 0; d < n_inputs; ++d) {
+    if (!edges[d]) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL", d);
+    if (n_edges[d] < 1) return fail(XHIST_ERR_INVALID, "edges[%d] needs at least one edge", d);
+    if (n_edges[d] > ((int64_t)1 << 30))
+      return fail(XHIST_ERR_UNSUPPORTED, "edges[%d] has %lld edges; this build supports at most 2^30 per dimension", d,
+                  (long long)n_edges[d]);
+    max_e = std::max(max_e, n_edges[d]);
+    if (cmp_domain == XHIST_CMP_F64) {
+      const double* e = static_cast<const double*>(edges[d]);
+      for (int64_t j = 0; j < n_edges[d]; ++j) {
+        if (e[j] != e[j]) return fail(XHIST_ERR_EDGES, "edges[%d] contains NaN", d);
+        if (j && e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
+      }
+    } else {
+      const int64_t* e = static_cast<const int64_t*>(edges[d]);
+      for (int64_t j = 1; j < n_edges[d]; ++j)
+        if (e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
+    }
+  }
+  if (device < 0 || device >= n_devices())
+    return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available (%d visible); this library has no CPU path", device,
+                n_devices());
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+
+  xhist_plan* p = new (std::nothrow) xhist_plan();
+  if (!p) return fail(XHIST_ERR_NOMEM, "out of host memory");
+  p->device = device;
+  p->n_dims = n_inputs;
+  p->cmp = cmp_domain;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p->lds_max = prop.sharedMemPerBlock;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > 0)
+      p->lds_max = std::max(p->lds_max, (size_t)optin);
+  }
+
+  // ---- table sets: one per compare domain this plan can be asked for -----------------------
+  //   native (float64 or int64): every kernel family;  float32 thresholds: float32 fast family
+  int64_t n_bins = 1;
+  for (int d = 0; d < n_inputs; ++d) {
+    const int64_t nb = n_edges[d] - 1;
+    if (nb > 0 && n_bins > (int64_t)1 << 40) {
+      delete p;
+      return fail(XHIST_ERR_UNSUPPORTED, "histogram has more than 2^40 bins");
+    }
+    n_bins *= nb;
+  }
+  p->n_bins = n_bins;
+  std::vector<std::vector<uint64_t>> words(n_inputs);
+  std::vector<double> lo(n_inputs), hi(n_inputs);
+  for (int d = 0; d < n_inputs; ++d) {
+    const int E = (int)n_edges[d];
+    words[d].assign((size_t)E, 0);
+    memcpy(words[d].data(), edges[d], (size_t)E * 8);
+  }
+  // every edge array is followed by 4 sentinels that compare false against any sample (NaN), so
+  // the linear in-bucket count may read up to 4 entries past a bucket's start unconditionally
+  const uint64_t kNaN64 = 0x7ff8000000000000ull;
+  for (int d = 0; d < n_inputs; ++d)
+    for (int k = 0; k < 4; ++k) words[d].push_back(cmp_domain == XHIST_CMP_F64 ? kNaN64 : 0x7fffffffffffffffull);
+  // more than 65535 edges in some dimension: only the native set, without bucket tables (the vector
+  // family then runs table-free on arithmetic edges, everything else takes the generic family)
+  p->huge = max_e > 65535;
+  const bool vector_sets = cmp_domain == XHIST_CMP_F64 && !p->huge;
+  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0]);
+  if (rc == XHIST_OK && vector_sets) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
+  if (rc == XHIST_OK && vector_sets) {
+    // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
+    for (int d = 0; d < n_inputs; ++d) {
+      const int E = (int)n_edges[d];
+      const double* e = static_cast<const double*>(edges[d]);
+      std::vector<float> thr((size_t)E + 6, std::nanf(""));  // >= 4 NaN sentinels after the thresholds
+      for (int j = 0; j < E; ++j) {
+        float f = (float)e[j];
+        if ((double)f < e[j]) f = std::nextafterf(f, INFINITY);
+        thr[(size_t)j] = f;
+      }
+      words[d].assign(((size_t)E + 5) / 2, 0);
+      memcpy(words[d].data(), thr.data(), words[d].size() * 8);
+    }
+    rc = build_domain(p, 2, false, n_inputs, n_edges, words, edges, &p->ts[1][0]);
+    if (rc == XHIST_OK) rc = build_domain(p, 2, true, n_inputs, n_edges, words, edges, &p->ts[1][1]);
+  }
+  if (rc != XHIST_OK) {
+    for (auto& dom : p->ts)
+      for (auto& t : dom)
+        if (t.blob) (void)hipFree(t.blob);
+    delete p;
+    return rc;
+  }
+  // ---- arithmetic edges: e_j == fl(fl(j * step) + e_0) for every j < nb, step = (e_nb - e_0) / nb ----
+  // (what numpy.linspace / histogram_bin_edges produce for `bins=int`).  Checked edge by edge with the
+  // two roundings kept apart (volatile product: no fma contraction), and only when bins are well
+  // resolved (step >= 4 ulp of the largest magnitude) — the bound count_le_arith's guess relies on.
+  if (cmp_domain == XHIST_CMP_F64) {
+    bool all = true;
+    for (int d = 0; d < n_inputs && all; ++d) {
+      const double* e = static_cast<const double*>(edges[d]);
+      const int nb = (int)n_edges[d] - 1;
+      bool ok = nb >= 1 && std::isfinite(e[0]) && std::isfinite(e[nb]);
+      double step = 0.0;
+      if (ok) {
+        step = (e[nb] - e[0]) / (double)nb;
+        const double mag = std::max(std::max(std::fabs(e[0]), std::fabs(e[nb])), e[nb] - e[0]);
+        const double ulp = std::nextafter(mag, INFINITY) - mag;
+        ok = std::isfinite(step) && step > 0.0 && step >= 4.0 * ulp && std::isfinite(1.0 / step);
+      }
+      for (int j = 0; j < nb && ok; ++j) {
+        volatile double m = (double)j * step;
+        ok = (m + e[0]) == e[j];
+      }
+      if (ok) ok = e[nb] >= e[nb - 1];
+      all = ok;
+      if (ok)
+        for (auto& dom : p->ts[0]) {
+          dom.dim[d].step = step;
+          dom.dim[d].inv_step = 1.0 / step;
+          dom.dim[d].arith = 1;
+        }
+    }
+    p->arith = all;
+  }
+  *out_plan = p;
+  return XHIST_OK;
+}
+
+
+extern "C" int xhist_plan_destroy(xhist_plan* p) {
+  if (!p) return XHIST_OK;
+  DeviceGuard g;
+  if (g.set(p->device) == XHIST_OK) {
+    for (auto& dom : p->ts)
+      for (auto& t : dom)
+        if (t.blob) (void)hipFree(t.blob);
+    for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+  delete p;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return fail(XHIST_ERR_INVALID, "plan / key is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (!strcmp(key, "block_threads")) {
+    if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(XHIST_ERR_INVALID, "block_threads must be a multiple of 64 in [64, 1024]");
+    p->block_threads = (int)value;
+  } else if (!strcmp(key, "grid_blocks")) {
+    if (value < 0) return fail(XHIST_ERR_INVALID, "grid_blocks must be >= 0");
+    p->grid_blocks = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (!strcmp(key, "force_global")) {
+    p->force_global = value != 0;
+  } else if (!strcmp(key, "force_generic")) {
+    p->force_generic = value != 0;
+  } else if (!strcmp(key, "partition")) {
+    p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "lanes")) {
+    p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "arith")) {
+    p->arith_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "lds_copies")) {
+    if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
+    p->lds_copies = (int)value;
+  } else if (!strcmp(key, "profile")) {
+    // value = number of most recent executes whose main-kernel duration is kept (0 = off)
+    if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "profile must be in [0, 4096]");
+    DeviceGuard g;
+    if (int rc = g.set(p->device)) return rc;
+    while ((int64_t)p->ring.size() < value) {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIPC(hipEventCreate(&a));
+      HIPC(hipEventCreate(&b));
+      p->ring.emplace_back(a, b);
+    }
+    p->profile = (int)value;
+    p->n_recorded = 0;
+  } else {
+    return fail(XHIST_ERR_INVALID, "unknown parameter '%s'", key);
+  }
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_describe(xhist_plan* p, char* buf, size_t cap) {
+  if (!p || !buf || !cap) return fail(XHIST_ERR_INVALID, "plan / buf is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  strncpy(buf, p->desc.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_plan_profile_read(xhist_plan* p, float* ms, int cap, int* n_out) {
+  if (!p || !ms || !n_out || cap < 0) return fail(XHIST_ERR_INVALID, "plan / ms / n_out is NULL");
+  std::lock_guard<std::mutex> lk(p->mu);
+  *n_out = 0;
+  if (!p->profile || p->n_recorded == 0) return XHIST_OK;
+  DeviceGuard g;
+  if (int rc = g.set(p->device)) return rc;
+  const int64_t kept = std::min<int64_t>(p->n_recorded, p->profile);
+  for (int64_t k = p->n_recorded - kept; k < p->n_recorded && *n_out < cap; ++k) {
+    auto& e = p->ring[(size_t)(k % p->profile)];
+    HIPC(hipEventSynchronize(e.second));
+    HIPC(hipEventElapsedTime(&ms[*n_out], e.first, e.second));
+    ++*n_out;
+  }
+  p->n_recorded = 0;
+  return XHIST_OK;
+}
