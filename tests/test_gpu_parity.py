@@ -551,6 +551,22 @@ def test_partitioned_mode_tiny_and_ragged_inputs(xh):
             assert_hist_equal(got, onp.bincount_rows([x, y], edges, ww), ww is not None)
 
 
+def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
+    """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
+    rng = np.random.default_rng(59)
+    for dt, lo, hi in ((np.uint8, 0, 256), (np.int16, -300, 300), (np.int32, -70000, 70000)):
+        x = rng.integers(lo, hi, (1, 500_001)).astype(dt)
+        edges = [np.arange(max(lo, -200), min(hi, 257) + 1)]  # int64 edges
+        got, desc = _run(xh, [x], edges, None, True)
+        assert "family=fast" in desc and "cmp=f64" in desc, desc
+        np.testing.assert_array_equal(got, onp.bincount_rows([x], edges))
+    # int64 samples keep the exact int64 comparison
+    x = rng.integers(-5, 300, (1, 10_000)).astype(np.int64)
+    got, desc = _run(xh, [x], [np.arange(257)], None, True)
+    assert "cmp=i64" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x], [np.arange(257)]))
+
+
 # ---------------------------------------------------------------------------------------------
 # arithmetic edges (bins=int / np.linspace): table-free digitize when the edge tables would not fit
 # ---------------------------------------------------------------------------------------------

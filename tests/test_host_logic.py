@@ -72,7 +72,11 @@ def test_compare_domain_follows_numpy_promotion():
     assert core._compare_domain([f32], [e_i])[0] == _native.CMP_F64
     dom, conv, _ = core._compare_domain([i64], [e_i])
     assert dom == _native.CMP_I64 and conv[0].dtype == np.int64
-    assert core._compare_domain([i32, u8], [e_i, e_i.astype(np.int16)])[0] == _native.CMP_I64
+    # <= 32-bit integer samples against integer edges within +-2^53: exact in float64, taken there
+    dom, conv, _ = core._compare_domain([i32, u8], [e_i, e_i.astype(np.int16)])
+    assert dom == _native.CMP_F64 and all(c.dtype == np.float64 for c in conv)
+    assert core._compare_domain([i32, i64], [e_i, e_i])[0] == _native.CMP_I64       # a 64-bit input keeps int64
+    assert core._compare_domain([i32], [np.array([0, (1 << 53) + 1])])[0] == _native.CMP_I64  # edge not exact in float64
     assert core._compare_domain([i32, f64], [e_i.astype(np.int32), e_f])[0] == _native.CMP_F64  # small ints are exact in f64
     with pytest.raises(NotImplementedError):
         core._compare_domain([i64, f64], [e_i, e_f])

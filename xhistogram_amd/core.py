@@ -146,6 +146,17 @@ def _compare_domain(sample_dtypes, edges):
         else:
             conv.append(e.astype(np.int64))
             doms.append((_native.CMP_I64, None))
+    # Integer samples of at most 32 bits against integer edges within +-2^53: both sides are exact
+    # in float64, so the comparison may run there — which is where the vector kernels are
+    # (`bins=np.arange(257)` on uint8 / int32 data: 3-4x the generic int64 family).
+    def small_exact(k):
+        d, common = doms[k]
+        e = np.asarray(edges[k])
+        return (d == _native.CMP_I64 and common is None and sample_dtypes[k].itemsize <= 4 and
+                (e.size == 0 or (int(e.min()) >= -(1 << 53) and int(e.max()) <= (1 << 53))))
+    if any(d == _native.CMP_I64 for d, _ in doms) and all(d == _native.CMP_F64 or small_exact(k) for k, (d, _) in enumerate(doms)):
+        conv = [np.asarray(e).astype(np.float64) for e in edges]
+        return _native.CMP_F64, conv, [None] * len(edges)
     kinds = {d for d, _ in doms}
     if len(kinds) > 1:
         # mixed: everything goes to float64 unless that could round an int64/datetime dimension
