@@ -537,6 +537,32 @@ def test_partitioned_mode_more_than_128_partitions(xh, weighted):
     assert_hist_equal(got, want, weighted)
 
 
+def test_partitioned_mode_a_few_long_rows(xh):
+    """one beyond-LDS joint histogram per row (e.g. per time step): the partitioned mode row by row"""
+    rng = np.random.default_rng(49)
+    rows, n = 3, 1_200_000
+    x = rng.standard_normal((rows, n))
+    y = rng.standard_normal((rows, n)) * 1.3
+    w = rng.uniform(0, 1, (rows, n))
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    for ww in (None, w):
+        got, desc = _run(xh, [x, y], edges, ww, True, partition=1)
+        assert "hist=partitioned" in desc, desc
+        assert_hist_equal(got, onp.bincount_rows([x, y], edges, ww), ww is not None)
+    # rows of a strided parent (every second row) and weights broadcast along the rows
+    xs = _dev(np.repeat(x, 2, axis=0))[::2]
+    ys = _dev(np.repeat(y, 2, axis=0))[::2]
+    wb = _dev(w[:1]).expand(rows, n)
+    plan = _plan_for(xh, [xs, ys], edges)
+    plan.set_param("partition", 1)
+    try:
+        got = xh._bincount_2d_vectorized(xs, ys, bins=edges, weights=wb).cpu().numpy()
+        assert "hist=partitioned" in plan.describe()
+    finally:
+        plan.set_param("partition", 0)
+    assert_hist_equal(got, onp.bincount_rows([x, y], edges, np.broadcast_to(w[:1], (rows, n))), True)
+
+
 def test_partitioned_mode_tiny_and_ragged_inputs(xh):
     """forced partitioned mode on inputs of a few records: carried records and padding only"""
     edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]

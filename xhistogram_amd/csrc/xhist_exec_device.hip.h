@@ -49,7 +49,7 @@ static const void* advance(const void* base, int dt, int64_t elems) {
 // `stream`, scratch from the stream-ordered allocator (so concurrent callers never share it).
 static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
                                hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
-                               int n_parts, int profile) {
+                               int n_parts, int profile, LaunchRecord& rec, bool first, bool last) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
   if (n_cols >= ((int64_t)1 << 40)) return XHIST_ERR_UNSUPPORTED;
@@ -141,8 +141,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   kernel_fn_acc k_acc = weighted ? (kernel_fn_acc)part_accumulate<true> : (kernel_fn_acc)part_accumulate<false>;
   if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
 
-  LaunchRecord rec(p, stream);
-  if (int rrc = rec.begin(profile)) return release(rrc);
+  if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
+    if (int rrc = rec.begin(profile)) return release(rrc);
   hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, grp, d_offsets, d_base);
@@ -160,7 +160,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
              "lds_count=%zu lds_scatter=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
              n_parts, 1 << shift, grp, vec, kPartTile, kPartBlock, G, Gb, lds_count, lds_scatter, lds_acc, scan, (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
-    if (int rrc = rec.end(desc)) return release(rrc);
+    if (last)
+      if (int rrc = rec.end(desc)) return release(rrc);
   }
 #undef HIPR
   return release(XHIST_OK);
@@ -487,13 +488,30 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const DimTable* dims = tset->dim;
 
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
-  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows == 1) {
+  // (a few long rows — e.g. one joint histogram per time step — run it row by row)
+  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64) {
     const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
     if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
-      const int rc = execute_partitioned(p, samples, weights, n_cols, out, stream, sdt, wdt, scan, use_f32, *tset, shift,
-                                         (int)n_parts, profile);
+      LaunchRecord rec(p, stream);
+      int rc = XHIST_OK;
+      for (int64_t r = 0; r < n_rows && rc == XHIST_OK; ++r) {
+        xhist_array row_s[XHIST_MAX_DIMS], row_w;
+        for (int d = 0; d < D; ++d) {
+          row_s[d] = samples[d];
+          row_s[d].data = const_cast<void*>(advance(samples[d].data, samples[d].dtype,
+                                                    row_offset(r, samples[d].row_stride, samples[d].inner_rows, samples[d].outer_stride)));
+        }
+        if (weighted) {
+          row_w = *weights;
+          row_w.data = const_cast<void*>(advance(weights->data, weights->dtype,
+                                                 row_offset(r, weights->row_stride, weights->inner_rows, weights->outer_stride)));
+        }
+        rc = execute_partitioned(p, row_s, weighted ? &row_w : nullptr, n_cols, static_cast<char*>(out) + (size_t)r * p->n_bins * 8, stream,
+                                 sdt, wdt, scan, use_f32, *tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1);
+        if (rc == XHIST_ERR_UNSUPPORTED && r > 0) rc = fail(XHIST_ERR_HIP, "internal: partitioned mode refused row %lld after accepting row 0", (long long)r);
+      }
       if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = fall through to global atomics
     }
   }

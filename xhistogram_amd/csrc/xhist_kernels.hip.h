@@ -89,7 +89,7 @@ struct Params {
   int32_t n_parts;
 };
 
-__device__ __forceinline__ int64_t row_offset(int64_t r, int64_t rs, int64_t ir, int64_t os) {
+__host__ __device__ __forceinline__ int64_t row_offset(int64_t r, int64_t rs, int64_t ir, int64_t os) {
   if (ir == 0) return r * rs;
   const int64_t g = r / ir;
   return g * os + (r - g * ir) * rs;
