@@ -55,6 +55,10 @@ typedef enum {
 } xhist_dtype;
 
 typedef enum { XHIST_CMP_F64 = 0, XHIST_CMP_I64 = 1 } xhist_cmp_domain;
+/* Per-input domains (a datetime64 axis next to a float axis): cmp_domain = XHIST_CMP_PER_DIM | mask,
+ * bit d of mask set <=> input d compares in int64 (its edge array is int64), else in float64.
+ * numpy digitizes every argument on its own (core.py:163-174), so such mixtures are legal there. */
+#define XHIST_CMP_PER_DIM 0x100
 typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1 } xhist_mem_kind;
 
 /* A logical [M, C] array addressed as data[row_offset(r) + c * col_stride] (strides in ELEMENTS):
@@ -85,7 +89,8 @@ int xhist_device_count(int* count);
 int xhist_device_info(int device, char* name, size_t name_cap, int* compute_units, size_t* total_mem_bytes);
 
 /* ---- plans ------------------------------------------------------------------------------- */
-/* Upload D edge arrays (HOST pointers; float64 for XHIST_CMP_F64, int64 for XHIST_CMP_I64) and
+/* Upload D edge arrays (HOST pointers; float64 for XHIST_CMP_F64, int64 for XHIST_CMP_I64, per input
+ * for XHIST_CMP_PER_DIM) and
  * build the per-dimension bucket->edge-range tables used by the branch-free digitize.
  * Replaces the per-call edge handling of core.py:154-155, 163-174. */
 int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,

@@ -577,6 +577,44 @@ def test_partitioned_mode_tiny_and_ragged_inputs(xh):
             assert_hist_equal(got, onp.bincount_rows([x, y], edges, ww), ww is not None)
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_per_input_compare_domains_datetime_and_int64_next_to_floats(xh, resident):
+    """a time axis (datetime64 / int64, compared exactly) against a float axis, as numpy does per argument"""
+    rng = np.random.default_rng(58)
+    n = 200_000
+    t0 = np.datetime64("2001-03-04T00:00:00", "s")
+    t = (t0 + rng.integers(-10_000, 400 * 86400, (2, n)).astype("timedelta64[s]")).astype("datetime64[s]")
+    t_edges = np.arange(np.datetime64("2001-03-01"), np.datetime64("2002-03-02"), np.timedelta64(1, "D"))  # datetime64[D]
+    v = rng.standard_normal((2, n))
+    v_edges = np.linspace(-3, 3, 25)
+    w = rng.uniform(0, 1, (2, n))
+    for samples, edges in (([t, v], [t_edges, v_edges]), ([v, t], [v_edges, t_edges])):
+        for ww in (None, w):
+            want = onp.bincount_rows(samples, edges, ww)
+            if resident and any(s.dtype.kind == "M" for s in samples):
+                # torch has no datetime64: the int64 view (in the common unit) is what a torch user holds
+                common = np.result_type(t.dtype, t_edges.dtype)
+                samples_t = [s.astype(common).view(np.int64) if s.dtype.kind == "M" else s for s in samples]
+                edges_t = [e.astype(common).view(np.int64) if e.dtype.kind == "M" else e for e in edges]
+                got, desc = _run(xh, samples_t, edges_t, ww, True)
+            else:
+                got, desc = _run(xh, samples, edges, ww, resident)
+            assert_hist_equal(got, want, ww is not None)
+    if not resident:  # the public entry point: datetime64 unit alignment + per-input domains + axis handling
+        h, _ = xh.histogram(t, v, bins=[t_edges, v_edges], axis=1, weights=w)
+        assert_hist_equal(h, onp.histogram(t, v, bins=[t_edges, v_edges], axis=1, weights=w)[0], True)
+    # int64 values beyond 2^53 (float64 would merge neighbours) next to a float input
+    big = (1 << 60) + rng.integers(0, 40, (1, 50_000))
+    big_edges = (1 << 60) + np.arange(0, 41, 2)
+    f = rng.uniform(0, 1, (1, 50_000)).astype(np.float32)
+    f_edges = np.linspace(0, 1, 5)
+    got, desc = _run(xh, [big, f], [big_edges, f_edges], None, resident)
+    assert "cmp=per-input" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([big, f], [big_edges, f_edges]))
+    got = _run(xh, [f, big, f], [f_edges, big_edges, f_edges], None, resident)[0]
+    np.testing.assert_array_equal(got, onp.bincount_rows([f, big, f], [f_edges, big_edges, f_edges]))
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

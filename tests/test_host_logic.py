@@ -78,8 +78,11 @@ def test_compare_domain_follows_numpy_promotion():
     assert core._compare_domain([i32, i64], [e_i, e_i])[0] == _native.CMP_I64       # a 64-bit input keeps int64
     assert core._compare_domain([i32], [np.array([0, (1 << 53) + 1])])[0] == _native.CMP_I64  # edge not exact in float64
     assert core._compare_domain([i32, f64], [e_i.astype(np.int32), e_f])[0] == _native.CMP_F64  # small ints are exact in f64
-    with pytest.raises(NotImplementedError):
-        core._compare_domain([i64, f64], [e_i, e_f])
+    # a 64-bit integer (or datetime) input next to a float one: per-input domains
+    dom, conv, _ = core._compare_domain([i64, f64], [e_i, e_f])
+    assert dom == (_native.CMP_PER_DIM | 0b01) and conv[0].dtype == np.int64 and conv[1].dtype == np.float64
+    dom, conv, common = core._compare_domain([f32, np.dtype("datetime64[s]")], [e_f, np.array(["2000-01-01", "2001-01-01"], dtype="datetime64[D]")])
+    assert dom == (_native.CMP_PER_DIM | 0b10) and common[1] == np.dtype("datetime64[s]") and conv[1].dtype == np.int64
     t = np.array(["2000-01-01", "2001-01-01"], dtype="datetime64[D]")
     dom, conv, common = core._compare_domain([np.dtype("datetime64[ns]")], [t])
     assert dom == _native.CMP_I64 and common[0] == np.dtype("datetime64[ns]")

@@ -27,6 +27,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_EDGES =
 # dtype tags (xhist_dtype)
 F64, F32, F16, I64, I32, I16, I8, U64, U32, U16, U8, BOOL = range(12)
 CMP_F64, CMP_I64 = 0, 1
+CMP_PER_DIM = 0x100  # | mask: bit d set <=> input d compares in int64 (XHIST_CMP_PER_DIM)
 MEM_HOST, MEM_DEVICE = 0, 1
 
 _NP_TAG = {
@@ -162,8 +163,11 @@ class Plan:
         lib = load()
         self.device = int(device)
         self.cmp = int(cmp_domain)
-        want = np.int64 if cmp_domain == CMP_I64 else np.float64
-        self._edges = [np.ascontiguousarray(e, dtype=want) for e in edges]
+        def want(d):
+            if (self.cmp & ~0xff) == CMP_PER_DIM:
+                return np.int64 if (self.cmp >> d) & 1 else np.float64
+            return np.int64 if self.cmp == CMP_I64 else np.float64
+        self._edges = [np.ascontiguousarray(e, dtype=want(d)) for d, e in enumerate(edges)]
         for e in self._edges:
             if e.ndim != 1:
                 raise ValueError("bin edges must be 1-D")

@@ -118,7 +118,8 @@ def _get_plan(edges, cmp_domain, device):
 
 def _compare_domain(sample_dtypes, edges):
     """Decide how samples are compared with edges, following numpy's promotion in searchsorted
-    (core.py:170): float64 compares unless BOTH sides are integers / datetimes, then exact int64.
+    (core.py:170): float64 compares unless BOTH sides are integers / datetimes, then exact int64;
+    decided per input (CMP_PER_DIM | mask when the inputs differ).
     Returns (cmp_domain, edges converted to the domain's dtype, per-input 'view as int64' flag)."""
     doms = []
     conv = []
@@ -159,12 +160,10 @@ def _compare_domain(sample_dtypes, edges):
         return _native.CMP_F64, conv, [None] * len(edges)
     kinds = {d for d, _ in doms}
     if len(kinds) > 1:
-        # mixed: everything goes to float64 unless that could round an int64/datetime dimension
-        for (d, common), sd, e in zip(doms, sample_dtypes, edges):
-            if d == _native.CMP_I64 and (common is not None or sd.itemsize == 8 or np.asarray(e).dtype.itemsize == 8):
-                raise NotImplementedError("mixing 64-bit integer/datetime dimensions with float dimensions")
-        conv = [np.asarray(e).astype(np.float64) for e in edges]
-        return _native.CMP_F64, conv, [None] * len(edges)
+        # 64-bit integer / datetime inputs next to float ones (a time axis against a value axis):
+        # every input keeps its own domain, as numpy digitizes every argument on its own
+        mask = sum(1 << k for k, (d, _) in enumerate(doms) if d == _native.CMP_I64)
+        return _native.CMP_PER_DIM | mask, conv, [c for _, c in doms]
     return doms[0][0], conv, [c for _, c in doms]
 
 

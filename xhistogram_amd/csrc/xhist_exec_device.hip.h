@@ -16,7 +16,8 @@ static int validate_arrays(const xhist_plan* p, const xhist_array* samples, cons
     if (!dtype_size(samples[d].dtype)) return fail(XHIST_ERR_INVALID, "samples[%d] has unknown dtype tag %d", d, samples[d].dtype);
     if (samples[d].row_stride < 0 || samples[d].col_stride < 0 || samples[d].inner_rows < 0 || samples[d].outer_stride < 0)
       return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
-    if (p->cmp == XHIST_CMP_I64 && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
+    const bool int_dim = p->cmp == XHIST_CMP_I64 || ((p->cmp & ~0xff) == XHIST_CMP_PER_DIM && ((p->cmp >> d) & 1));
+    if (int_dim && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
       return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", samples[d].dtype);
   }
   if (weights) {
@@ -617,7 +618,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
                  fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
                  fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
                  table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
-                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : "f64"), lds_cap);
+                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : (p->cmp == XHIST_CMP_F64 ? "f64" : "per-input")), lds_cap);
       }
       first_launch = false;
       r0 += nr;

@@ -52,7 +52,8 @@ struct DimTable {
   // arithmetic edges (numpy.linspace: e_j = fl(fl(j * step) + e_0) for j < nb, e_nb given), verified
   // edge by edge at plan creation: digitize needs no table at all (count_le_scan<.., kScanArith>)
   double step, inv_step;
-  int32_t arith, pad_;
+  int32_t arith;
+  int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
 };
 
 struct Params {
@@ -135,6 +136,12 @@ struct Dom<2> {  // float32 samples against float64 edges, compared EXACTLY in f
   static __device__ __forceinline__ float offset(float x, const DimTable& t) { return x - (float)t.e0_f; }
 };
 
+// per-dimension domains: the sample travels as 64 raw bits (an int64, or the bits of a float64)
+template <>
+struct Dom<3> {
+  using T = int64_t;
+};
+
 // Monotone bucket index in [0, K-1] for ANY x (NaN -> 0).  Used by the table builder (on the
 // edges) and by digitize (on the samples): the two must be the same code.
 template <int CMP>
@@ -163,31 +170,40 @@ struct DigState {
 
 template <int CMP, typename TabPtr>
 __device__ __forceinline__ void upper_bound_step(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab, DigState& s) {
-  using T = typename Dom<CMP>::T;
-  auto edges = reinterpret_cast<const T*>(tab + t.edge_off);
-  const uint32_t half = s.len >> 1;
-  const uint32_t mid = s.lo + half;
-  const T e = edges[min((int)mid, t.n_edges - 1)];
-  const bool le = (s.len != 0u) & (e <= x);
-  s.lo = le ? mid + 1u : s.lo;
-  s.len = le ? s.len - half - 1u : half;
+  if constexpr (CMP == 3) {  // per-dimension domain; the branch is uniform (t is a kernel argument)
+    if (t.is_i64) upper_bound_step<1>(x, t, tab, s);
+    else upper_bound_step<0>(__longlong_as_double(x), t, tab, s);
+  } else {
+    using T = typename Dom<CMP>::T;
+    auto edges = reinterpret_cast<const T*>(tab + t.edge_off);
+    const uint32_t half = s.len >> 1;
+    const uint32_t mid = s.lo + half;
+    const T e = edges[min((int)mid, t.n_edges - 1)];
+    const bool le = (s.len != 0u) & (e <= x);
+    s.lo = le ? mid + 1u : s.lo;
+    s.len = le ? s.len - half - 1u : half;
+  }
 }
 
 template <int CMP, typename TabPtr>
 __device__ __forceinline__ DigState digitize_begin(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
-  auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
-  DigState s;
-  s.ok = Dom<CMP>::in_range(x, t);
-  if (t.lut_k == 0) {  // more than 65535 edges: no bucket table, binary search over all of them
-    s.lo = 0u;
-    s.len = (uint32_t)t.n_edges;
+  if constexpr (CMP == 3) {
+    return t.is_i64 ? digitize_begin<1>(x, t, tab) : digitize_begin<0>(__longlong_as_double(x), t, tab);
   } else {
-    const uint32_t ent = lut[bucket_of<CMP>(x, t)];
-    s.lo = ent & 0xffffu;  // edges below x's bucket: certainly <= x
-    s.len = ent >> 16;     // edges sharing the bucket: compared explicitly
+    auto lut = reinterpret_cast<const uint32_t*>(tab) + t.lut_off;
+    DigState s;
+    s.ok = Dom<CMP>::in_range(x, t);
+    if (t.lut_k == 0) {  // more than 65535 edges: no bucket table, binary search over all of them
+      s.lo = 0u;
+      s.len = (uint32_t)t.n_edges;
+    } else {
+      const uint32_t ent = lut[bucket_of<CMP>(x, t)];
+      s.lo = ent & 0xffffu;  // edges below x's bucket: certainly <= x
+      s.len = ent >> 16;     // edges sharing the bucket: compared explicitly
+    }
+    upper_bound_step<CMP>(x, t, tab, s);
+    return s;
   }
-  upper_bound_step<CMP>(x, t, tab, s);
-  return s;
 }
 
 template <int CMP, typename TabPtr>
@@ -280,6 +296,13 @@ __device__ __forceinline__ OUT load_as(const void* p, int32_t dt, int64_t i) {
     case DT_U8: return (OUT) reinterpret_cast<const uint8_t*>(p)[i];
     default: return (OUT)(reinterpret_cast<const uint8_t*>(p)[i] != 0);  // DT_BOOL
   }
+}
+
+// a sample in its compare domain; per-dimension domains (3) carry an int64 or the bits of a float64
+template <int CMP>
+__device__ __forceinline__ typename Dom<CMP>::T load_dom(const void* p, int32_t dt, int64_t i, const DimTable& t) {
+  if constexpr (CMP == 3) return t.is_i64 ? load_as<int64_t>(p, dt, i) : __double_as_longlong(load_as<double>(p, dt, i));
+  else return load_as<typename Dom<CMP>::T>(p, dt, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -639,7 +662,7 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
       for (int k = 0; k < B; ++k) {
 #pragma unroll
         for (int d = 0; d < 2; ++d)
-          if (d < nd) x[k][d] = load_as<CT>(p.s_ptr[d], p.s_dt[d], roff[d] + (i + k * stride) * p.s_cs[d]);
+          if (d < nd) x[k][d] = load_dom<CMP>(p.s_ptr[d], p.s_dt[d], roff[d] + (i + k * stride) * p.s_cs[d], p.dim[d]);
         w[k] = WEIGHTED ? load_as<double>(p.w_ptr, p.w_dt, woff + (i + k * stride) * p.w_cs) : 0.0;
       }
 #pragma unroll
@@ -676,7 +699,7 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
 #pragma unroll
     for (int d = 0; d < kMaxDims; ++d) {
       if (d < nd) {
-        const CT x = load_as<CT>(p.s_ptr[d], p.s_dt[d], roff[d] + i * p.s_cs[d]);
+        const CT x = load_dom<CMP>(p.s_ptr[d], p.s_dt[d], roff[d] + i * p.s_cs[d], p.dim[d]);
         const int b = digitize<CMP>(x, p.dim[d], tab);
         ok &= (b >= 0);
         flat += (int64_t)b * p.dim[d].out_stride;

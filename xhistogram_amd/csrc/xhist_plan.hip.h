@@ -6,8 +6,10 @@
 //   [per-dimension edge arrays, 8-byte aligned] [per-dimension bucket tables (uint32 x K)]
 // dom: 0 float64, 1 int64, 2 float32 thresholds.  `words[d]` holds dimension d's edge array
 // already converted to the domain's element type; `edges` are the caller's original arrays.
-static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const int64_t* n_edges,
-                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, TableSet* ts) {
+// dim_dom (optional): per-dimension domain (0 / 1) overriding `dom` — plans with mixed domains
+static int build_domain(xhist_plan* p, int dom_all, bool lut16, int n_inputs, const int64_t* n_edges,
+                        const std::vector<std::vector<uint64_t>>& words, const void* const* edges, TableSet* ts,
+                        const int* dim_dom = nullptr) {
   DimTable* dims = ts->dim;
   uint64_t** d_blob_out = &ts->blob;
   int32_t* table_words_out = &ts->words;
@@ -23,6 +25,8 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
     t.nb = E - 1;
     t.edge_off = edge_off;
     edge_off += (int32_t)words[d].size();
+    const int dom = dim_dom ? dim_dom[d] : dom_all;
+    t.is_i64 = dim_dom && dom == 1;
     double range;
     if (dom == 0) {
       const double* e = static_cast<const double*>(edges[d]);
@@ -98,6 +102,7 @@ static int build_domain(xhist_plan* p, int dom, bool lut16, int n_inputs, const 
   HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
   for (int d = 0; d < n_inputs; ++d) {
     if (dims[d].lut_k == 0) continue;
+    const int dom = dim_dom ? dim_dom[d] : dom_all;
     if (dom == 0 && !lut16) hipLaunchKernelGGL((build_tables<0, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
     else if (dom == 0) hipLaunchKernelGGL((build_tables<0, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
     else if (dom == 1) hipLaunchKernelGGL((build_tables<1, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
@@ -145,8 +150,21 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS)
     return fail(XHIST_ERR_INVALID, "n_inputs must be in [1, %d], got %d", XHIST_MAX_DIMS, n_inputs);
   if (!edges || !n_edges) return fail(XHIST_ERR_INVALID, "edges / n_edges is NULL");
-  if (cmp_domain != XHIST_CMP_F64 && cmp_domain != XHIST_CMP_I64)
+  // per-input domains: bit d of the mask = input d compares in int64; uniform masks are the plain domains
+  int dim_dom[XHIST_MAX_DIMS] = {0};
+  bool mixed = false;
+  if ((cmp_domain & ~0xff) == XHIST_CMP_PER_DIM) {
+    const int mask = cmp_domain & 0xff;
+    if (mask >> n_inputs) return fail(XHIST_ERR_INVALID, "per-input compare mask 0x%x names inputs beyond the %d given", mask, n_inputs);
+    if (mask == 0) cmp_domain = XHIST_CMP_F64;
+    else if (mask == (1 << n_inputs) - 1) cmp_domain = XHIST_CMP_I64;
+    else mixed = true;
+    for (int d = 0; d < n_inputs; ++d) dim_dom[d] = (mask >> d) & 1;
+  } else if (cmp_domain != XHIST_CMP_F64 && cmp_domain != XHIST_CMP_I64) {
     return fail(XHIST_ERR_INVALID, "unknown compare domain %d", cmp_domain);
+  }
+  if (!mixed)
+    for (int d = 0; d < n_inputs; ++d) dim_dom[d] = cmp_domain == XHIST_CMP_I64 ? 1 : 0;
   int64_t max_e = 0;
   for (int d = 0; d < n_inputs; ++d) {
     if (!edges[d]) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL", d);
@@ -155,7 +173,7 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
       return fail(XHIST_ERR_UNSUPPORTED, "edges[%d] has %lld edges; this build supports at most 2^30 per dimension", d,
                   (long long)n_edges[d]);
     max_e = std::max(max_e, n_edges[d]);
-    if (cmp_domain == XHIST_CMP_F64) {
+    if (dim_dom[d] == 0) {
       const double* e = static_cast<const double*>(edges[d]);
       for (int64_t j = 0; j < n_edges[d]; ++j) {
         if (e[j] != e[j]) return fail(XHIST_ERR_EDGES, "edges[%d] contains NaN", d);
@@ -210,12 +228,13 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   // the linear in-bucket count may read up to 4 entries past a bucket's start unconditionally
   const uint64_t kNaN64 = 0x7ff8000000000000ull;
   for (int d = 0; d < n_inputs; ++d)
-    for (int k = 0; k < 4; ++k) words[d].push_back(cmp_domain == XHIST_CMP_F64 ? kNaN64 : 0x7fffffffffffffffull);
+    for (int k = 0; k < 4; ++k) words[d].push_back(dim_dom[d] == 0 ? kNaN64 : 0x7fffffffffffffffull);
   // more than 65535 edges in some dimension: only the native set, without bucket tables (the vector
   // family then runs table-free on arithmetic edges, everything else takes the generic family)
   p->huge = max_e > 65535;
   const bool vector_sets = cmp_domain == XHIST_CMP_F64 && !p->huge;
-  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0]);
+  int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0],
+                        mixed ? dim_dom : nullptr);
   if (rc == XHIST_OK && vector_sets) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
   if (rc == XHIST_OK && vector_sets) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)

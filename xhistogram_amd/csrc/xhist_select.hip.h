@@ -195,6 +195,11 @@ static kernel_fn generic_kernel(int cmp, bool weighted, bool lds) {
     if (weighted) return lds ? (kernel_fn)hist_generic<0, true, true> : (kernel_fn)hist_generic<0, true, false>;
     return lds ? (kernel_fn)hist_generic<0, false, true> : (kernel_fn)hist_generic<0, false, false>;
   }
-  if (weighted) return lds ? (kernel_fn)hist_generic<1, true, true> : (kernel_fn)hist_generic<1, true, false>;
-  return lds ? (kernel_fn)hist_generic<1, false, true> : (kernel_fn)hist_generic<1, false, false>;
+  if (cmp == XHIST_CMP_I64) {
+    if (weighted) return lds ? (kernel_fn)hist_generic<1, true, true> : (kernel_fn)hist_generic<1, true, false>;
+    return lds ? (kernel_fn)hist_generic<1, false, true> : (kernel_fn)hist_generic<1, false, false>;
+  }
+  // per-input domains (XHIST_CMP_PER_DIM | mask)
+  if (weighted) return lds ? (kernel_fn)hist_generic<3, true, true> : (kernel_fn)hist_generic<3, true, false>;
+  return lds ? (kernel_fn)hist_generic<3, false, true> : (kernel_fn)hist_generic<3, false, false>;
 }
