@@ -59,6 +59,10 @@ typedef enum { XHIST_CMP_F64 = 0, XHIST_CMP_I64 = 1 } xhist_cmp_domain;
  * bit d of mask set <=> input d compares in int64 (its edge array is int64), else in float64.
  * numpy digitizes every argument on its own (core.py:163-174), so such mixtures are legal there. */
 #define XHIST_CMP_PER_DIM 0x100
+/* OR-ed onto XHIST_CMP_I64 / XHIST_CMP_PER_DIM: the int64-domain inputs are UNSIGNED 64-bit — their
+ * edge arrays hold uint64 values and their samples (uint8..uint64, bool) compare as unsigned
+ * (numpy: uint64 data against uint64 edges). */
+#define XHIST_CMP_UNSIGNED 0x200
 typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1 } xhist_mem_kind;
 
 /* A logical [M, C] array addressed as data[row_offset(r) + c * col_stride] (strides in ELEMENTS):

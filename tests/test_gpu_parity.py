@@ -615,6 +615,33 @@ def test_per_input_compare_domains_datetime_and_int64_next_to_floats(xh, residen
     np.testing.assert_array_equal(got, onp.bincount_rows([f, big, f], [f_edges, big_edges, f_edges]))
 
 
+def test_unsigned_64_bit_samples_and_edges(xh):
+    """uint64 data against uint64 edges (numpy compares them as uint64): values on both sides of 2^63"""
+    rng = np.random.default_rng(57)
+    base = np.uint64((1 << 63) - 20)
+    x = (base + rng.integers(0, 60, (2, 40_000)).astype(np.uint64)).astype(np.uint64)
+    x[0, :5] = [0, 1, np.iinfo(np.uint64).max, (1 << 63) - 1, 1 << 63]
+    edges = [(base + np.arange(0, 50, 3).astype(np.uint64)).astype(np.uint64)]
+    assert edges[0][0] < (1 << 63) < edges[0][-1]
+    want = onp.bincount_rows([x], edges)
+    got, desc = _run(xh, [x], edges, None, False)
+    assert "cmp=i64" in desc, desc
+    np.testing.assert_array_equal(got, want)
+    w = rng.uniform(0, 1, x.shape)
+    assert_hist_equal(_run(xh, [x], edges, w, False)[0], onp.bincount_rows([x], edges, w), True)
+    # smaller unsigned samples against uint64 edges, next to a float input
+    s8 = rng.integers(0, 256, (2, 40_000)).astype(np.uint8)
+    e8 = [np.arange(0, 300, 7).astype(np.uint64)]
+    np.testing.assert_array_equal(_run(xh, [s8], e8, None, False)[0], onp.bincount_rows([s8], e8))
+    f = rng.standard_normal((2, 40_000))
+    ef = np.linspace(-2, 2, 6)
+    got, desc = _run(xh, [f, x], [ef, edges[0]], None, False)
+    assert "cmp=per-input" in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([f, x], [ef, edges[0]]))
+    h, _ = xh.histogram(x, bins=edges[0], axis=1)
+    np.testing.assert_array_equal(h, onp.histogram(x, bins=edges[0], axis=1)[0])
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

@@ -91,8 +91,12 @@ def test_compare_domain_follows_numpy_promotion():
         core._compare_domain([np.dtype(np.complex128)], [e_f])
     with pytest.raises(TypeError):
         core._compare_domain([np.dtype("datetime64[ns]")], [e_f])
-    with pytest.raises(NotImplementedError):
-        core._compare_domain([np.dtype(np.uint64)], [e_i.astype(np.uint64)])
+    # unsigned 64-bit on both sides: the int64 domain with the sign bit flipped
+    dom, conv, _ = core._compare_domain([np.dtype(np.uint64)], [e_i.astype(np.uint64)])
+    assert dom == (_native.CMP_I64 | _native.CMP_UNSIGNED) and conv[0].dtype == np.uint64
+    assert core._compare_domain([u8, f64], [e_i.astype(np.uint64), e_f])[0] == (_native.CMP_PER_DIM | 0b01 | _native.CMP_UNSIGNED)
+    with pytest.raises(NotImplementedError):  # one signedness per plan
+        core._compare_domain([np.dtype(np.uint64), i64], [e_i.astype(np.uint64), e_i])
 
 
 def test_axis_and_argument_errors_raise_before_compute():

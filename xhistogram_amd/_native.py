@@ -28,6 +28,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_EDGES =
 F64, F32, F16, I64, I32, I16, I8, U64, U32, U16, U8, BOOL = range(12)
 CMP_F64, CMP_I64 = 0, 1
 CMP_PER_DIM = 0x100  # | mask: bit d set <=> input d compares in int64 (XHIST_CMP_PER_DIM)
+CMP_UNSIGNED = 0x200  # | onto CMP_I64 / CMP_PER_DIM: the int64-domain inputs are unsigned 64-bit (edges passed as uint64)
 MEM_HOST, MEM_DEVICE = 0, 1
 
 _NP_TAG = {
@@ -163,10 +164,13 @@ class Plan:
         lib = load()
         self.device = int(device)
         self.cmp = int(cmp_domain)
+        base = self.cmp & ~CMP_UNSIGNED
+        int_t = np.uint64 if self.cmp & CMP_UNSIGNED else np.int64
+
         def want(d):
-            if (self.cmp & ~0xff) == CMP_PER_DIM:
-                return np.int64 if (self.cmp >> d) & 1 else np.float64
-            return np.int64 if self.cmp == CMP_I64 else np.float64
+            if (base & ~0xff) == CMP_PER_DIM:
+                return int_t if (base >> d) & 1 else np.float64
+            return int_t if base == CMP_I64 else np.float64
         self._edges = [np.ascontiguousarray(e, dtype=want(d)) for d, e in enumerate(edges)]
         for e in self._edges:
             if e.ndim != 1:

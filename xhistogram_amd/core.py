@@ -143,13 +143,25 @@ def _compare_domain(sample_dtypes, edges):
             conv.append(e.astype(np.float64))
             doms.append((_native.CMP_F64, None))
         elif common == np.dtype(np.uint64):
-            raise NotImplementedError("uint64 samples against uint64 edges need a uint64 compare domain")
+            # unsigned on both sides: the int64 domain with the sign bit flipped (CMP_UNSIGNED)
+            conv.append(e.astype(np.uint64))
+            doms.append((_native.CMP_I64, "unsigned"))
         else:
             conv.append(e.astype(np.int64))
             doms.append((_native.CMP_I64, None))
     # Integer samples of at most 32 bits against integer edges within +-2^53: both sides are exact
     # in float64, so the comparison may run there — which is where the vector kernels are
     # (`bins=np.arange(257)` on uint8 / int32 data: 3-4x the generic int64 family).
+    unsigned = [c == "unsigned" for _, c in doms]
+    doms = [(d, None if c == "unsigned" else c) for d, c in doms]
+    if any(unsigned):
+        # one flag per plan: every int64-domain input must then be unsigned
+        if any(d == _native.CMP_I64 and not u for (d, _), u in zip(doms, unsigned)):
+            raise NotImplementedError("uint64 inputs together with signed 64-bit integer / datetime inputs")
+        mask = sum(1 << k for k, (d, _) in enumerate(doms) if d == _native.CMP_I64)
+        full = mask == (1 << len(doms)) - 1
+        return (_native.CMP_I64 if full else _native.CMP_PER_DIM | mask) | _native.CMP_UNSIGNED, conv, [None] * len(doms)
+
     def small_exact(k):
         d, common = doms[k]
         e = np.asarray(edges[k])

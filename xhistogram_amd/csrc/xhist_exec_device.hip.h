@@ -17,8 +17,12 @@ static int validate_arrays(const xhist_plan* p, const xhist_array* samples, cons
     if (samples[d].row_stride < 0 || samples[d].col_stride < 0 || samples[d].inner_rows < 0 || samples[d].outer_stride < 0)
       return fail(XHIST_ERR_UNSUPPORTED, "negative strides are not supported; pass a contiguous copy");
     const bool int_dim = p->cmp == XHIST_CMP_I64 || ((p->cmp & ~0xff) == XHIST_CMP_PER_DIM && ((p->cmp >> d) & 1));
-    if (int_dim && (!dtype_is_int(samples[d].dtype) || samples[d].dtype == XHIST_U64))
-      return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", samples[d].dtype);
+    const int sdt_d = samples[d].dtype;
+    const bool unsigned_dt = sdt_d == XHIST_U64 || sdt_d == XHIST_U32 || sdt_d == XHIST_U16 || sdt_d == XHIST_U8 || sdt_d == XHIST_BOOL;
+    if (int_dim && p->uns && !unsigned_dt)
+      return fail(XHIST_ERR_UNSUPPORTED, "unsigned int64 compare domain needs unsigned integer samples (got dtype tag %d)", sdt_d);
+    if (int_dim && !p->uns && (!dtype_is_int(sdt_d) || sdt_d == XHIST_U64))
+      return fail(XHIST_ERR_UNSUPPORTED, "int64 compare domain needs signed/small integer samples (got dtype tag %d)", sdt_d);
   }
   if (weights) {
     if (!empty && !weights->data) return fail(XHIST_ERR_INVALID, "weights.data is NULL");

@@ -78,6 +78,7 @@ struct xhist_plan {
   //             [0: (start | cnt << 16) uint32 buckets, 1: uint16 start-only buckets on a 2x finer
   //                 grid for the linear-scan kernels (float domains only)]
   TableSet ts[2][2];
+  bool uns = false;    // the int64-domain inputs hold unsigned 64-bit values (XHIST_CMP_UNSIGNED)
   bool huge = false;   // some dimension has more than 65535 edges: no bucket tables (lut_k = 0)
   bool arith = false;  // every dimension has arithmetic (numpy.linspace) edges: table-free digitize available
   int64_t n_bins = 0;

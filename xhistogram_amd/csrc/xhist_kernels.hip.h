@@ -54,6 +54,7 @@ struct DimTable {
   double step, inv_step;
   int32_t arith;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
+  int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
 
 struct Params {
@@ -301,7 +302,8 @@ __device__ __forceinline__ OUT load_as(const void* p, int32_t dt, int64_t i) {
 // a sample in its compare domain; per-dimension domains (3) carry an int64 or the bits of a float64
 template <int CMP>
 __device__ __forceinline__ typename Dom<CMP>::T load_dom(const void* p, int32_t dt, int64_t i, const DimTable& t) {
-  if constexpr (CMP == 3) return t.is_i64 ? load_as<int64_t>(p, dt, i) : __double_as_longlong(load_as<double>(p, dt, i));
+  if constexpr (CMP == 3) return t.is_i64 ? (load_as<int64_t>(p, dt, i) ^ t.xor_bias) : __double_as_longlong(load_as<double>(p, dt, i));
+  else if constexpr (CMP == 1) return load_as<int64_t>(p, dt, i) ^ t.xor_bias;
   else return load_as<typename Dom<CMP>::T>(p, dt, i);
 }
 

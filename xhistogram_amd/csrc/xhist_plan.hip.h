@@ -153,6 +153,8 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   // per-input domains: bit d of the mask = input d compares in int64; uniform masks are the plain domains
   int dim_dom[XHIST_MAX_DIMS] = {0};
   bool mixed = false;
+  const bool uns = (cmp_domain & XHIST_CMP_UNSIGNED) != 0;  // int64-domain inputs hold unsigned values
+  cmp_domain &= ~XHIST_CMP_UNSIGNED;
   if ((cmp_domain & ~0xff) == XHIST_CMP_PER_DIM) {
     const int mask = cmp_domain & 0xff;
     if (mask >> n_inputs) return fail(XHIST_ERR_INVALID, "per-input compare mask 0x%x names inputs beyond the %d given", mask, n_inputs);
@@ -179,6 +181,10 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
         if (e[j] != e[j]) return fail(XHIST_ERR_EDGES, "edges[%d] contains NaN", d);
         if (j && e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
       }
+    } else if (uns) {
+      const uint64_t* e = static_cast<const uint64_t*>(edges[d]);
+      for (int64_t j = 1; j < n_edges[d]; ++j)
+        if (e[j] < e[j - 1]) return fail(XHIST_ERR_EDGES, "bins must increase monotonically (edges[%d])", d);
     } else {
       const int64_t* e = static_cast<const int64_t*>(edges[d]);
       for (int64_t j = 1; j < n_edges[d]; ++j)
@@ -217,6 +223,21 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     n_bins *= nb;
   }
   p->n_bins = n_bins;
+  // unsigned int64-domain inputs: flipping the sign bit of edges (here) and samples (load_dom) maps
+  // the uint64 order onto the int64 order every kernel compares in
+  p->uns = uns;
+  std::vector<std::vector<uint64_t>> biased(n_inputs);
+  const void* eff[XHIST_MAX_DIMS];
+  for (int d = 0; d < n_inputs; ++d) {
+    eff[d] = edges[d];
+    if (uns && dim_dom[d] == 1) {
+      const uint64_t* e = static_cast<const uint64_t*>(edges[d]);
+      biased[d].resize((size_t)n_edges[d]);
+      for (int64_t j = 0; j < n_edges[d]; ++j) biased[d][(size_t)j] = e[j] ^ 0x8000000000000000ull;
+      eff[d] = biased[d].data();
+    }
+  }
+  edges = eff;  // from here on: the arrays in the domain the kernels compare in
   std::vector<std::vector<uint64_t>> words(n_inputs);
   std::vector<double> lo(n_inputs), hi(n_inputs);
   for (int d = 0; d < n_inputs; ++d) {
@@ -260,6 +281,9 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     delete p;
     return rc;
   }
+  if (uns)
+    for (int d = 0; d < n_inputs; ++d)
+      if (dim_dom[d] == 1) p->ts[0][0].dim[d].xor_bias = (int64_t)0x8000000000000000ull;
   // ---- arithmetic edges: e_j == fl(fl(j * step) + e_0) for every j < nb, step = (e_nb - e_0) / nb ----
   // (what numpy.linspace / histogram_bin_edges produce for `bins=int`).  Checked edge by edge with the
   // two roundings kept apart (volatile product: no fma contraction), and only when bins are well
