@@ -53,7 +53,7 @@ def cases(draw):
     density = draw(st.booleans())
     seed = draw(st.integers(0, 2**31 - 1))
     resident = draw(st.booleans())
-    override = draw(st.sampled_from([None, "force_global", "force_generic", "lds_copies"]))
+    override = draw(st.sampled_from([None, "force_global", "force_generic", "lds_copies", "arith", "arith"]))
     return d, shape, axis, dtype, edges, wshape, density, seed, resident, override
 
 
