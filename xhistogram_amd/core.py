@@ -233,13 +233,15 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
     _native.require_device(device)
     plan = _get_plan(edges, cmp_domain, device)
 
+    # the library zero-initialises (overwrites) the output itself: no fill here, which for torch
+    # would be one more kernel launch per call
     out_shape = (nrows,) + plan.bins_shape
     if backend == "numpy":
-        out = np.zeros(out_shape, dtype=np.float64 if weighted else np.int64)
+        out = np.empty(out_shape, dtype=np.float64 if weighted else np.int64)
         out_ptr = out.ctypes.data
         empty = out.size == 0
     else:
-        out = torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=like.device)
+        out = torch.empty(out_shape, dtype=torch.float64 if weighted else torch.int64, device=like.device)
         out_ptr = out.data_ptr()
         empty = out.numel() == 0
     if empty:
