@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 2
+#define XHIST_ABI_VERSION 3
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -113,6 +113,16 @@ int xhist_plan_destroy(xhist_plan* plan);
 int xhist_plan_execute(xhist_plan* plan, const xhist_array* samples, const xhist_array* weights,
                        int64_t n_rows, int64_t n_cols, void* out, int out_dtype, int mem_kind,
                        int accumulate, void* stream);
+
+/* Two weight arrays binned in ONE pass over the samples: out_a = histogram weighted by weights_a,
+ * out_b by weights_b (both float64 [n_rows, prod(nb_d)]).  The idiom behind it is the ratio of two
+ * histograms, "mean of A in the bins of x" = hist(x, weights=A*w) / hist(x, weights=w): the
+ * reference runs the whole path twice (its own TODO, xarray.py:106); here the samples are read and
+ * digitized once when the arrays are device-resident and the vector kernels apply, and the call
+ * degrades to two xhist_plan_execute passes otherwise — same results either way. */
+int xhist_plan_execute_two_weights(xhist_plan* plan, const xhist_array* samples, const xhist_array* weights_a,
+                                   const xhist_array* weights_b, int64_t n_rows, int64_t n_cols, void* out_a,
+                                   void* out_b, int mem_kind, int accumulate, void* stream);
 
 /* One-shot form of the two calls above with an internal plan cache keyed on (device, edges). */
 int xhist_bincount_rows(int device, int n_inputs, const xhist_array* samples,

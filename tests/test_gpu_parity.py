@@ -642,6 +642,47 @@ def test_unsigned_64_bit_samples_and_edges(xh):
     np.testing.assert_array_equal(h, onp.histogram(x, bins=edges[0], axis=1)[0])
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_two_weight_arrays_in_one_pass(xh, resident):
+    """histogram_two_weights == two weighted histograms; device-resident float inputs share one pass"""
+    rng = np.random.default_rng(56)
+    conv = _dev if resident else (lambda a: a)
+
+    def check(args, bins, wa, wb, axis=None, expect_fused=None):
+        ha, hb, edges = xh.histogram_two_weights(*[conv(a) for a in args], bins=bins, weights=(conv(wa), conv(wb)), axis=axis)
+        if resident:
+            ha, hb = ha.cpu().numpy(), hb.cpu().numpy()
+        ra, _ = onp.histogram(*args, bins=bins, weights=wa, axis=axis)
+        rb, _ = onp.histogram(*args, bins=bins, weights=wb, axis=axis)
+        assert ha.shape == ra.shape and hb.shape == rb.shape
+        assert_hist_equal(ha, ra, True)
+        assert_hist_equal(hb, rb, True)
+        if expect_fused is not None and resident:
+            plan = _plan_for(xh, [conv(a) for a in args], [np.asarray(e) for e in edges])
+            assert ("weights=2" in plan.describe()) == expect_fused, plan.describe()
+
+    x = rng.standard_normal(700_001)
+    x[::1001] = np.nan
+    a = rng.uniform(-2, 3, x.shape)
+    w = rng.uniform(0, 1, x.shape)
+    e = np.linspace(-4, 4, 101)
+    check([x], e, a * w, w, expect_fused=True)                                   # the mean-in-bins idiom, C2 shape
+    check([x.astype(np.float32)], e, (a * w).astype(np.float32), w.astype(np.float32), expect_fused=True)
+    y = rng.standard_normal(x.shape)
+    check([x, y], [np.linspace(-4, 4, 33), _nonuniform_edges(rng, 41)], a, w, expect_fused=True)
+    t = rng.standard_normal((5, 7, 3001))
+    wt = rng.uniform(0, 1, t.shape)
+    check([t], np.linspace(-3, 3, 21), wt, wt * t, axis=2)                          # rows
+    check([t], np.linspace(-3, 3, 21), wt, wt * t, axis=(1, 2))
+    check([t], np.linspace(-3, 3, 21), wt[:1], wt, axis=0)                          # broadcast first weights, leading axis
+    # no fused kernel: integer samples, a histogram beyond LDS, different weight dtypes -> two passes, same answer
+    check([rng.integers(0, 50, 100_000).astype(np.int32)], np.arange(51), w[:100_000], a[:100_000], expect_fused=False)
+    check([x[:200_000], y[:200_000]], [np.linspace(-4, 4, 301)] * 2, a[:200_000], w[:200_000], expect_fused=False)
+    check([x[:100_000]], e, a[:100_000].astype(np.float32), w[:100_000], expect_fused=False)
+    with pytest.raises(ValueError):
+        xh.histogram_two_weights(conv(x), bins=e, weights=(conv(w),))
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

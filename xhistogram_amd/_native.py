@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -66,7 +66,7 @@ _lock = threading.Lock()
 
 EXPORTS = (
     "xhist_abi_version", "xhist_last_error", "xhist_device_count", "xhist_device_info",
-    "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_bincount_rows",
+    "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
     "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_shutdown",
 )
@@ -95,6 +95,10 @@ def load():
         lib.xhist_plan_execute.argtypes = [
             C.c_void_p, C.POINTER(XhistArray), C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
             C.c_int, C.c_void_p,
+        ]
+        lib.xhist_plan_execute_two_weights.argtypes = [
+            C.c_void_p, C.POINTER(XhistArray), C.POINTER(XhistArray), C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_int, C.c_void_p,
         ]
         lib.xhist_bincount_rows.argtypes = [
             C.c_int, C.c_int, C.POINTER(XhistArray), C.POINTER(XhistArray), C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
@@ -224,6 +228,22 @@ class Plan:
             load().xhist_plan_execute(
                 self._h, arr, w, int(n_rows), int(n_cols), C.c_void_p(out_ptr), F64 if weighted else I64, int(mem_kind),
                 1 if accumulate else 0, C.c_void_p(stream or 0),
+            )
+        )
+
+
+    def execute_two_weights(self, sample_views, wa_view, wb_view, n_rows, n_cols, out_a_ptr, out_b_ptr, mem_kind,
+                            accumulate=False, stream=0):
+        """two float64 histograms [n_rows, bins] of the same samples, weighted by wa / wb, in one pass
+        when the fused kernel applies (xhist_plan_execute_two_weights)"""
+        d = self.n_dims
+        if len(sample_views) != d:
+            raise ValueError("plan was built for %d inputs, got %d" % (d, len(sample_views)))
+        arr = (XhistArray * d)(*sample_views)
+        check(
+            load().xhist_plan_execute_two_weights(
+                self._h, arr, C.byref(wa_view), C.byref(wb_view), int(n_rows), int(n_cols), C.c_void_p(out_a_ptr),
+                C.c_void_p(out_b_ptr), int(mem_kind), 1 if accumulate else 0, C.c_void_p(stream or 0),
             )
         )
 

@@ -28,7 +28,7 @@ from . import _native
 # range is a keyword of histogram(), like in the reference
 _range = range
 
-__all__ = ["histogram"]
+__all__ = ["histogram", "histogram_two_weights"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -214,9 +214,10 @@ def _strided_view(a2d, backend):
     return a2d.ctypes.data, _native.dtype_tag(a2d.dtype), rs, cs, 0, 0, a2d
 
 
-def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, like, block_size):
+def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, like, block_size, wview2=None):
     """Hand [rows, cols] views (ptr, tag, row stride, col stride, rows per group, group stride,
-    keepalive) to the native library and return the [rows, nb_0, ...] histogram."""
+    keepalive) to the native library and return the [rows, nb_0, ...] histogram.  With ``wview2``
+    (a second weight view): a [2, rows, nb_0, ...] pair from one pass (histogram_two_weights)."""
     cmp_domain, edges, _ = _compare_domain(sample_dtypes, bins)
     weighted = wview is not None
     if backend == "numpy":
@@ -235,7 +236,7 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
 
     # the library zero-initialises (overwrites) the output itself: no fill here, which for torch
     # would be one more kernel launch per call
-    out_shape = (nrows,) + plan.bins_shape
+    out_shape = ((2,) if wview2 is not None else ()) + (nrows,) + plan.bins_shape
     if backend == "numpy":
         out = np.empty(out_shape, dtype=np.float64 if weighted else np.int64)
         out_ptr = out.ctypes.data
@@ -247,7 +248,7 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
     if empty:
         return out
 
-    grouped = any(v[4] for v in views) or (weighted and wview[4])
+    grouped = any(v[4] for v in views) or (weighted and wview[4]) or (wview2 is not None and wview2[4])
     if block_size in (None, "auto") or grouped:
         row_blocks = [(0, nrows)]
     else:
@@ -263,6 +264,12 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
 
     row_bytes = plan.n_bins * 8
     for r0, r1 in row_blocks:
+        if wview2 is not None:
+            plan.execute_two_weights(
+                [shifted(v, r0) for v in views], shifted(wview, r0), shifted(wview2, r0), r1 - r0, ncols,
+                out_ptr + r0 * row_bytes, out_ptr + (nrows + r0) * row_bytes, mem, accumulate=False, stream=stream,
+            )
+            continue
         plan.execute(
             [shifted(v, r0) for v in views],
             shifted(wview, r0) if weighted else None,
@@ -431,7 +438,7 @@ def _view_of(a, desc, backend, both_strided_limit=1 << 16):
     return a.ctypes.data, _native.dtype_tag(a.dtype), rs, cs, ir, os_, a
 
 
-def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
+def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
     """Block adapter with the reference's contract (core.py:197-247): N-D block(s) in, array of
     shape kept-axes (1 for each reduced axis) + bin dims out.  Called directly for numpy/torch
     inputs and once per block by the dask branch (core.py:429-437).
@@ -450,27 +457,37 @@ def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, bl
         kept_axes_shape = tuple(int(a0.shape[i]) if i not in axis else 1 for i in _range(ndim))
 
     arrays = list(all_arrays)
+    w2_array = arrays.pop() if second_weights else None  # histogram_two_weights (extension)
     w_array = arrays.pop() if weights else None
     n_inputs = len(arrays)
     dtypes = [_np_dtype_of(a) for a in arrays]
     arrays, w_array = _prepare_dtypes(arrays, w_array, dtypes, bins, backend)
+    if second_weights and (w2_array.dtype.is_complex if backend == "torch" else w2_array.dtype.kind == "c"):
+        raise TypeError("complex weights are not supported")
+    w_list = ([w_array] if weights else []) + ([w2_array] if second_weights else [])
 
     counts = None
     order = _reduced_order(arrays[0], list(_range(ndim)) if do_full_array else axis)
-    descs = [_collapse(a, axis, do_full_array, order) for a in arrays + ([w_array] if weights else [])]
+    descs = [_collapse(a, axis, do_full_array, order) for a in arrays + w_list]
     if all(d is not None for d in descs) and len({d[:2] for d in descs}) == 1:
-        views = [_view_of(a, d, backend) for a, d in zip(arrays + ([w_array] if weights else []), descs)]
+        views = [_view_of(a, d, backend) for a, d in zip(arrays + w_list, descs)]
         if all(v is not None for v in views):
             m, c = descs[0][:2]
             try:
                 counts = _execute_views(views[:n_inputs], views[n_inputs] if weights else None, int(m), int(c), dtypes, bins,
-                                        backend, a0, block_size)
+                                        backend, a0, block_size, wview2=views[n_inputs + 1] if second_weights else None)
             except NotImplementedError:
                 counts = None  # e.g. a host view spanning > 2^32 elements: take the copying route
     if counts is None:
-        blocks = [_rows_cols(a, axis, do_full_array) for a in arrays + ([w_array] if weights else [])]
-        weights_block = blocks.pop() if weights else None
-        counts = _bincount_2d_vectorized(*blocks, bins=bins, weights=weights_block, density=density, block_size=block_size)
+        blocks = [_rows_cols(a, axis, do_full_array) for a in arrays + w_list]
+        if second_weights:  # the copying route: two passes
+            pair = [_bincount_2d_vectorized(*blocks[:n_inputs], bins=bins, weights=wb, block_size=block_size) for wb in blocks[n_inputs:]]
+            counts = _torch().stack(pair) if backend == "torch" else np.stack(pair)
+        else:
+            weights_block = blocks.pop() if weights else None
+            counts = _bincount_2d_vectorized(*blocks, bins=bins, weights=weights_block, density=density, block_size=block_size)
+    if second_weights:
+        return counts.reshape((2,) + kept_axes_shape + tuple(counts.shape[2:]))
     return counts.reshape(kept_axes_shape + tuple(counts.shape[1:]))
 
 
@@ -555,7 +572,27 @@ def _density(counts, bins, n_inputs):
         return counts / areas / np.reshape(sums, sums.shape + n_inputs * (1,))
 
 
-def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto"):
+def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None, block_size="auto"):
+    """Two weighted histograms of the same data from ONE pass over it (an extension; the reference
+    leaves it as a TODO at xarray.py:106 and runs the path once per weight array).
+
+    ``weights`` is a pair ``(wa, wb)``; everything else is as in :func:`histogram`.  Returns
+    ``(ha, hb, bins)`` with ``ha == histogram(*args, weights=wa, ...)[0]`` and likewise ``hb``.  The
+    idiom: the mean of ``A`` in the bins of ``x`` is ``ha / hb`` for ``wa = A * w``, ``wb = w``.
+    Device-resident float32/float64 inputs with histograms that fit LDS share one read and one
+    digitize of the samples; every other case degrades to two passes with identical results."""
+    if weights is None or len(weights) != 2:
+        raise ValueError("weights must be a pair of arrays")
+    wa, wb = weights
+    if any(_is_dask(a) for a in list(args) + [wa, wb]):
+        ha, bins_out = histogram(*args, bins=bins, range=range, axis=axis, weights=wa, block_size=block_size)
+        hb, _ = histogram(*args, bins=bins_out, axis=axis, weights=wb, block_size=block_size)
+        return ha, hb, bins_out
+    ha, bins_out = histogram(*args, bins=bins, range=range, axis=axis, weights=wa, block_size=block_size, _second_weights=wb)
+    return ha[0], ha[1], bins_out
+
+
+def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", _second_weights=None):
     """Histogram applied along specified axis / axes, computed on an MI355X.
 
     Same signature, argument meaning, return value and error behaviour as
@@ -606,6 +643,9 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     has_weights = weights is not None
     if has_weights:
         all_arrays.append(weights)
+    two = _second_weights is not None  # histogram_two_weights: the second weight array rides along
+    if two:
+        all_arrays.append(_second_weights)
 
     # ---- bring every input to one backend and broadcast (core.py:366) -------------------------
     if is_dask_array:
@@ -636,7 +676,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         bins = [_device_bin_edges(a, b, r, has_weights) for a, b, r in zip(all_arrays, bins, range)]
     else:
         bins = [
-            np.histogram_bin_edges(a, bins=b, range=r, weights=all_arrays[-1] if has_weights else None)
+            np.histogram_bin_edges(a, bins=b, range=r, weights=all_arrays[n_inputs] if has_weights else None)
             for a, b, r in zip(all_arrays, bins, range)
         ]
     bincount_kwargs = dict(weights=has_weights, axis=axis, bins=bins, density=density, block_size=block_size)
@@ -663,8 +703,10 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         )
         bin_counts = bin_counts.sum(drop_axes)
     else:
+        if two:
+            bincount_kwargs["second_weights"] = True
         bin_counts = _bincount(*all_arrays, **bincount_kwargs)
-        squeeze_axes = tuple(int(i) for i in drop_axes)
+        squeeze_axes = tuple(int(i) + (1 if two else 0) for i in drop_axes)  # (two: a leading pair axis)
         if backend == "torch":
             keep = [s for i, s in enumerate(bin_counts.shape) if i not in squeeze_axes]
             bin_counts = bin_counts.reshape(keep)

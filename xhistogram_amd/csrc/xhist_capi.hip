@@ -195,6 +195,24 @@ extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, con
   return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s);
 }
 
+extern "C" int xhist_plan_execute_two_weights(xhist_plan* p, const xhist_array* samples, const xhist_array* weights_a,
+                                              const xhist_array* weights_b, int64_t n_rows, int64_t n_cols, void* out_a,
+                                              void* out_b, int mem_kind, int accumulate, void* stream) {
+  if (!weights_a || !weights_b) return fail(XHIST_ERR_INVALID, "two weight arrays are required");
+  if (int rc = validate_arrays(p, samples, weights_a, n_rows, n_cols, out_a, XHIST_F64)) return rc;
+  if (int rc = validate_arrays(p, samples, weights_b, n_rows, n_cols, out_b, XHIST_F64)) return rc;
+  if (mem_kind != XHIST_MEM_HOST && mem_kind != XHIST_MEM_DEVICE) return fail(XHIST_ERR_INVALID, "unknown mem_kind %d", mem_kind);
+  if (mem_kind == XHIST_MEM_DEVICE) {
+    DeviceGuard g;
+    if (int rc = g.set(p->device)) return rc;
+    const int rc = execute_device(p, samples, weights_a, n_rows, n_cols, out_a, accumulate, static_cast<hipStream_t>(stream),
+                                  weights_b, out_b);
+    if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED: no fused kernel for this case, nothing written yet
+  }
+  if (int rc = xhist_plan_execute(p, samples, weights_a, n_rows, n_cols, out_a, XHIST_F64, mem_kind, accumulate, stream)) return rc;
+  return xhist_plan_execute(p, samples, weights_b, n_rows, n_cols, out_b, XHIST_F64, mem_kind, accumulate, stream);
+}
+
 // ------------------------------------------------------------------------------------------
 // one-shot form with a plan cache
 // ------------------------------------------------------------------------------------------

@@ -368,15 +368,23 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   return release(XHIST_OK);
 }
 
+// weights2 / out2 (optional): a second weight array binned in the same pass (hist_fast<..., W2>).
+// Only the vector family with LDS histograms does that; anything else returns
+// XHIST_ERR_UNSUPPORTED before touching the outputs, and the caller runs two passes.
 static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
-                          int64_t n_cols, void* out, int accumulate, hipStream_t stream) {
+                          int64_t n_cols, void* out, int accumulate, hipStream_t stream,
+                          const xhist_array* weights2 = nullptr, void* out2 = nullptr) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
+  const bool two = weights2 != nullptr;
   const int64_t out_elems = n_rows * p->n_bins;
   if (out_elems == 0) return XHIST_OK;
   if (n_cols == 0) {
-    if (!accumulate)
+    if (!accumulate) {
       if (int zrc = zero_output(out, out_elems, stream)) return zrc;
+      if (two)
+        if (int zrc = zero_output(out2, out_elems, stream)) return zrc;
+    }
     return XHIST_OK;
   }
 
@@ -389,11 +397,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
-  if (lanes >= 0 && !force_generic && !force_global) {
+  if (lanes >= 0 && !force_generic && !force_global && !two) {
     const int rc = execute_lanes(p, samples, weights, n_rows, n_cols, out, accumulate, stream, lanes > 0, profile);
     if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED = not this shape, fall through
   }
-  if (!accumulate)
+  if (!accumulate && !two)  // (two weights: zeroed below, once the fused kernel is known to apply)
     if (int zrc = zero_output(out, out_elems, stream)) return zrc;
 
   // ---- family: fast (vector loads, homogeneous f64/f32) or generic --------------------------
@@ -423,7 +431,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const TableSet* tset = nullptr;
   size_t table_bytes = 0, hist_bytes = 0, lds_bytes = 0;
   kernel_fn fn = nullptr;
-  const int acc_size = weighted ? 8 : 4;
+  const int acc_size = (weighted ? 8 : 4) * (two ? 2 : 1);  // two weights: two replicated histograms side by side
   const int max_cl2 = weighted ? 4 : 5;
   // histogram placement for a given table footprint:
   //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
@@ -486,7 +494,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     tables_in_lds = tables_fit;
     lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
     // (scan 1..4: linear in-bucket count, no bucket holds more than 4 edges — always for uniform bins)
+    if (two) {  // one attempt only: the vector family, LDS histograms, table digitize with <= 2 edges per bucket
+      if (!fast || hist != kHistLds || (scan != 1 && scan != 2) || !float_samples || weights2->dtype != wdt ||
+          weights2->col_stride != 1 || ((uintptr_t)weights2->data % (size_t)dtype_size(wdt)) != 0)
+        return XHIST_ERR_UNSUPPORTED;
+      fn = fast_kernel_two_weights(sdt, wdt, D, scan, &vec);
+      if (!fn) return XHIST_ERR_UNSUPPORTED;
+      break;
+    }
     fn = fast ? fast_kernel(sdt, wdt, D, scan, hist, &vec) : generic_kernel(p->cmp, weighted, lds_hist);
+  }
+  if (two && !accumulate) {
+    if (int zrc = zero_output(out, out_elems, stream)) return zrc;
+    if (int zrc = zero_output(out2, out_elems, stream)) return zrc;
   }
   if (!fn) return fail(XHIST_ERR_HIP, "internal: no kernel for this combination");
   if (!fast) vec = 1;
@@ -494,7 +514,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
 
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
   // (a few long rows — e.g. one joint histogram per time step — run it row by row)
-  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64) {
+  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64 && !two) {
     const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
@@ -599,6 +619,13 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         kp.w_os = weights->outer_stride;
         kp.w_dt = weights->dtype;
       }
+      if (two) {
+        kp.w2_ptr = advance(weights2->data, weights2->dtype, c0);
+        kp.w2_rs = weights2->row_stride;
+        kp.w2_ir = weights2->inner_rows;
+        kp.w2_os = weights2->outer_stride;
+        kp.out2 = static_cast<char*>(out2) + (size_t)r0 * p->n_bins * 8;
+      }
       kp.row0 = r0;
       kp.n_dims = D;
       kp.tables = tset->blob;
@@ -618,11 +645,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       if (first_launch) {
         snprintf(desc, sizeof desc,
                  "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
-                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu",
+                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu%s",
                  fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
                  fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
                  table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
-                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : (p->cmp == XHIST_CMP_F64 ? "f64" : "per-input")), lds_cap);
+                 use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : (p->cmp == XHIST_CMP_F64 ? "f64" : "per-input")), lds_cap,
+                 two ? " weights=2" : "");
       }
       first_launch = false;
       r0 += nr;

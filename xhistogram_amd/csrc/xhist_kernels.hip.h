@@ -71,6 +71,10 @@ struct Params {
   const void* w_ptr;       // nullptr = unweighted
   int64_t w_rs, w_cs, w_ir, w_os;
   int32_t w_dt;
+  // second weight array of the two-weight variant (same dtype, unit column stride) and its histogram
+  const void* w2_ptr;
+  int64_t w2_rs, w2_ir, w2_os;
+  void* out2;
   int64_t row0;            // first logical row of this launch (inputs only; `out` is pre-advanced)
   int32_t n_dims;
   DimTable dim[kMaxDims];
@@ -406,9 +410,13 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
 constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 
 // SCAN: 1..4 = linear in-bucket count over at most SCAN edges (count_le_scan), 0 = binary search
-template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN>
+// W2: two weight arrays binned in ONE pass over the samples ("mean of A in the bins of x" =
+//     sum(A w) / sum(w)): a second replicated LDS histogram, written to p.out2 — the samples are
+//     read and digitized once instead of twice (reference TODO, xarray.py:106)
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
+  static_assert(!W2 || (HIST == kHistLds && !__is_same(WT, NoWeight)), "two weights: weighted, LDS histograms");
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
   constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
@@ -434,8 +442,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   const uint32_t mycopy = (uint32_t)tid & cmask;
   const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
   uint32_t* packed = reinterpret_cast<uint32_t*>(hist);
+  const uint32_t hist_elems = ((uint32_t)p.n_bins + 1u) << p.copies_log2;  // one replicated histogram (+ trash slots)
+  lds_t* hist2 = hist + hist_elems;                                          // W2: the second weight's
   if (LDS_HIST) {
-    const uint32_t n = ((uint32_t)p.n_bins + 1u) << p.copies_log2;
+    const uint32_t n = hist_elems * (W2 ? 2u : 1u);
     for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
   }
   if (HIST == kHistPacked) {
@@ -450,16 +460,20 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]) + row_offset(p.row0 + row, p.s_rs[d], p.s_ir[d], p.s_os[d]);
   const wscalar* wp = nullptr;
   if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os);
+  const wscalar* wp2 = nullptr;
+  if (W2) wp2 = reinterpret_cast<const wscalar*>(p.w2_ptr) + row_offset(p.row0 + row, p.w2_rs, p.w2_ir, p.w2_os);
   out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
+  out_t* out2 = W2 ? reinterpret_cast<out_t*>(p.out2) + row * p.n_bins : nullptr;
 
   // D == 1 fast scatter (see the tile loop): this lane's copy of bin -1, and its trash slot
   const uint32_t slot_shift = (uint32_t)p.copies_log2 + (sizeof(lds_t) == 8 ? 3u : 2u);
   unsigned char* slot_base = reinterpret_cast<unsigned char*>(hist + mycopy) - ((size_t)1 << slot_shift);
   lds_t* trash_slot = hist + trash;
-  auto scatter = [&](bool ok, uint32_t flat, double w) {
+  auto scatter = [&](bool ok, uint32_t flat, double w, double w2) {
     if (LDS_HIST) {
       const uint32_t idx = ok ? ((flat << p.copies_log2) + mycopy) : trash;
       A::lds_add(hist, idx, w);
+      if constexpr (W2) A::lds_add(hist2, idx, w2);
     } else if (ok) {
       if (kWeighted) A::out_add(out, (int64_t)flat, w);
       else A::out_add(out, (int64_t)flat, 1);
@@ -494,7 +508,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   for (int64_t tile = seg; tile < n_tiles; tile += p.segs) {
     const int64_t base = tile * tile_elems;
     svec xv[D][UNROLL];
-    wvec wv[UNROLL];
+    wvec wv[UNROLL], wv2[UNROLL];
     uint32_t past_end = 0;  // bit (u * VEC + v): that sample lies beyond the row (ragged tile only)
     static_assert(UNROLL * VEC <= 32, "past_end is a 32-bit mask");
     if (base + tile_elems <= p.n_cols) {
@@ -505,6 +519,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
         for (int d = 0; d < D; ++d)
           xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(sp[d] + i));
         if (kWeighted) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + i));
+        if (W2) wv2[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp2 + i));
       }
     } else {
       // ragged last tile (for a short row: the whole row): vectors that fit are loaded whole, the
@@ -517,6 +532,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
           for (int d = 0; d < D; ++d) xv[d][u] = *reinterpret_cast<const svec*>(sp[d] + i);
           if (kWeighted) wv[u] = *reinterpret_cast<const wvec*>(wp + i);
+          if (W2) wv2[u] = *reinterpret_cast<const wvec*>(wp2 + i);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
@@ -524,6 +540,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
             for (int d = 0; d < D; ++d) xv[d][u][v] = in ? sp[d][i + v] : kPastEnd;
             if (kWeighted) wv[u][v] = in ? wp[i + v] : (wscalar)0;
+            if (W2) wv2[u][v] = in ? wp2[i + v] : (wscalar)0;
             if (!in) past_end |= 1u << (u * VEC + v);  // integer samples have no NaN: masked below
           }
         }
@@ -546,8 +563,12 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
                              (kFloatSamples || !((past_end >> (u * VEC + v)) & 1u));
             const uint32_t off = min(cnt[0][u][v], (uint32_t)p.dim[0].nb) << slot_shift;
             lds_t* slot = ok1 ? reinterpret_cast<lds_t*>(slot_base + off) : trash_slot;
-            if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
-            else atomicAdd(reinterpret_cast<uint32_t*>(slot), 1u);
+            if (kWeighted) {
+              unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
+              if constexpr (W2) unsafeAtomicAdd(reinterpret_cast<double*>(slot) + hist_elems, (double)wv2[u][v]);
+            } else {
+              atomicAdd(reinterpret_cast<uint32_t*>(slot), 1u);
+            }
             continue;
           }
           bool ok = kFloatSamples || !((past_end >> (u * VEC + v)) & 1u);
@@ -566,7 +587,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
             flatv[u][v] = flat;
             oldv[u][v] = packed_add(ok, flat);
           } else {
-            scatter(ok, flat, kWeighted ? (double)wv[u][v] : 0.0);
+            scatter(ok, flat, kWeighted ? (double)wv[u][v] : 0.0, W2 ? (double)wv2[u][v] : 0.0);
           }
         }
       if (HIST == kHistPacked) {  // all returning adds are in flight before the first check
@@ -597,6 +618,11 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
       for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
       if (sum != 0) A::out_add(out, (int64_t)b, sum);
+      if constexpr (W2) {
+        double sum2 = 0;
+        for (uint32_t c = 0; c < copies; ++c) sum2 += hist2[(b << p.copies_log2) + ((c + tid) & cmask)];
+        if (sum2 != 0) A::out_add(out2, (int64_t)b, sum2);
+      }
     }
   }
 }

@@ -171,6 +171,37 @@ static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* v
   }
 }
 
+// two weight arrays in one pass (hist_fast<..., W2 = true>): float samples, one weight dtype for
+// both arrays, LDS histograms, bucket tables with 1 or 2 edges per bucket
+template <typename ST, typename WT, int D>
+static kernel_fn two_weights_pick(int scan) {
+  constexpr int wsz = (int)sizeof(WT);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  if (scan == 1) return (kernel_fn)hist_fast<ST, WT, D, VEC, unroll_for(D, VEC, 1), kHistLds, 1, true>;
+  if (scan == 2) return (kernel_fn)hist_fast<ST, WT, D, VEC, unroll_for(D, VEC, 2), kHistLds, 2, true>;
+  return nullptr;
+}
+
+template <typename ST, typename WT>
+static kernel_fn two_weights_pick_d(int D, int scan) {
+  switch (D) {
+    case 1: return two_weights_pick<ST, WT, 1>(scan);
+    case 2: return two_weights_pick<ST, WT, 2>(scan);
+    case 3: return two_weights_pick<ST, WT, 3>(scan);
+    default: return nullptr;
+  }
+}
+
+static kernel_fn fast_kernel_two_weights(int sdt, int wdt, int D, int scan, int* vec) {
+  const int ssz = dtype_size(sdt), wsz = dtype_size(wdt);
+  *vec = 16 / std::max(ssz, wsz);
+  if (sdt == XHIST_F64 && wdt == XHIST_F64) return two_weights_pick_d<double, double>(D, scan);
+  if (sdt == XHIST_F64 && wdt == XHIST_F32) return two_weights_pick_d<double, float>(D, scan);
+  if (sdt == XHIST_F32 && wdt == XHIST_F64) return two_weights_pick_d<float, double>(D, scan);
+  if (sdt == XHIST_F32 && wdt == XHIST_F32) return two_weights_pick_d<float, float>(D, scan);
+  return nullptr;
+}
+
 typedef void (*kernel_fn_rows1)(const Params, int32_t);
 
 template <typename ST>
