@@ -546,11 +546,22 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
   // (profiles/r01_a_sweep.jsonl) the streaming rate peaks at ~64 KiB of outstanding loads per CU
   // (f64+weights: 2 x 256 threads x 128 B; f64: 4 x 256 x 64 B) and falls by 5-10% with more.
-  // big LDS footprints leave room for one or two workgroups per CU; within-box sweeps: 512 threads
-  // for the replicated/plain LDS histograms (2.43-2.47 ms against 2.50-2.55 at 1024 for 10^9 x 2
-  // f64), 768 = three wavefronts per SIMD for the packed-uint16 one (C3: 2.45 against 2.54 at 1024,
-  // 2.86 at 512)
-  int block = block_threads ? block_threads : (lds_bytes > 40 * 1024 ? (hist == kHistPacked ? 768 : 512) : 256);
+  int64_t lane_bytes = 0;
+  for (int d = 0; d < D; ++d) lane_bytes += dtype_size(samples[d].dtype);
+  if (weighted) lane_bytes += dtype_size(weights->dtype);
+  if (two) lane_bytes += dtype_size(weights->dtype);
+  lane_bytes *= fast ? (int64_t)vec * kUnroll : 4;
+  int block = block_threads ? block_threads : 256;
+  if (!block_threads && lds_bytes > 40 * 1024) {
+    // one to three workgroups fit a CU: make them carry the ~64 KiB of loads in flight together
+    // (2 x f64 with 128 B per lane: 512 threads; 2 x f32 with 64 B per lane and 88 KB of LDS:
+    // 1024 — 4.85 TB/s at 512).  The packed-uint16 histogram waits on returning atomics and wants
+    // half as much again (C3: 768).
+    const int fit = (int)std::max<int64_t>(1, std::min<int64_t>(3, (int64_t)(160 * 1024 / lds_bytes)));
+    int64_t want = (64 * 1024) / (fit * std::max<int64_t>(lane_bytes, 1));
+    if (hist == kHistPacked) want += want / 2;
+    block = (int)std::min<int64_t>(1024, std::max<int64_t>(256, (want + 255) / 256 * 256));
+  }
   if (!block_threads && n_rows > 1 && lds_bytes <= 40 * 1024) {
     // many rows, one workgroup each: a tile should be ~1/4 of the row or most of the workgroup
     // idles in the ragged tile (100k rows x 3650: 0.46 -> 0.39 ms; 356k x 1024: 1.3 -> 0.58 ms)
@@ -559,10 +570,6 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     block = 64;
     while (block < 256 && block * 2 <= want) block *= 2;
   }
-  int64_t lane_bytes = 0;
-  for (int d = 0; d < D; ++d) lane_bytes += dtype_size(samples[d].dtype);
-  if (weighted) lane_bytes += dtype_size(weights->dtype);
-  lane_bytes *= fast ? (int64_t)vec * kUnroll : 4;
   int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
   bpc = std::min<int>(bpc, 2048 / block);
   if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
