@@ -141,6 +141,7 @@ int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_col
  *       "partition" (0 auto / 1 prefer / -1 never: multi-pass mode for histograms beyond LDS),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
+ *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
  *       "lds_copies" (0 = auto), "profile" (0 = off, R = keep the last R kernel timings) */
 int xhist_plan_set_param(xhist_plan* plan, const char* key, int64_t value);
 /* human-readable description of the last launch (kernel family, LDS bytes, copies, grid...) */

@@ -537,6 +537,42 @@ def test_partitioned_mode_more_than_128_partitions(xh, weighted):
     assert_hist_equal(got, want, weighted)
 
 
+@pytest.mark.parametrize("case", ["w_f32_200x200", "u_f64_300x300", "w_1d_50000_arith", "u_3d_f32", "rows_40"])
+def test_bin_slices_for_histograms_of_a_few_times_lds(xh, case):
+    """histograms of a few times the LDS capacity: S launches, each keeping one slice of the bins in LDS"""
+    rng = np.random.default_rng(46)
+    n = 400_000
+    if case == "w_f32_200x200":
+        s = [rng.standard_normal((2, n)).astype(np.float32), (rng.standard_normal((2, n)) * 1.2).astype(np.float32)]
+        edges = [np.linspace(-4, 4, 201), _nonuniform_edges(rng, 201)]
+        w = rng.uniform(0, 1, (2, n)).astype(np.float32)
+    elif case == "u_f64_300x300":
+        s = [rng.standard_normal((1, n)), rng.uniform(-4.5, 4.5, (1, n))]
+        edges = [np.linspace(-4, 4, 301), np.linspace(-4, 4, 301)]
+        w = None
+    elif case == "w_1d_50000_arith":
+        edges = [np.linspace(-3, 3, 50_001)]
+        s = [_edge_torture(edges[0], rng, n)]
+        w = rng.uniform(-1, 1, s[0].shape)
+    elif case == "u_3d_f32":
+        s = [rng.standard_normal((3, n)).astype(np.float32) for _ in range(3)]
+        edges = [np.linspace(-3, 3, 61), np.linspace(-3, 3, 51), np.linspace(-3, 3, 41)]  # 122400 bins
+        w = None
+    else:  # many rows: not a shape the partitioned mode takes
+        s = [rng.standard_normal((40, 30_000)), rng.standard_normal((40, 30_000))]
+        edges = [np.linspace(-4, 4, 181), np.linspace(-4, 4, 161)]
+        w = rng.uniform(0, 1, (40, 30_000))
+    want = onp.bincount_rows(s, edges, w)
+    got, desc = _run(xh, s, edges, w, True)
+    n_slices = int(desc.split("slices=")[1].split()[0])
+    assert "family=fast" in desc and n_slices >= 2, desc
+    assert_hist_equal(got, want, w is not None)
+    assert_hist_equal(_run(xh, s, edges, w, False)[0], want, w is not None)            # host route
+    got, desc = _run(xh, s, edges, w, True, slices=-1)                                 # and without slices
+    assert "slices=1" in desc or "partitioned" in desc, desc
+    assert_hist_equal(got, want, w is not None)
+
+
 def test_partitioned_mode_a_few_long_rows(xh):
     """one beyond-LDS joint histogram per row (e.g. per time step): the partitioned mode row by row"""
     rng = np.random.default_rng(49)
@@ -1131,7 +1167,7 @@ def test_tables_too_large_for_lds_are_read_through_l2(xh):
 @pytest.mark.parametrize("weighted", [False, True])
 def test_more_than_65535_edges_per_dimension(xh, weighted):
     """no 16-bit table fields any more: arithmetic edges run table-free on the vector kernels
-    (global atomics below 4 M samples, the partitioned mode when forced), anything else binary-searches
+    (in bin slices here, the partitioned mode when forced), anything else binary-searches
     the whole edge array in the generic family"""
     rng = np.random.default_rng(98)
     e = np.linspace(-5, 5, 100_001)
@@ -1140,7 +1176,7 @@ def test_more_than_65535_edges_per_dimension(xh, weighted):
     w = rng.uniform(0, 1, x.shape) if weighted else None
     want = onp.bincount_rows([x], [e], w)
     got, desc = _run(xh, [x], [e], w, True)
-    assert "family=fast" in desc and "scan=5" in desc and "hist=global" in desc, desc
+    assert "family=fast" in desc and "scan=5" in desc and "slices=1" not in desc, desc  # 100000 bins: LDS bin slices
     assert_hist_equal(got, want, weighted)
     got, desc = _run(xh, [x], [e], w, True, partition=1)
     assert "hist=partitioned" in desc and "scan=5" in desc, desc

@@ -1,5 +1,7 @@
+"""Development tool: a typical ocean-model workload - joint T/S histograms per time step (32 rows x 3*10^7 f32 samples),
+unweighted and volume-weighted, for several bin counts; plus mean-T-in-S-bins with two weights in one pass."""
 import os, sys, json, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from xhistogram_amd import core, _native
 dev = torch.device("cuda", 0)

@@ -388,12 +388,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     return XHIST_OK;
   }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
-    lanes = p->lanes; arith_pref = p->arith_pref;
+    lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref;
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
@@ -445,16 +445,16 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       const size_t soft = 24 * 1024;  // replication is only worth LDS that small workgroups can share
       cl2 = max_cl2;
       if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
-      auto bytes_at = [&](int c) { return ((size_t)p->n_bins + 1) * ((size_t)acc_size << c); };
+      auto bytes_at = [&](int c) { return (((size_t)p->n_bins << c) + 32) * (size_t)acc_size; };  // + 32 trash slots
       if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
       while (cl2 > 0 && tbytes + bytes_at(cl2) > lds_cap) --cl2;
       if (tbytes + bytes_at(cl2) <= lds_cap) {
         hist = kHistLds;
         hist_bytes = bytes_at(cl2);
-      } else if (vector_family && float_samples && !weighted && tbytes + ((size_t)p->n_bins + 1) / 2 * 4 <= lds_cap) {
+      } else if (vector_family && float_samples && !weighted && tbytes + (((size_t)p->n_bins + 1) / 2 + 32) * 4 <= lds_cap) {
         hist = kHistPacked;
         cl2 = 0;
-        hist_bytes = ((size_t)p->n_bins + 1) / 2 * 4;
+        hist_bytes = (((size_t)p->n_bins + 1) / 2 + 32) * 4;
       }
     }
     if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
@@ -512,9 +512,46 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   if (!fast) vec = 1;
   const DimTable* dims = tset->dim;
 
+  // ---- a few times the LDS capacity: bin slices ---------------------------------------------------
+  // S launches, each streaming all samples and keeping 1/S of the bins in LDS (hist_fast<SLICED>),
+  // cost S x the streaming time at ~6.3 TB/s; the partitioned mode below moves B + 8 + 2 x record
+  // bytes per sample at ~5 TB/s and needs a few long rows.  200 x 200 weighted bins of f32 pairs:
+  // 9.3 ms partitioned -> 3 slices; 300 x 300 counts: 8.3 ms -> 2 slices of packed uint16 counters.
+  int n_slices = 1;
+  int64_t slice_bins = p->n_bins;
+  if (fast && float_samples && hist == kHistGlobal && !force_global && !two && slices_pref >= 0 && p->n_bins < ((int64_t)1 << 24) &&
+      (scan == 1 || scan == 2 || scan == kScanArith) && table_bytes + 4096 < lds_cap) {
+    const size_t budget = lds_cap - table_bytes - 2048;
+    const int64_t cap = weighted ? (int64_t)(budget / 8) - 32 : (((int64_t)(budget / 2) - 66) & ~(int64_t)1);
+    const int64_t S = (p->n_bins + cap - 1) / cap;
+    int64_t B = 0;
+    for (int d = 0; d < D; ++d) B += dtype_size(samples[d].dtype);
+    if (weighted) B += dtype_size(weights->dtype);
+    const int64_t rec = 2 + (weighted ? 8 : 0);
+    const int part_shift = weighted ? 14 : 15;
+    const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) &&
+                         ((p->n_bins + ((int64_t)1 << part_shift) - 1) >> part_shift) <= kPartMaxParts;
+    const bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 4 * S * B <= 5 * (B + 8 + 2 * rec) : S <= 16));
+    if (choose && S >= 1) {
+      const int shist = weighted ? kHistLds : kHistPacked;
+      kernel_fn sfn = fast_kernel_sliced(sdt, wdt, D, scan, shist, &vec);
+      if (sfn) {
+        fn = sfn;
+        hist = shist;
+        cl2 = 0;
+        n_slices = (int)S;
+        slice_bins = ((p->n_bins + S - 1) / S + 1) & ~(int64_t)1;  // even: packed counters pair up inside a slice
+        hist_bytes = weighted ? ((size_t)slice_bins + 32) * 8 : (((size_t)slice_bins + 1) / 2 + 32) * 4;
+        lds_hist = hist == kHistLds;
+        tables_in_lds = true;
+        lds_bytes = table_bytes + hist_bytes;
+      }
+    }
+  }
+
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
   // (a few long rows — e.g. one joint histogram per time step — run it row by row)
-  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64 && !two) {
+  if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64 && !two && n_slices == 1) {
     const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
     const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
@@ -647,17 +684,21 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       const dim3 grid((unsigned)(nr * segs));
       if (first_launch)
         if (int rrc = rec.begin(profile)) return rrc;
-      hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
-      HIPC(hipGetLastError());
+      for (int sl = 0; sl < n_slices; ++sl) {  // (one launch unless the histogram is built in bin slices)
+        kp.slice_lo = (int64_t)sl * slice_bins;
+        kp.slice_n = (int32_t)std::min<int64_t>(slice_bins, p->n_bins - kp.slice_lo);
+        hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
+        HIPC(hipGetLastError());
+      }
       if (first_launch) {
         snprintf(desc, sizeof desc,
                  "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
-                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu%s",
+                 "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu%s slices=%d",
                  fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
                  fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
                  table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
                  use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : (p->cmp == XHIST_CMP_F64 ? "f64" : "per-input")), lds_cap,
-                 two ? " weights=2" : "");
+                 two ? " weights=2" : "", n_slices);
       }
       first_launch = false;
       r0 += nr;

@@ -75,6 +75,9 @@ struct Params {
   const void* w2_ptr;
   int64_t w2_rs, w2_ir, w2_os;
   void* out2;
+  // bin slice of the SLICED variant: this launch accumulates flat bins [slice_lo, slice_lo + slice_n) only
+  int64_t slice_lo;
+  int32_t slice_n;
   int64_t row0;            // first logical row of this launch (inputs only; `out` is pre-advanced)
   int32_t n_dims;
   DimTable dim[kMaxDims];
@@ -413,9 +416,14 @@ constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 // W2: two weight arrays binned in ONE pass over the samples ("mean of A in the bins of x" =
 //     sum(A w) / sum(w)): a second replicated LDS histogram, written to p.out2 — the samples are
 //     read and digitized once instead of twice (reference TODO, xarray.py:106)
-template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false>
+// SLICED: a histogram of up to a few times the LDS capacity is built in several launches, each
+//     streaming ALL samples but keeping only the flat bins [slice_lo, slice_lo + slice_n) in LDS
+//     (the rest go to the trash slot).  S passes cost S x the streaming time; the partitioned mode
+//     moves ~3-4x the algorithmic bytes, so slices win up to S = 3-4 and work for any number of rows.
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false, bool SLICED = false>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
+  static_assert(!SLICED || HIST != kHistGlobal, "slices are for LDS-resident histograms");
   static_assert(!W2 || (HIST == kHistLds && !__is_same(WT, NoWeight)), "two weights: weighted, LDS histograms");
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
   constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
@@ -440,17 +448,21 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem + (size_t)p.table_words * 8);
   const uint32_t cmask = (1u << p.copies_log2) - 1u;
   const uint32_t mycopy = (uint32_t)tid & cmask;
-  const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
+  const uint32_t hb = SLICED ? (uint32_t)p.slice_n : (uint32_t)p.n_bins;  // bins resident in LDS
+  // samples the reference drops (out of range, NaN) still issue their LDS atomic, on one of 32 trash
+  // slots picked by lane: with a single copy they would otherwise all meet on ONE address and
+  // serialise (10^9 samples, 90 % out of range: 4.9 ms against 2.4)
+  const uint32_t trash = (hb << p.copies_log2) + ((uint32_t)tid & 31u);
   uint32_t* packed = reinterpret_cast<uint32_t*>(hist);
-  const uint32_t hist_elems = ((uint32_t)p.n_bins + 1u) << p.copies_log2;  // one replicated histogram (+ trash slots)
+  const uint32_t hist_elems = (hb << p.copies_log2) + 32u;  // one replicated histogram (+ trash slots)
   lds_t* hist2 = hist + hist_elems;                                          // W2: the second weight's
   if (LDS_HIST) {
     const uint32_t n = hist_elems * (W2 ? 2u : 1u);
     for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
   }
+  const uint32_t packed_words = (hb + 1u) >> 1;  // + 32 trash words
   if (HIST == kHistPacked) {
-    const uint32_t n = ((uint32_t)p.n_bins + 1u) >> 1;
-    for (uint32_t i = tid; i < n; i += blockDim.x) packed[i] = 0u;
+    for (uint32_t i = tid; i < packed_words + 32u; i += blockDim.x) packed[i] = 0u;
   }
   __syncthreads();
 
@@ -462,8 +474,8 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os);
   const wscalar* wp2 = nullptr;
   if (W2) wp2 = reinterpret_cast<const wscalar*>(p.w2_ptr) + row_offset(p.row0 + row, p.w2_rs, p.w2_ir, p.w2_os);
-  out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins;
-  out_t* out2 = W2 ? reinterpret_cast<out_t*>(p.out2) + row * p.n_bins : nullptr;
+  out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins + (SLICED ? p.slice_lo : 0);  // bin 0 of the slice
+  out_t* out2 = W2 ? reinterpret_cast<out_t*>(p.out2) + row * p.n_bins + (SLICED ? p.slice_lo : 0) : nullptr;
 
   // D == 1 fast scatter (see the tile loop): this lane's copy of bin -1, and its trash slot
   const uint32_t slot_shift = (uint32_t)p.copies_log2 + (sizeof(lds_t) == 8 ? 3u : 2u);
@@ -471,9 +483,15 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   lds_t* trash_slot = hist + trash;
   auto scatter = [&](bool ok, uint32_t flat, double w, double w2) {
     if (LDS_HIST) {
-      const uint32_t idx = ok ? ((flat << p.copies_log2) + mycopy) : trash;
-      A::lds_add(hist, idx, w);
-      if constexpr (W2) A::lds_add(hist2, idx, w2);
+      if constexpr (SLICED) {
+        // most samples belong to other slices: a shared trash slot would serialise their atomics
+        // on one address, so they are predicated off instead
+        if (ok) A::lds_add(hist, (flat << p.copies_log2) + mycopy, w);
+      } else {
+        const uint32_t idx = ok ? ((flat << p.copies_log2) + mycopy) : trash;
+        A::lds_add(hist, idx, w);
+        if constexpr (W2) A::lds_add(hist2, idx, w2);
+      }
     } else if (ok) {
       if (kWeighted) A::out_add(out, (int64_t)flat, w);
       else A::out_add(out, (int64_t)flat, 1);
@@ -481,7 +499,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   };
   // packed mode, step 1: returning add of 1 into the sample's 16-bit half (0 for a dropped sample)
   auto packed_add = [&](bool ok, uint32_t flat) -> uint32_t {
-    const uint32_t idx = ok ? (flat >> 1) : 0u;
+    if constexpr (SLICED) {
+      if (!ok) return 0u;  // (see scatter: no shared dummy address for the samples of other slices)
+    }
+    const uint32_t idx = ok ? (flat >> 1) : packed_words + ((uint32_t)tid & 31u);
     const uint32_t inc = ok ? (1u << ((flat & 1u) << 4)) : 0u;
     return atomicAdd(packed + idx, inc);
   };
@@ -492,7 +513,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     const uint32_t half = hi ? (old >> 16) : (old & 0xffffu);
     if (half == 0xffffu) {
       atomicAdd(reinterpret_cast<unsigned long long*>(out) + flat, 65536ull);
-      if (!hi && (int64_t)flat + 1 < p.n_bins) {  // the carry landed in the neighbour's half
+      if (!hi && flat + 1u < hb) {  // the carry landed in the neighbour's half
         unsigned long long fix = ~0ull;            // -1
         if ((old >> 16) == 0xffffu) fix += 65536ull;  // ...and wrapped it too
         atomicAdd(reinterpret_cast<unsigned long long*>(out) + flat + 1, fix);
@@ -555,7 +576,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          if constexpr (D == 1 && LDS_HIST) {
+          if constexpr (D == 1 && LDS_HIST && !SLICED) {
             // one input, LDS histogram: the slot address comes straight from the edge count
             //   bin = min(cnt, nb) - 1  ->  byte offset (min(cnt, nb) << sh) from a base moved back
             //   by one bin; out-of-range / NaN / past-the-end samples go to the lane's trash slot
@@ -582,6 +603,10 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
             else if (HIST != kHistGlobal) flat = __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;  // full-rate mad_u24
             else flat = flat * (uint32_t)p.dim[d].nb + (uint32_t)b;
           }
+          if constexpr (SLICED) {  // keep only this launch's bins; from here on `flat` is relative to the slice
+            flat -= (uint32_t)p.slice_lo;
+            ok &= flat < hb;
+          }
           if (HIST == kHistPacked) {
             okv[u][v] = ok;
             flatv[u][v] = flat;
@@ -601,12 +626,12 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 
   if (HIST == kHistPacked) {
     __syncthreads();
-    const uint32_t n = ((uint32_t)p.n_bins + 1u) >> 1;
+    const uint32_t n = (hb + 1u) >> 1;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
       const uint32_t word = packed[i];
       const uint32_t lo = word & 0xffffu, hi = word >> 16;
       if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * (int64_t)i, (unsigned long long)lo);
-      if (hi && 2 * (int64_t)i + 1 < p.n_bins)
+      if (hi && 2 * i + 1u < hb)
         atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * (int64_t)i + 1, (unsigned long long)hi);
     }
   }
@@ -614,7 +639,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   if (LDS_HIST) {
     __syncthreads();
     const uint32_t copies = 1u << p.copies_log2;
-    for (uint32_t b = tid; b < (uint32_t)p.n_bins; b += blockDim.x) {
+    for (uint32_t b = tid; b < hb; b += blockDim.x) {
       typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
       for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
       if (sum != 0) A::out_add(out, (int64_t)b, sum);
@@ -652,9 +677,9 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
   lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem + hist_off);
   const uint32_t cmask = (1u << p.copies_log2) - 1u;
   const uint32_t mycopy = (uint32_t)tid & cmask;
-  const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + mycopy;
+  const uint32_t trash = ((uint32_t)p.n_bins << p.copies_log2) + ((uint32_t)tid & 31u);  // 32 trash slots, see hist_fast
   if (LDS_HIST) {
-    const uint32_t n = ((uint32_t)p.n_bins + 1u) << p.copies_log2;
+    const uint32_t n = ((uint32_t)p.n_bins << p.copies_log2) + 32u;
     for (uint32_t i = tid; i < n; i += blockDim.x) hist[i] = (lds_t)0;
   }
   __syncthreads();

@@ -351,6 +351,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lanes")) {
     p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "slices")) {
+    p->slices_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "arith")) {
     p->arith_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {

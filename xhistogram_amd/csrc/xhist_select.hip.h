@@ -171,6 +171,53 @@ static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* v
   }
 }
 
+// bin slices (hist_fast<..., SLICED = true>): float samples, LDS or packed-uint16 histograms, table
+// digitize with <= 2 edges per bucket or arithmetic edges
+template <typename ST, typename WT, int D, int SCAN>
+static kernel_fn sliced_pick(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  constexpr int U = unroll_for(D, VEC, SCAN);
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN, false, true>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN, false, true>;
+  }
+  return nullptr;
+}
+
+template <typename ST, typename WT>
+static kernel_fn sliced_pick_ds(int D, int scan, int hist) {
+#define XH_SLICED_CASE(DD)                                            \
+  case DD:                                                            \
+    if (scan == 1) return sliced_pick<ST, WT, DD, 1>(hist);           \
+    if (scan == 2) return sliced_pick<ST, WT, DD, 2>(hist);           \
+    if (scan == kScanArith) return sliced_pick<ST, WT, DD, kScanArith>(hist); \
+    return nullptr;
+  switch (D) {
+    XH_SLICED_CASE(1)
+    XH_SLICED_CASE(2)
+    XH_SLICED_CASE(3)
+    default: return nullptr;
+  }
+#undef XH_SLICED_CASE
+}
+
+static kernel_fn fast_kernel_sliced(int sdt, int wdt, int D, int scan, int hist, int* vec) {
+  const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
+  *vec = 16 / std::max(ssz, wsz);
+  if (sdt == XHIST_F64) {
+    if (wdt == -1) return sliced_pick_ds<double, NoWeight>(D, scan, hist);
+    if (wdt == XHIST_F64) return sliced_pick_ds<double, double>(D, scan, hist);
+    if (wdt == XHIST_F32) return sliced_pick_ds<double, float>(D, scan, hist);
+  } else if (sdt == XHIST_F32) {
+    if (wdt == -1) return sliced_pick_ds<float, NoWeight>(D, scan, hist);
+    if (wdt == XHIST_F64) return sliced_pick_ds<float, double>(D, scan, hist);
+    if (wdt == XHIST_F32) return sliced_pick_ds<float, float>(D, scan, hist);
+  }
+  return nullptr;
+}
+
 // two weight arrays in one pass (hist_fast<..., W2 = true>): float samples, one weight dtype for
 // both arrays, LDS histograms, bucket tables with 1 or 2 edges per bucket
 template <typename ST, typename WT, int D>
