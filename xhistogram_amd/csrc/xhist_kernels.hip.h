@@ -75,6 +75,7 @@ struct Params {
   const void* w2_ptr;
   int64_t w2_rs, w2_ir, w2_os;
   void* out2;
+  int32_t direct_store;    // hist_fast, LDS histograms: this workgroup is the only one of its row — store, do not add
   // bin slice of the SLICED variant: this launch accumulates flat bins [slice_lo, slice_lo + slice_n) only
   int64_t slice_lo;
   int32_t slice_n;
@@ -642,7 +643,8 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     for (uint32_t b = tid; b < hb; b += blockDim.x) {
       typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
       for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
-      if (sum != 0) A::out_add(out, (int64_t)b, sum);
+      if (p.direct_store) out[b] = (out_t)sum;  // the only workgroup of this row: plain store, zeros included
+      else if (sum != 0) A::out_add(out, (int64_t)b, sum);
       if constexpr (W2) {
         double sum2 = 0;
         for (uint32_t c = 0; c < copies; ++c) sum2 += hist2[(b << p.copies_log2) + ((c + tid) & cmask)];
