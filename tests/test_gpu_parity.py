@@ -900,7 +900,10 @@ def test_lanes_many_short_rows(xh, shape):
     want, _ = onp.histogram(x, bins=edges, axis=1, weights=w, density=True)
     got, _ = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w), density=True)
     desc = _describe_last(xh, [_dev(x[:1])], [edges])
-    assert "family=lanes" in desc and "transpose=1" in desc, desc  # weighted: transposed scratch + lanes
+    if shape[1] <= 80:
+        assert "family=lanes" in desc and "transpose=1" in desc, desc  # weighted, very short rows: transposed scratch + lanes
+    else:
+        assert "family=fast" in desc and "direct_store=1" in desc, desc  # one 64-thread workgroup per row, plain-store flush
     assert_hist_equal(got.cpu().numpy(), want, True)
     # host route reaches the same kernels through the staged copy
     np.testing.assert_array_equal(xh.histogram(x, bins=edges, axis=1)[0], onp.histogram(x, bins=edges, axis=1)[0])

@@ -206,10 +206,11 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   bool transpose = false;
   if (all_natural && (samples[0].row_stride == 1 || prefer)) {
     // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
-  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 896 : 384)))) {
-    // many short rows.  Measured crossovers with the row-streaming kernels at 64-thread workgroups
-    // (profiles/r01_f_shapes.jsonl): ~900 columns for the fused kernel (one unweighted input),
-    // ~400 for scratch-transpose + lanes
+  } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 400 : 80)))) {
+    // many short rows.  Measured crossovers with the row-streaming kernels (64-thread workgroups,
+    // few LDS copies, plain-store flush; 3.65 x 10^8 f32 samples): ~400 columns for the fused kernel
+    // (one unweighted input: 384 columns 0.64 against 0.67 ms, 512 columns 0.62 against 0.50), below
+    // ~90 for scratch-transpose + lanes (weighted, 96 columns: 3.6 against 3.3 ms)
     transpose = true;
   } else {
     return XHIST_ERR_UNSUPPORTED;
