@@ -719,6 +719,44 @@ def test_two_weight_arrays_in_one_pass(xh, resident):
         xh.histogram_two_weights(conv(x), bins=e, weights=(conv(w),))
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.int32])
+def test_device_min_max_feeding_integer_bins(xh, dt):
+    """bins=int without range on device data: the GPU min/max (vectorised for contiguous floats, generic
+    otherwise) must give numpy's edges bit for bit, NaN-propagating like numpy"""
+    from xhistogram_amd import _native
+
+    rng = np.random.default_rng(55)
+    for n in (1, 7, 4095, 4096, 4097, 1_000_003):
+        x = (rng.standard_normal(n) * 100).astype(dt)
+        if n > 10:
+            x[-3] = 12345 if dt == np.int32 else 1e6   # maximum in the ragged tail
+            x[1] = -54321 if dt == np.int32 else -1e7
+        v = _native.make_view(_dev(x).data_ptr(), _native.dtype_tag(np.dtype(dt)), n, 1)
+        t = _dev(x)
+        v = _native.make_view(t.data_ptr(), _native.dtype_tag(np.dtype(dt)), n, 1)
+        lo, hi = _native.minmax(v, 1, n, _native.MEM_DEVICE)
+        assert lo == float(x.min()) and hi == float(x.max()), (n, lo, hi)
+        h, e = xh.histogram(t, bins=13)
+        hr, er = np.histogram(x, bins=13)
+        np.testing.assert_array_equal(e[0], er)
+        np.testing.assert_array_equal(h.cpu().numpy(), hr)
+    if dt != np.int32:
+        x = rng.standard_normal(100_000).astype(dt)
+        x[99_999] = np.nan
+        t = _dev(x)
+        lo, hi = _native.minmax(_native.make_view(t.data_ptr(), _native.dtype_tag(np.dtype(dt)), x.size, 1), 1, x.size, _native.MEM_DEVICE)
+        assert np.isnan(lo) and np.isnan(hi)
+        x[99_999] = np.inf
+        x[5] = -np.inf
+        t = _dev(x)
+        lo, hi = _native.minmax(_native.make_view(t.data_ptr(), _native.dtype_tag(np.dtype(dt)), x.size, 1), 1, x.size, _native.MEM_DEVICE)
+        assert lo == -np.inf and hi == np.inf
+        # a strided (non-contiguous) view takes the generic kernel
+        s2 = _dev(rng.standard_normal((300, 40)).astype(dt))[:, ::3]
+        lo, hi = _native.minmax(_native.make_view(s2.data_ptr(), _native.dtype_tag(np.dtype(dt)), s2.stride(0), s2.stride(1)), 300, s2.shape[1], _native.MEM_DEVICE)
+        assert lo == float(s2.min()) and hi == float(s2.max())
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

@@ -288,8 +288,16 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
     return code;
   };
   if (hipMalloc(&d_part, sizeof(double) * 3 * grid) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc failed"));
-  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, view.inner_rows,
-                     view.outer_stride, n_rows, n_cols, d_part);
+  // contiguous float data (the usual `bins=int` on a whole array): the vectorised kernel
+  const bool flat = (view.dtype == XHIST_F64 || view.dtype == XHIST_F32) && view.inner_rows == 0 && (n_cols == 1 || view.col_stride == 1) &&
+                    (n_rows == 1 || view.row_stride == n_cols) && ((uintptr_t)view.data % (size_t)dtype_size(view.dtype)) == 0;
+  if (flat && view.dtype == XHIST_F64)
+    hipLaunchKernelGGL(minmax_flat<double>, dim3(grid), dim3(256), 0, s, (const double*)view.data, n_rows * n_cols, d_part);
+  else if (flat)
+    hipLaunchKernelGGL(minmax_flat<float>, dim3(grid), dim3(256), 0, s, (const float*)view.data, n_rows * n_cols, d_part);
+  else
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, view.inner_rows,
+                       view.outer_stride, n_rows, n_cols, d_part);
   std::vector<double> part(3 * grid);
   if (hipGetLastError() != hipSuccess ||
       hipMemcpyAsync(part.data(), d_part, sizeof(double) * 3 * grid, hipMemcpyDeviceToHost, s) != hipSuccess ||

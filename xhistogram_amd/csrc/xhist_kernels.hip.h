@@ -841,4 +841,54 @@ __global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt
   }
 }
 
+// contiguous float64 / float32 data: 16-byte non-temporal loads, 4 in flight per lane, comparisons
+// in the data's own type (exact); same partial[] layout as minmax_kernel
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_flat(const T* __restrict__ x, int64_t n, double* partial) {
+  constexpr int VEC = 16 / (int)sizeof(T), UNROLL = 4;
+  using vec_t = typename VecOf<T, VEC>::type;
+  T mn = (T)__builtin_huge_val(), mx = -(T)__builtin_huge_val();
+  int nan = 0;
+  const int64_t tile = (int64_t)blockDim.x * VEC * UNROLL;
+  const int64_t n_full = n / tile;
+  for (int64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
+    vec_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(x + t * tile + ((int64_t)u * blockDim.x + threadIdx.x) * VEC));
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T e = v[u][k];
+        nan |= (e != e);
+        mn = e < mn ? e : mn;  // (NaN compares false: skipped here, reported through `nan`)
+        mx = e > mx ? e : mx;
+      }
+  }
+  for (int64_t i = n_full * tile + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T e = x[i];
+    nan |= (e != e);
+    mn = e < mn ? e : mn;
+    mx = e > mx ? e : mx;
+  }
+  double dmn = (double)mn, dmx = (double)mx;
+  for (int off = 32; off > 0; off >>= 1) {
+    dmn = fmin(dmn, __shfl_down(dmn, off, 64));
+    dmx = fmax(dmx, __shfl_down(dmx, off, 64));
+    nan |= __shfl_down(nan, off, 64);
+  }
+  __shared__ double s_mn[4], s_mx[4];
+  __shared__ int s_nan[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_mn[wave] = dmn; s_mx[wave] = dmx; s_nan[wave] = nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { dmn = fmin(dmn, s_mn[w]); dmx = fmax(dmx, s_mx[w]); nan |= s_nan[w]; }
+    partial[3 * blockIdx.x + 0] = dmn;
+    partial[3 * blockIdx.x + 1] = dmx;
+    partial[3 * blockIdx.x + 2] = (double)nan;
+  }
+}
+
 }  // namespace xhist
