@@ -757,6 +757,48 @@ def test_device_min_max_feeding_integer_bins(xh, dt):
         assert lo == float(s2.min()) and hi == float(s2.max())
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_weights_broadcast_along_reduced_axes(xh, resident):
+    """cos(lat)-style weights: constant along some reduced axes -> counted unweighted over those axes,
+    weights applied to the counts; must equal the reference's materialised-weights result"""
+    rng = np.random.default_rng(54)
+    conv = _dev if resident else (lambda a: a)
+    t = rng.standard_normal((6, 40, 700))
+    t[0, 3, :5] = np.nan
+    e = np.linspace(-3, 3, 31)
+
+    def check(args, wts, axis, bins=e, density=False):
+        want, _ = onp.histogram(*args, bins=bins, weights=wts, axis=axis, density=density)
+        got, _ = xh.histogram(*[conv(a) for a in args], bins=bins, weights=conv(wts), axis=axis, density=density)
+        got = got.cpu().numpy() if resident else got
+        assert got.shape == want.shape and got.dtype == np.float64
+        assert_hist_equal(got, want, True)
+
+    w_lat = np.cos(np.linspace(-1.4, 1.4, 40)).reshape(1, 40, 1)
+    for axis in ((1, 2), None, (2,), (0, 2), (0, 1, 2)):
+        check([t], w_lat, axis)
+    check([t], w_lat, (1, 2), density=True)
+    check([t], rng.uniform(0, 2, (6, 1, 1)), (1, 2))          # one weight per kept row
+    check([t], rng.uniform(0, 2, (700,)), (1, 2))             # varies along the LAST axis only: counts over the middle one
+    check([t], np.float64(0.25) * np.ones((1, 1, 1)), None)   # a scalar weight
+    check([t.astype(np.float32)], w_lat.astype(np.float32), (1, 2))
+    u = rng.standard_normal(t.shape)
+    check([t, u], w_lat, (1, 2), bins=[np.linspace(-3, 3, 9), np.linspace(-3, 3, 7)])
+    # NaN / inf weights: only bins that received a sample of that weight are affected
+    w_bad = w_lat.copy()
+    w_bad[0, 5, 0] = np.nan
+    w_bad[0, 9, 0] = np.inf
+    narrow = t.copy()
+    narrow[:, 5, :] = 0.1    # latitude 5 only ever hits one bin
+    want, _ = onp.histogram(narrow, bins=e, weights=w_bad, axis=(1, 2))
+    got, _ = xh.histogram(conv(narrow), bins=e, weights=conv(w_bad), axis=(1, 2))
+    got = got.cpu().numpy() if resident else got
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-6)
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

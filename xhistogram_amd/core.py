@@ -572,6 +572,55 @@ def _density(counts, bins, n_inputs):
         return counts / areas / np.reshape(sums, sums.shape + n_inputs * (1,))
 
 
+def _weights_constant_along_reduced(args_b, w_raw, drop_axes, bins, block_size, backend):
+    """Weights that do not vary along some of the reduced axes (``cos(lat)`` of shape (1, lat, 1) under a
+    reduction over lat and lon; one weight per time step; ...): the reference materialises them at
+    full size (``broadcast_arrays`` + reshape, core.py:366 / 211-229).  Here the samples are COUNTED
+    over those axes, unweighted, and the weights are applied to the counts:
+
+        sum_{r0, r1} w[r1] [x in bin]  =  sum_{r1} w[r1] * count_{r0}[r1, bin]
+
+    which reads the data once and moves no weight array at all.  Bins nobody fell into get 0 whatever
+    their weight (a NaN weight poisons only bins that received a sample, as in np.bincount).
+    Returns the ``_bincount``-shaped result, or None when the rewrite does not apply / does not pay."""
+    shape = tuple(int(n) for n in args_b[0].shape)
+    nd = len(shape)
+    if w_raw is None or w_raw.ndim > nd:
+        return None
+    wshape = (1,) * (nd - w_raw.ndim) + tuple(int(n) for n in w_raw.shape)
+    cand = sorted(int(ax) for ax in drop_axes if wshape[ax] == 1 and shape[ax] > 1)
+    if not cand:
+        return None
+    # count over ONE block of adjacent axes (the one ending at the last candidate): adjacent axes walk
+    # memory as a single strided dimension, which the counting kernels take without a copy
+    r0 = [cand[-1]]
+    while r0[0] - 1 in cand:
+        r0.insert(0, r0[0] - 1)
+    r1 = [int(ax) for ax in drop_axes if int(ax) not in r0]
+    n_bins = 1
+    for b in bins:
+        n_bins *= max(len(b) - 1, 0)
+    cols = 1
+    for ax in r0:
+        cols *= shape[ax]
+    itemsize = sum(_np_dtype_of(a).itemsize for a in args_b)
+    if n_bins * 8 * 4 > cols * itemsize:  # the intermediate counts must stay small next to the data they summarise
+        return None
+    counts = _bincount(*args_b, weights=False, axis=sorted(r0), bins=bins, density=False, block_size=block_size)
+    tail = (1,) * len(bins)
+    if backend == "torch":
+        torch = _torch()
+        w = w_raw.reshape(wshape + tail).to(torch.float64)
+        contrib = torch.where(counts != 0, counts.to(torch.float64) * w, torch.zeros((), dtype=torch.float64, device=counts.device))
+        return contrib.sum(dim=r1, keepdim=True) if r1 else contrib
+    w = np.asarray(w_raw).reshape(wshape + tail)
+    if w.dtype.kind == "c":
+        return None  # let the regular path raise numpy's error
+    with np.errstate(invalid="ignore", over="ignore"):
+        contrib = np.where(counts != 0, counts.astype(np.float64) * w.astype(np.float64), 0.0)
+    return contrib.sum(axis=tuple(r1), keepdims=True) if r1 else contrib
+
+
 def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None, block_size="auto"):
     """Two weighted histograms of the same data from ONE pass over it (an extension; the reference
     leaves it as a TODO at xarray.py:106 and runs the path once per weight array).
@@ -658,10 +707,13 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         torch = _torch()
         dev = next(a.device for a in all_arrays if _is_torch(a) and a.device.type == "cuda")
         all_arrays = [a.to(dev) if _is_torch(a) else torch.as_tensor(np.asarray(a)).to(dev) for a in all_arrays]
+        w_raw = all_arrays[n_inputs] if has_weights else None  # as given, before broadcasting
         all_arrays = list(torch.broadcast_tensors(*all_arrays))
         backend = "torch"
     else:
-        all_arrays = list(np.broadcast_arrays(*[np.asarray(a) for a in all_arrays]))
+        all_arrays = [np.asarray(a) for a in all_arrays]
+        w_raw = all_arrays[n_inputs] if has_weights else None
+        all_arrays = list(np.broadcast_arrays(*all_arrays))
         backend = "numpy"
     input_axes = tuple(_range(all_arrays[0].ndim))
 
@@ -703,9 +755,13 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         )
         bin_counts = bin_counts.sum(drop_axes)
     else:
+        bin_counts = None
         if two:
             bincount_kwargs["second_weights"] = True
-        bin_counts = _bincount(*all_arrays, **bincount_kwargs)
+        elif has_weights:
+            bin_counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
+        if bin_counts is None:
+            bin_counts = _bincount(*all_arrays, **bincount_kwargs)
         squeeze_axes = tuple(int(i) + (1 if two else 0) for i in drop_axes)  # (two: a leading pair axis)
         if backend == "torch":
             keep = [s for i, s in enumerate(bin_counts.shape) if i not in squeeze_axes]
