@@ -799,6 +799,27 @@ def test_weights_broadcast_along_reduced_axes(xh, resident):
     np.testing.assert_allclose(got[ok], want[ok], rtol=1e-6)
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_non_adjacent_reduced_axes_in_two_steps(xh, resident):
+    """axis=(0, 2) of a 3-D array: histogram over the last block of adjacent axes, then sum the rest"""
+    rng = np.random.default_rng(53)
+    conv = _dev if resident else (lambda a: a)
+    t = rng.standard_normal((9, 30, 700))
+    q = rng.standard_normal((5, 8, 6, 300)).astype(np.float32)
+    e = np.linspace(-3, 3, 21)
+    for arr, axis in ((t, (0, 2)), (q, (0, 3)), (q, (1, 3)), (q, (0, 1, 3)), (q, (0, 2, 3))):
+        want, _ = onp.histogram(arr, bins=e, axis=axis)
+        got, _ = xh.histogram(conv(arr), bins=e, axis=axis)
+        got = got.cpu().numpy() if resident else got
+        assert got.dtype == np.int64
+        np.testing.assert_array_equal(got, want)
+        w = rng.uniform(0, 1, arr.shape)
+        want, _ = onp.histogram(arr, bins=e, axis=axis, weights=w, density=True)
+        got, _ = xh.histogram(conv(arr), bins=e, axis=axis, weights=conv(w), density=True)
+        got = got.cpu().numpy() if resident else got
+        assert_hist_equal(got, want, True)
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

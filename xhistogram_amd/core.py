@@ -572,6 +572,36 @@ def _density(counts, bins, n_inputs):
         return counts / areas / np.reshape(sums, sums.shape + n_inputs * (1,))
 
 
+def _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend):
+    """Reduced axes that are NOT adjacent (``axis=(0, 2)`` of a 3-D array) cannot be walked as one strided
+    dimension, and the reference's moveaxis + reshape copies everything (core.py:218-226).  Histograms
+    add up, so: histogram over the last block of adjacent reduced axes (no copy), then sum the — much
+    smaller — result over the remaining reduced axes.  int64 counts stay exact.  None when the reduced
+    axes are one block anyway, or the intermediate would not be small next to the data."""
+    axes = sorted(int(a) for a in drop_axes)
+    if len(axes) < 2 or axes[-1] - axes[0] + 1 == len(axes):
+        return None
+    last = [axes[-1]]
+    while last[0] - 1 in axes:
+        last.insert(0, last[0] - 1)
+    rest = [a for a in axes if a not in last]
+    shape = tuple(int(n) for n in all_arrays[0].shape)
+    n_bins = 1
+    for b in bins:
+        n_bins *= max(len(b) - 1, 0)
+    cols = 1
+    for ax in last:
+        cols *= shape[ax]
+    n_in = len(all_arrays) - (1 if has_weights else 0)
+    itemsize = sum(_np_dtype_of(a).itemsize for a in all_arrays[:n_in])
+    if n_bins * 8 * 4 > cols * itemsize:
+        return None
+    part = _bincount(*all_arrays, weights=has_weights, axis=last, bins=bins, density=False, block_size=block_size)
+    if backend == "torch":
+        return part.sum(dim=rest, keepdim=True)
+    return part.sum(axis=tuple(rest), keepdims=True)
+
+
 def _weights_constant_along_reduced(args_b, w_raw, drop_axes, bins, block_size, backend):
     """Weights that do not vary along some of the reduced axes (``cos(lat)`` of shape (1, lat, 1) under a
     reduction over lat and lon; one weight per time step; ...): the reference materialises them at
@@ -760,6 +790,8 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
             bincount_kwargs["second_weights"] = True
         elif has_weights:
             bin_counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
+        if bin_counts is None and not two:
+            bin_counts = _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend)
         if bin_counts is None:
             bin_counts = _bincount(*all_arrays, **bincount_kwargs)
         squeeze_axes = tuple(int(i) + (1 if two else 0) for i in drop_axes)  # (two: a leading pair axis)
