@@ -820,6 +820,32 @@ def test_non_adjacent_reduced_axes_in_two_steps(xh, resident):
         assert_hist_equal(got, want, True)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_int64_domain_vector_kernels(xh, weighted):
+    """int64 / datetime64 samples against integer edges: exact int64 comparison on the vector kernels,
+    including values float64 cannot tell apart"""
+    rng = np.random.default_rng(51)
+    base = (1 << 60) + 7
+    for n in (1, 3, 1023, 200_003):
+        x = base + rng.integers(-50, 250, (2, n))
+        x[0, 0] = np.iinfo(np.int64).min
+        x[-1, -1] = np.iinfo(np.int64).max
+        edges = [base + np.sort(rng.choice(np.arange(-40, 240), 37, replace=False))]
+        edges[0][-1] = edges[0][-2] + 1  # neighbours that are one apart
+        w = rng.uniform(0, 1, x.shape) if weighted else None
+        got, desc = _run(xh, [x], edges, w, True)
+        assert "family=fast" in desc and "cmp=i64" in desc, desc
+        assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
+        assert_hist_equal(_run(xh, [x], edges, w, False)[0], onp.bincount_rows([x], edges, w), weighted)
+    t0 = np.datetime64("1999-12-31T23:59:00", "s")
+    t = (t0 + rng.integers(0, 200_000, (3, 50_001)).astype("timedelta64[s]")).astype("datetime64[s]")
+    te = np.arange(np.datetime64("2000-01-01"), np.datetime64("2000-01-04"), np.timedelta64(6, "h"))
+    w = rng.uniform(0, 1, t.shape) if weighted else None
+    got, desc = _run(xh, [t], [te], w, False)
+    assert "family=fast" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([t], [te], w), weighted)
+
+
 def test_small_integer_samples_with_integer_edges_take_the_vector_kernels(xh):
     """bins=np.arange(257) on uint8 / int16 / int32 data: exact in float64, so no int64 generic family"""
     rng = np.random.default_rng(59)

@@ -411,7 +411,9 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   int vec = 1;
   const bool float_samples = sdt == XHIST_F64 || sdt == XHIST_F32;
   const bool small_samples = sdt == XHIST_I32 || sdt == XHIST_I64 || sdt == XHIST_I16 || sdt == XHIST_U8 || sdt == XHIST_F16;
-  bool fast_ok = !force_generic && p->cmp == XHIST_CMP_F64 && p->n_bins < ((int64_t)1 << 31) &&
+  // the exact int64 domain has vector kernels for one int64 / datetime64 input
+  const bool i64dom = p->cmp == XHIST_CMP_I64 && !p->uns && sdt == XHIST_I64 && D == 1 && (wdt == -1 || wdt == XHIST_F64);
+  bool fast_ok = !force_generic && (p->cmp == XHIST_CMP_F64 || i64dom) && p->n_bins < ((int64_t)1 << 31) &&
                  ((float_samples && D <= 3 && (wdt == -1 || wdt == XHIST_F64 || wdt == XHIST_F32)) ||
                   (small_samples && D == 1 && (wdt == -1 || wdt == XHIST_F64)));
   if (fast_ok) {
@@ -512,7 +514,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       if (!fn) return XHIST_ERR_UNSUPPORTED;
       break;
     }
-    fn = fast ? fast_kernel(sdt, wdt, D, scan, hist, &vec) : generic_kernel(p->cmp, weighted, lds_hist);
+    fn = fast ? (i64dom ? int64_domain_kernel(wdt, D, scan, hist, &vec) : fast_kernel(sdt, wdt, D, scan, hist, &vec))
+              : generic_kernel(p->cmp, weighted, lds_hist);
   }
   if (two && !accumulate) {
     if (int zrc = zero_output(out, out_elems, stream)) return zrc;

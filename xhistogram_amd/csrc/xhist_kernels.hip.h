@@ -421,13 +421,15 @@ constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 //     streaming ALL samples but keeping only the flat bins [slice_lo, slice_lo + slice_n) in LDS
 //     (the rest go to the trash slot).  S passes cost S x the streaming time; the partitioned mode
 //     moves ~3-4x the algorithmic bytes, so slices win up to S = 3-4 and work for any number of rows.
-template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false, bool SLICED = false>
+// I64DOM: int64 / datetime64 samples compared exactly in int64 against integer edges (Dom<1>)
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false, bool SLICED = false, bool I64DOM = false>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
   static_assert(!SLICED || HIST != kHistGlobal, "slices are for LDS-resident histograms");
   static_assert(!W2 || (HIST == kHistLds && !__is_same(WT, NoWeight)), "two weights: weighted, LDS histograms");
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
-  constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
+  constexpr int CMP = I64DOM ? 1 : ((__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0);
+  static_assert(!I64DOM || (__is_same(ST, int64_t) && SCAN == 0), "int64 domain: int64 samples, (start, cnt) tables");
   using CT = typename Dom<CMP>::T;
   // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
   // integer samples: zero, masked by the past_end bit

@@ -156,6 +156,21 @@ static kernel_fn small_pick(int wdt, int D, int scan, int hist) {
   return nullptr;
 }
 
+// int64 / datetime64 samples against integer edges, compared exactly in int64: one input, unweighted or
+// float64 weights, LDS or global histogram, (start, cnt) tables with the branch-free binary search
+static kernel_fn int64_domain_kernel(int wdt, int D, int scan, int hist, int* vec) {
+  if (D != 1 || scan != 0 || (hist != kHistLds && hist != kHistGlobal)) return nullptr;
+  *vec = 2;
+  constexpr int U = unroll_for(1, 2, 0);
+  if (wdt == -1)
+    return hist == kHistLds ? (kernel_fn)hist_fast<int64_t, NoWeight, 1, 2, U, kHistLds, 0, false, false, true>
+                            : (kernel_fn)hist_fast<int64_t, NoWeight, 1, 2, U, kHistGlobal, 0, false, false, true>;
+  if (wdt == XHIST_F64)
+    return hist == kHistLds ? (kernel_fn)hist_fast<int64_t, double, 1, 2, U, kHistLds, 0, false, false, true>
+                            : (kernel_fn)hist_fast<int64_t, double, 1, 2, U, kHistGlobal, 0, false, false, true>;
+  return nullptr;
+}
+
 static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* vec) {
   const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
   *vec = 16 / std::max(ssz, wsz);
