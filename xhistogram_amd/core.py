@@ -97,6 +97,7 @@ def _np_dtype_of(a):
 # plan cache (edge tables live on the GPU; building one costs a launch + a sync)
 # ---------------------------------------------------------------------------------------------
 _plans = OrderedDict()
+_areas = OrderedDict()  # device-resident bin areas of the density epilogue, per set of edges
 _plans_lock = threading.Lock()
 _PLAN_CACHE = 32
 
@@ -553,12 +554,22 @@ def _density(counts, bins, n_inputs):
     widths = [np.diff(b) for b in bins]
     bin_axes = tuple(_range(-n_inputs, 0))
     if _is_torch(counts):
-        # the outer product is formed on the device (same float64 products): only the widths travel
+        # the outer product is formed on the device (same float64 products): only the widths travel,
+        # and only once per set of edges (a host-to-device copy per call costs more than the epilogue)
         torch = _torch()
-        areas_t = None
-        for w in widths:
-            wt = torch.as_tensor(np.asarray(w, dtype=np.float64), device=counts.device)
-            areas_t = wt if areas_t is None else areas_t[..., None] * wt
+        key = (str(counts.device),) + tuple(np.asarray(w, dtype=np.float64).tobytes() for w in widths)
+        with _plans_lock:
+            areas_t = _areas.get(key)
+            if areas_t is not None:
+                _areas.move_to_end(key)
+        if areas_t is None:
+            for w in widths:
+                wt = torch.as_tensor(np.asarray(w, dtype=np.float64), device=counts.device)
+                areas_t = wt if areas_t is None else areas_t[..., None] * wt
+            with _plans_lock:
+                _areas[key] = areas_t
+                while len(_areas) > 8:
+                    _areas.popitem(last=False)
         sums = counts.sum(dim=bin_axes, keepdim=True)
         return counts / areas_t / sums
     areas = widths[0]
