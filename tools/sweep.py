@@ -158,8 +158,8 @@ def main():
         p4 = core._get_plan([np.linspace(-4, 4, 51)], _native.CMP_F64, 0)
         out = torch.zeros(rows * 50, dtype=torch.int64, device=dev)
         v4 = [_native.make_view(xf.data_ptr(), _native.F32, cols, 1)]
-        for block in (256, 512):
-            for grid in (0, 2048, 4096, 8192):
+        for block in (128, 256, 512):
+            for grid in (0, 4096, 8192, 16384, 32768, 65536):
                 p4.set_param("block_threads", block)
                 p4.set_param("grid_blocks", grid)
                 med, mn = timed(p4, v4, None, rows, cols, out, False, stream, args.reps, _native)
