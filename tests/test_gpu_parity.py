@@ -782,6 +782,10 @@ def test_weights_broadcast_along_reduced_axes(xh, resident):
     check([t], rng.uniform(0, 2, (700,)), (1, 2))             # varies along the LAST axis only: counts over the middle one
     check([t], np.float64(0.25) * np.ones((1, 1, 1)), None)   # a scalar weight
     check([t.astype(np.float32)], w_lat.astype(np.float32), (1, 2))
+    check([t], np.broadcast_to(w_lat, t.shape), (1, 2))    # already broadcast: a stride-0 view of full shape
+    if resident:
+        got, _ = xh.histogram(_dev(t), bins=e, weights=_dev(w_lat).expand(t.shape), axis=(1, 2))
+        assert_hist_equal(got.cpu().numpy(), onp.histogram(t, bins=e, weights=w_lat, axis=(1, 2))[0], True)
     u = rng.standard_normal(t.shape)
     check([t, u], w_lat, (1, 2), bins=[np.linspace(-3, 3, 9), np.linspace(-3, 3, 7)])
     # NaN / inf weights: only bins that received a sample of that weight are affected

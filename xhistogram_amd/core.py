@@ -628,6 +628,12 @@ def _weights_constant_along_reduced(args_b, w_raw, drop_axes, bins, block_size, 
     nd = len(shape)
     if w_raw is None or w_raw.ndim > nd:
         return None
+    # weights that arrive already broadcast (stride-0 views: np.broadcast_to, torch.expand, what the
+    # xarray wrapper hands over) are as good as size-1 axes
+    wstrides = tuple(w_raw.stride()) if backend == "torch" else tuple(w_raw.strides)
+    for ax in _range(w_raw.ndim):
+        if wstrides[ax] == 0 and w_raw.shape[ax] > 1:
+            w_raw = w_raw[tuple(slice(0, 1) if k == ax else slice(None) for k in _range(w_raw.ndim))]
     wshape = (1,) * (nd - w_raw.ndim) + tuple(int(n) for n in w_raw.shape)
     cand = sorted(int(ax) for ax in drop_axes if wshape[ax] == 1 and shape[ax] > 1)
     if not cand:
