@@ -154,3 +154,66 @@ def test_collapse_describes_the_reference_layout_by_strides():
     y = x[:, :, :, ::2]
     d = core._collapse(y, [3], False, [3])
     assert d == (60, 3, 6, 2, 0, 0) and core._view_of(y, d, "numpy")[4:6] == (60, 0)
+
+
+def _oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+    """stand-in for core._bincount with the same contract, computed by the oracle (CPU): lets the
+    host-side rewrites around it run without a GPU"""
+    arrays = list(all_arrays)
+    w = arrays.pop() if weights else None
+    nd = arrays[0].ndim
+    ax = tuple(range(nd)) if axis is None else tuple(int(a) for a in axis)
+    h, _ = onp.histogram(*arrays, bins=bins if len(arrays) > 1 else bins[0], weights=w, axis=ax)
+    kept = tuple(1 if i in ax else arrays[0].shape[i] for i in range(nd))
+    return np.asarray(h).reshape(kept + tuple(len(b) - 1 for b in bins))
+
+
+def test_host_side_rewrites_around_the_block_adapter(monkeypatch):
+    """weights constant along reduced axes -> counts then weights; non-adjacent reduced axes -> two steps.
+    Both only re-arrange calls of the block adapter, so with the adapter replaced by the oracle they can be
+    checked on the CPU against the reference semantics (materialised weights, moveaxis + reshape)."""
+    calls = []
+
+    def spy(*a, **k):
+        calls.append((k.get("weights"), tuple(k.get("axis") or ())))
+        return _oracle_bincount(*a, **k)
+
+    monkeypatch.setattr(core, "_bincount", spy)
+    rng = np.random.default_rng(3)
+    t = rng.standard_normal((5, 12, 300))
+    t[1, 2, :4] = np.nan
+    e = np.linspace(-3, 3, 13)
+    w_lat = np.cos(np.linspace(-1, 1, 12)).reshape(1, 12, 1)
+    for axis in ((1, 2), None, (0, 2), (2,)):
+        calls.clear()
+        got, _ = core.histogram(t, bins=e, weights=w_lat, axis=axis)
+        want, _ = onp.histogram(t, bins=e, weights=w_lat, axis=axis)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+        assert calls and calls[0][0] is False, calls           # the samples were counted unweighted
+    calls.clear()
+    got, _ = core.histogram(t, bins=e, weights=np.broadcast_to(w_lat, t.shape), axis=(1, 2), density=True)
+    np.testing.assert_allclose(got, onp.histogram(t, bins=e, weights=w_lat, axis=(1, 2), density=True)[0], rtol=1e-12)
+    assert calls[0] == (False, (2,)), calls                    # a stride-0 view counts as a size-1 axis
+    # NaN weight on a latitude nobody... every latitude has samples here, so the NaN must show where it lands
+    w_nan = w_lat.copy()
+    w_nan[0, 3, 0] = np.nan
+    got, _ = core.histogram(t, bins=e, weights=w_nan, axis=(1, 2))
+    want, _ = onp.histogram(t, bins=e, weights=w_nan, axis=(1, 2))
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    # full-size weights: not rewritten
+    calls.clear()
+    w_full = rng.uniform(0, 1, t.shape)
+    got, _ = core.histogram(t, bins=e, weights=w_full, axis=(1, 2))
+    np.testing.assert_allclose(got, onp.histogram(t, bins=e, weights=w_full, axis=(1, 2))[0], rtol=1e-12)
+    assert calls == [(True, (1, 2))], calls
+    # non-adjacent reduced axes: last adjacent block through the adapter, the rest summed
+    calls.clear()
+    got, _ = core.histogram(t, bins=e, axis=(0, 2))
+    np.testing.assert_array_equal(got, onp.histogram(t, bins=e, axis=(0, 2))[0])
+    assert got.dtype == np.int64 and calls == [(False, (2,))], calls
+    calls.clear()
+    q = rng.standard_normal((3, 4, 5, 200))
+    wq = rng.uniform(0, 1, q.shape)
+    got, _ = core.histogram(q, bins=e, axis=(0, 2, 3), weights=wq)
+    assert calls == [(True, (2, 3))], calls
+    np.testing.assert_allclose(got, onp.histogram(q, bins=e, axis=(0, 2, 3), weights=wq)[0], rtol=1e-12)
