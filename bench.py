@@ -122,6 +122,11 @@ def build_workload(cfg, args, torch, dev, rank):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON result of rank 0): whatever libraries print there — RCCL
+    # writes a five-line version banner to stdout when the communicator is created — goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -259,7 +264,8 @@ def main():
             m = min(args.cpu_sample // max(1, len(arrays)), n)
             flat = [a.reshape(-1)[:m].double().cpu().numpy() if args.config != "c4" else a.reshape(-1)[:m].cpu().numpy() for a in arrays]
             line["cpu_baseline"] = cpu_baseline(flat, w.reshape(-1)[:m].cpu().numpy() if weighted else None, edges)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
