@@ -85,7 +85,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   uint32_t* d_counts = nullptr;
   uint64_t *d_base = nullptr, *d_offsets = nullptr;
   uint16_t* d_codes = nullptr;
-  double* d_w = nullptr;
+  void* d_w = nullptr;  // record weights: float64, or float32 when the caller's weights are
   uint32_t* d_flat = nullptr;
   auto release = [&](int rc) {
     if (d_flat) (void)hipFreeAsync(d_flat, stream);
@@ -107,7 +107,8 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   HIPR(hipMallocAsync((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
   const size_t n_rec = (size_t)n_cols + (size_t)G * n_parts * grp;  // every slice rounded up to whole groups
   HIPR(hipMallocAsync((void**)&d_codes, n_rec * 2 + 16, stream));
-  if (weighted) HIPR(hipMallocAsync((void**)&d_w, n_rec * 8 + 16, stream));
+  const bool rec_f32 = wdt == XHIST_F32;
+  if (weighted) HIPR(hipMallocAsync(&d_w, n_rec * (rec_f32 ? 4 : 8) + 16, stream));
 
   Params kp;
   memset(&kp, 0, sizeof kp);
@@ -137,13 +138,14 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   kp.part_counts = d_counts;
   kp.part_base = d_base;
   kp.part_codes = d_codes;
-  kp.part_w = d_w;
+  kp.part_w = static_cast<double*>(d_w);
   kp.part_shift = shift;
   kp.n_parts = n_parts;
 
   if (lds_count > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
   if (lds_scatter > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
-  kernel_fn_acc k_acc = weighted ? (kernel_fn_acc)part_accumulate<true> : (kernel_fn_acc)part_accumulate<false>;
+  kernel_fn_acc k_acc = weighted ? (rec_f32 ? (kernel_fn_acc)part_accumulate<true, float> : (kernel_fn_acc)part_accumulate<true, double>)
+                                 : (kernel_fn_acc)part_accumulate<false, double>;
   if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
 
   if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
@@ -155,7 +157,7 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   hipLaunchKernelGGL(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
                      weighted ? weights->data : nullptr, n_cols, (const uint64_t*)d_base, d_codes, d_w, shift, n_parts);
   HIPR(hipGetLastError());
-  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const double*)d_w,
+  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const void*)d_w,
                      (const uint64_t*)d_offsets, out, p->n_bins, shift, n_parts);
   HIPR(hipGetLastError());
   {

@@ -144,9 +144,15 @@ __host__ __device__ constexpr size_t part_scatter_lds(int P, int grp, bool weigh
 template <typename WT, int GRP>
 __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __restrict__ flat, const void* wv_, int64_t n,
                                                             const uint64_t* __restrict__ base_tbl, uint16_t* __restrict__ codes,
-                                                            double* __restrict__ wrec, int shift, int P) {
+                                                            void* __restrict__ wrec_, int shift, int P) {
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
   using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  // record weights keep the caller's precision: float32 weights travel as 4 bytes (converted to
+  // float64 when they are added up in part_accumulate, exactly as the single-pass kernels do)
+  using RT = typename std::conditional<__is_same(WT, float), float, double>::type;
+  constexpr int RV = 16 / (int)sizeof(RT);  // record weights per 16-byte store
+  typedef RT rvec __attribute__((ext_vector_type(RV)));
+  RT* __restrict__ wrec = static_cast<RT*>(wrec_);
   constexpr int U = kScatterLoads, H = kPartTile / kScatterTile;
   static_assert(GRP == 8 || GRP == 4, "a group is one 16-byte or 8-byte code store");
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -168,10 +174,10 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
   unsigned char* dyn = xhist_smem + kScatterTableBytes;
   uint32_t* carry_key = reinterpret_cast<uint32_t*>(dyn);                  // [P][GRP]
   dyn += (size_t)P * GRP * 4;
-  double* carry_w = reinterpret_cast<double*>(dyn);                         // [P][GRP]
+  RT* carry_w = reinterpret_cast<RT*>(dyn);                                 // [P][GRP]
   if (kWeighted) dyn += (size_t)P * GRP * 8;
   const int S = part_scatter_slots(P, GRP);
-  double* sw = reinterpret_cast<double*>(dyn);                              // [S] weights of the sorted tile
+  RT* sw = reinterpret_cast<RT*>(dyn);                                      // [S] weights of the sorted tile
   if (kWeighted) dyn += (size_t)S * 8;
   uint32_t* skey = reinterpret_cast<uint32_t*>(dyn);                        // [S] keys: part << 16 | code
   const wscalar* wp = reinterpret_cast<const wscalar*>(wv_);
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
           const uint32_t part = f[u][v] >> shift;
           const uint32_t slot = first[part] + rank[u][v];
           skey[slot] = (part << 16) | (f[u][v] & code_mask);
-          if (kWeighted) sw[slot] = (double)wu[v];
+          if (kWeighted) sw[slot] = (RT)wu[v];
         }
     }
     for (int t = tid; t < P * GRP; t += blockDim.x) {  // the carried records go to the head of their block
@@ -341,14 +347,16 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
           }
       }
     }
-    // weights: one lane per PAIR of records, so that a wavefront's store is 1 KiB of one stream
+    // weights: one lane per 16 bytes of records (2 float64 / 4 float32), so that a wavefront's store
+    // is 1 KiB of one stream
     if (kWeighted) {
-      for (uint32_t t0 = (uint32_t)tid * 2; t0 < total; t0 += kPartBlock * 2) {
+      static_assert(GRP % RV == 0, "16-byte weight stores never straddle a group");
+      for (uint32_t t0 = (uint32_t)tid * RV; t0 < total; t0 += kPartBlock * RV) {
         const uint32_t g0 = t0 & ~kGm;
         const uint32_t q = skey[g0] >> 16;
         if (g0 + GRP <= endw[q]) {
-          const d2 w2 = *reinterpret_cast<const d2*>(sw + t0);
-          __builtin_nontemporal_store(w2, reinterpret_cast<d2*>(wrec + delta[q] + t0));
+          const rvec wq = *reinterpret_cast<const rvec*>(sw + t0);
+          __builtin_nontemporal_store(wq, reinterpret_cast<rvec*>(wrec + delta[q] + t0));
         }
       }
     }
@@ -362,7 +370,7 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
     for (int i = 0; i < GRP; ++i) {
       const bool real = (uint32_t)i < my_carry;
       codes[dst + i] = real ? (uint16_t)(carry_key[tid * GRP + i] & 0xffffu) : (uint16_t)(kWeighted ? 0u : (1u << shift));
-      if (kWeighted) wrec[dst + i] = real ? carry_w[tid * GRP + i] : 0.0;
+      if (kWeighted) wrec[dst + i] = real ? carry_w[tid * GRP + i] : (RT)0;
     }
   }
 }
@@ -422,13 +430,15 @@ __global__ void __launch_bounds__(1024) part_prefix(const uint32_t* counts, int 
 // to the output whenever its range crosses into the next partition.  The streams contain
 // part_scatter's padding records: weight 0 (weighted) or the code 2^shift, one slot past the
 // histogram, which is never flushed (unweighted).
-template <bool WEIGHTED>
-__global__ void __launch_bounds__(1024) part_accumulate(const uint16_t* codes, const double* wrec, const uint64_t* offsets,
+// RT: type of the record weights (float32 weights travel as 4 bytes and are widened here)
+template <bool WEIGHTED, typename RT = double>
+__global__ void __launch_bounds__(1024) part_accumulate(const uint16_t* codes, const void* wrec_, const uint64_t* offsets,
                                                          void* out_v, int64_t n_bins, int shift, int P) {
   using lds_t = typename std::conditional<WEIGHTED, double, uint32_t>::type;
   using out_t = typename std::conditional<WEIGHTED, double, unsigned long long>::type;
   lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem);
   out_t* out = reinterpret_cast<out_t*>(out_v);
+  const RT* wrec = static_cast<const RT*>(wrec_);
   const uint32_t bpp = 1u << shift;
   const int tid = threadIdx.x;
   for (uint32_t c = tid; c <= bpp; c += blockDim.x) hist[c] = (lds_t)0;  // [bpp] = trash slot
@@ -448,37 +458,34 @@ __global__ void __launch_bounds__(1024) part_accumulate(const uint16_t* codes, c
     const uint64_t head_end = min(pend, (lo + 3) & ~(uint64_t)3);
     for (uint64_t j = i + tid; j < head_end; j += blockDim.x) {
       const uint16_t c = codes[j];
-      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, wrec[j]);
+      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, (double)wrec[j]);
       else atomicAdd(reinterpret_cast<uint32_t*>(hist) + c, 1u);
     }
     i = head_end;
     typedef uint16_t c4 __attribute__((ext_vector_type(4)));
-    typedef double w2 __attribute__((ext_vector_type(2)));
+    typedef RT w4 __attribute__((ext_vector_type(4)));  // 4 record weights: 16 bytes (float32) or 2 x 16 (float64)
     constexpr int kGroups = 2;
     const uint64_t step = (uint64_t)blockDim.x * 4 * kGroups;
     for (; i + step <= pend; i += step) {
       c4 cv[kGroups];
-      w2 wa[kGroups], wb[kGroups];
+      w4 wq[kGroups];
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
         const uint64_t j = i + ((uint64_t)g * blockDim.x + tid) * 4;
         cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + j));
-        if (WEIGHTED) {
-          wa[g] = __builtin_nontemporal_load(reinterpret_cast<const w2*>(wrec + j));
-          wb[g] = __builtin_nontemporal_load(reinterpret_cast<const w2*>(wrec + j + 2));
-        }
+        if (WEIGHTED) wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + j));
       }
 #pragma unroll
       for (int g = 0; g < kGroups; ++g)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], k < 2 ? wa[g][k] : wb[g][k - 2]);
+          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
           else atomicAdd(reinterpret_cast<uint32_t*>(hist) + cv[g][k], 1u);
         }
     }
     for (uint64_t j = i + tid; j < pend; j += blockDim.x) {
       const uint16_t c = codes[j];
-      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, wrec[j]);
+      if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + c, (double)wrec[j]);
       else atomicAdd(reinterpret_cast<uint32_t*>(hist) + c, 1u);
     }
     __syncthreads();
