@@ -542,7 +542,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     int64_t B = 0;
     for (int d = 0; d < D; ++d) B += dtype_size(samples[d].dtype);
     if (weighted) B += dtype_size(weights->dtype);
-    const int64_t rec = 2 + (weighted ? 8 : 0);
+    const int64_t rec = 2 + (weighted ? (wdt == XHIST_F32 ? 4 : 8) : 0);  // a record: uint16 code + the weight in its own precision
     const int part_shift = weighted ? 14 : 15;
     const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) &&
                          ((p->n_bins + ((int64_t)1 << part_shift) - 1) >> part_shift) <= kPartMaxParts;
