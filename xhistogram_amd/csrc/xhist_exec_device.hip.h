@@ -529,8 +529,9 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
 
   // ---- a few times the LDS capacity: bin slices ---------------------------------------------------
   // S launches, each streaming all samples and keeping 1/S of the bins in LDS (hist_fast<SLICED>),
-  // cost S x the streaming time at ~6.3 TB/s; the partitioned mode below moves B + 8 + 2 x record
-  // bytes per sample at ~5 TB/s and needs a few long rows.  200 x 200 weighted bins of f32 pairs:
+  // cost S x the streaming time at ~6.5 TB/s; the partitioned mode below moves B + 8 + 2 x record
+  // bytes per sample at 3.7 (row by row) to 5 TB/s and needs a few long rows: slices while
+  // 0.65 S B <= B + 8 + 2 x record bytes.  200 x 200 weighted bins of f32 pairs:
   // 9.3 ms partitioned -> 3 slices; 300 x 300 counts: 8.3 ms -> 2 slices of packed uint16 counters.
   int n_slices = 1;
   int64_t slice_bins = p->n_bins;
@@ -546,7 +547,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const int part_shift = weighted ? 14 : 15;
     const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) &&
                          ((p->n_bins + ((int64_t)1 << part_shift) - 1) >> part_shift) <= kPartMaxParts;
-    const bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 4 * S * B <= 5 * (B + 8 + 2 * rec) : S <= 16));
+    const bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 13 * S * B <= 20 * (B + 8 + 2 * rec) : S <= 16));
     if (choose && S >= 1) {
       const int shist = weighted ? kHistLds : kHistPacked;
       kernel_fn sfn = fast_kernel_sliced(sdt, wdt, D, scan, shist, &vec);
