@@ -80,6 +80,26 @@ def one(seed):
     except (NotImplementedError, TypeError, ValueError):
         return None
     conv = (lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a)
+    # kernel-family overrides on the plan these edges map to (reset afterwards)
+    plan, override = None, None
+    if rng.random() < 0.5:
+        override = [("partition", 1), ("slices", 1), ("arith", 1), ("lanes", 1), ("lanes", -1), ("force_generic", 1), ("force_global", 1),
+                    ("lds_copies", 1), ("slices", -1), ("arith", -1)][int(rng.integers(0, 10))]
+        try:
+            dom, cedges, _ = core._compare_domain([a.dtype for a in args], edges)
+            plan = core._get_plan(cedges, dom, 0)
+            plan.set_param(*override)
+        except (NotImplementedError, TypeError):
+            plan = None
+    desc["override"] = override
+    try:
+        return _compare(args, bins, w, axis, density, resident, two, conv, want, desc, rng)
+    finally:
+        if plan is not None:
+            plan.set_param(override[0], 0)
+
+
+def _compare(args, bins, w, axis, density, resident, two, conv, want, desc, rng):
     try:
         if two:
             w2 = rng.uniform(0, 1, w.shape)
