@@ -1,5 +1,5 @@
 """Randomised differential soak of the public entry points against the numpy oracle (development tool;
-the test-suite runs seeded subsets of the same space).  python tools/soak.py [seconds] [seed]"""
+the test-suite runs seeded subsets of the same space).  python tools/soak.py [seconds] [seed] [max columns]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from xhistogram_amd import core
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big_cols = int(sys.argv[3]) if len(sys.argv) > 3 else 200_000  # upper bound of the last axis in the "big" third of the cases
 
 
 def edges_for(rng, kind, nb, lo=-3.0, hi=3.0):
@@ -35,7 +36,7 @@ def one(seed):
     rng = np.random.default_rng(seed)
     ndim = int(rng.integers(1, 4))
     big = rng.random() < 0.3
-    shape = tuple(int(rng.integers(1, 7)) for _ in range(ndim - 1)) + (int(rng.integers(1, 200_000 if big else 3000)),)
+    shape = tuple(int(rng.integers(1, 7)) for _ in range(ndim - 1)) + (int(rng.integers(1, big_cols if big else 3000)),)
     if rng.random() < 0.3:
         shape = tuple(rng.permutation(shape))
     d = int(rng.choice([1, 1, 1, 2, 2, 3]))
