@@ -2,9 +2,7 @@
 // Plans (device-resident edge tables), kernel-family selection, launch geometry, host staging.
 // No CPU compute path exists here on purpose: without a HIP device every compute entry point
 // fails with XHIST_ERR_NO_DEVICE.
-#include "xhist_kernels.hip.h"
-#include "xhist_partition.hip.h"
-#include "xhist_lanes.hip.h"
+#include "xhist_pick.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -16,9 +14,6 @@
 #include <string>
 #include <vector>
 
-#include "../../include/xhist_amd.h"
-
-using namespace xhist;
 
 #include "xhist_host_common.hip.h"
 #include "xhist_plan.hip.h"

@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
 // Output zeroing as a kernel of this library rather than hipMemsetAsync: a memset node captured
 // into a hipGraph was observed (ROCm 7.0 runtime under torch) to replay with a garbage fill
 // value; a kernel node replays exactly.
-__global__ void __launch_bounds__(256) zero_words(unsigned long long* p, int64_t n) {
+static __global__ void __launch_bounds__(256) zero_words(unsigned long long* p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0ull;
 }
 
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
 // min / max with numpy's NaN propagation (feeds np.histogram_bin_edges, core.py:383-388)
 // partial[3*b + {0,1,2}] = {min, max, saw_nan} of workgroup b
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs, int64_t ir, int64_t os,
+static __global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs, int64_t ir, int64_t os,
                                                        int64_t n_rows, int64_t n_cols, double* partial) {
   double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
   int nan = 0;

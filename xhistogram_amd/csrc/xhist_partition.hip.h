@@ -157,7 +157,6 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
   static_assert(GRP == 8 || GRP == 4, "a group is one 16-byte or 8-byte code store");
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-  typedef double d2 __attribute__((ext_vector_type(2)));
   // the caller's weights are only guaranteed element-aligned here (gfx950 vector loads need no more)
   typedef wscalar w4 __attribute__((ext_vector_type(4), aligned(sizeof(wscalar))));
   constexpr uint32_t kGm = GRP - 1;
@@ -380,7 +379,7 @@ __global__ void __launch_bounds__(kPartBlock) part_scatter(const uint32_t* __res
 // of them start group-aligned (part_scatter fills the slack with neutral records).  One workgroup
 // of 1024 threads arranged as R row groups x P columns so that every global access is coalesced
 // along P and each thread walks only G/R rows.
-__global__ void __launch_bounds__(1024) part_prefix(const uint32_t* counts, int G, int P, int grp, uint64_t* offsets, uint64_t* base) {
+static __global__ void __launch_bounds__(1024) part_prefix(const uint32_t* counts, int G, int P, int grp, uint64_t* offsets, uint64_t* base) {
   __shared__ uint64_t part[1024];  // [R][P] partial sums, then exclusive prefixes over r
   __shared__ uint64_t off[257];
   const int t = threadIdx.x;

@@ -1,0 +1,146 @@
+// xhist_pick.hip.h — kernel pickers of the float32 / float64 vector family.  The template instantiations
+// behind them are the bulk of the build (several hundred kernels), so they live in two translation
+// units of their own (xhist_pick_f64.hip, xhist_pick_f32.hip) that compile in parallel with
+// xhist_capi.hip; each exports the two plain functions declared at the end.
+#pragma once
+
+#include "xhist_kernels.hip.h"
+#include "xhist_partition.hip.h"
+#include "xhist_lanes.hip.h"
+
+#include <type_traits>
+
+#include "../../include/xhist_amd.h"
+
+using namespace xhist;
+
+typedef void (*kernel_fn)(const Params);
+typedef void (*kernel_fn_acc)(const uint16_t*, const void*, const uint64_t*, void*, int64_t, int, int);
+typedef void (*kernel_fn_count)(const Params, uint32_t*);
+typedef void (*kernel_fn_lanes)(const Params, int32_t, int64_t);
+typedef void (*kernel_fn_scatter)(const uint32_t*, const void*, int64_t, const uint64_t*, uint16_t*, void*, int, int);
+
+// Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
+// sample and dimension the batch keeps the value, its running count and (linear scan) up to
+// SCAN edge values in VGPRs, and 1024-thread workgroups leave 128 VGPRs per lane.
+constexpr int unroll_for(int D, int vec, int scan) {
+  int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
+  if (D >= 2 && scan >= 3) cap /= 2;
+  if (D == 1 && scan >= 3 && vec == 4) cap = 8;
+  const int u = cap / vec < 1 ? 1 : cap / vec;
+  return u > 4 ? 4 : u;
+}
+
+// partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
+constexpr int kHistPartCount = 4, kHistLanes = 6, kHistLanes16 = 7;
+constexpr int kPartMaxParts = 256;
+
+template <typename ST, typename WT, int D, int SCAN>
+static kernel_fn fast_pick(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  constexpr int U = unroll_for(D, VEC, SCAN);
+  if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, SCAN>;
+  if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+  if (hist == kHistLanes16) {
+    if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
+    else return nullptr;
+  }
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+    else return nullptr;
+  }
+  return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
+}
+
+// table-free digitize (arithmetic edges): only the kernels that mode is selected for
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick_arith(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  constexpr int U = unroll_for(D, VEC, kScanArith);
+  if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, kScanArith>;
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, kScanArith>;
+    else return nullptr;
+  }
+  if (hist == kHistGlobal) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, kScanArith>;
+  return nullptr;
+}
+
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick_s(int scan, int hist) {
+  switch (scan) {
+    case kScanArith: return fast_pick_arith<ST, WT, D>(hist);
+    case 1: return fast_pick<ST, WT, D, 1>(hist);
+    case 2: return fast_pick<ST, WT, D, 2>(hist);
+    case 3: return fast_pick<ST, WT, D, 3>(hist);
+    case 4: return fast_pick<ST, WT, D, 4>(hist);
+    default: return fast_pick<ST, WT, D, 0>(hist);
+  }
+}
+
+template <typename ST, typename WT>
+static kernel_fn fast_pick_d(int D, int scan, int hist) {
+  switch (D) {
+    case 1: return fast_pick_s<ST, WT, 1>(scan, hist);
+    case 2: return fast_pick_s<ST, WT, 2>(scan, hist);
+    case 3: return fast_pick_s<ST, WT, 3>(scan, hist);
+    default: return nullptr;
+  }
+}
+
+template <typename ST>
+static kernel_fn fast_pick_w(int wdt, int D, int scan, int hist) {
+  switch (wdt) {
+    case -1: return fast_pick_d<ST, NoWeight>(D, scan, hist);
+    case XHIST_F64: return fast_pick_d<ST, double>(D, scan, hist);
+    case XHIST_F32: return fast_pick_d<ST, float>(D, scan, hist);
+    default: return nullptr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bin slices (hist_fast<..., SLICED = true>): float samples, LDS or packed-uint16 histograms, table
+// digitize with <= 2 edges per bucket or arithmetic edges
+template <typename ST, typename WT, int D, int SCAN>
+static kernel_fn sliced_pick(int hist) {
+  constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+  constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+  constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+  constexpr int U = unroll_for(D, VEC, SCAN);
+  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN, false, true>;
+  if (hist == kHistPacked) {
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN, false, true>;
+  }
+  return nullptr;
+}
+
+template <typename ST, typename WT>
+static kernel_fn sliced_pick_ds(int D, int scan, int hist) {
+#define XH_SLICED_CASE(DD)                                            \
+  case DD:                                                            \
+    if (scan == 1) return sliced_pick<ST, WT, DD, 1>(hist);           \
+    if (scan == 2) return sliced_pick<ST, WT, DD, 2>(hist);           \
+    if (scan == kScanArith) return sliced_pick<ST, WT, DD, kScanArith>(hist); \
+    return nullptr;
+  switch (D) {
+    XH_SLICED_CASE(1)
+    XH_SLICED_CASE(2)
+    XH_SLICED_CASE(3)
+    default: return nullptr;
+  }
+#undef XH_SLICED_CASE
+}
+
+// ------------------------------------------------------------------------------------------
+// what the two picker translation units export (sample type fixed, everything else a run-time choice);
+// nullptr = no such kernel
+kernel_fn xhist_pick_f64(int wdt, int D, int scan, int hist);
+kernel_fn xhist_pick_f32(int wdt, int D, int scan, int hist);
+kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
+kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
