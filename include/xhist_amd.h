@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 3
+#define XHIST_ABI_VERSION 4
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -43,7 +43,8 @@ typedef enum {
   XHIST_ERR_NO_DEVICE = -3,   /* no HIP device visible / device index out of range                   */
   XHIST_ERR_HIP = -4,         /* HIP runtime error (message in xhist_last_error)                      */
   XHIST_ERR_NOMEM = -5,       /* host or device allocation failed                                     */
-  XHIST_ERR_EDGES = -6        /* edges decrease somewhere or contain NaN (numpy: ValueError)          */
+  XHIST_ERR_EDGES = -6,       /* edges decrease somewhere or contain NaN (numpy: ValueError)          */
+  XHIST_ERR_COMM = -7         /* RCCL not loadable / a collective failed (message in xhist_last_error) */
 } xhist_status;
 
 /* element type tags (numpy dtypes the reference accepts for samples / weights) */
@@ -135,6 +136,31 @@ int xhist_bincount_rows(int device, int n_inputs, const xhist_array* samples,
  * (core.py:383-388).  result[0] = min, result[1] = max, as float64 (HOST pointer). */
 int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result,
                  int mem_kind, void* stream);
+
+/* ---- exchange between GPUs (one process per GPU; RCCL over xGMI) ---------------------------- */
+/* Sharded inputs produce one partial histogram per GPU; what the reference does with dask's
+ * `bin_counts.sum(drop_axes)` (core.py:439) is ONE in-place all-reduce of that small buffer
+ * (shards cut along a reduced axis) or an all-gather of rows (shards cut along a kept axis:
+ * disjoint output rows).  These calls wrap RCCL, which is dlopen-ed on first use (an RCCL the
+ * process has mapped already is shared; XHIST_AMD_RCCL overrides the path), so single-GPU users and
+ * hosts that bring their own collective never load it.
+ *   rank 0: xhist_comm_unique_id -> hand the 128 bytes to every rank by any out-of-band means
+ *   (the host's launcher, a file, MPI) -> every rank: xhist_comm_create (collective).
+ * Buffers are DEVICE pointers on the comm's device; calls are asynchronous on `stream` and must be
+ * issued in the same order on every rank.  int64 sums are exact and order-independent. */
+#define XHIST_COMM_ID_BYTES 128
+typedef enum { XHIST_REDUCE_SUM = 0, XHIST_REDUCE_MIN = 1, XHIST_REDUCE_MAX = 2 } xhist_reduce_op;
+typedef struct xhist_comm xhist_comm; /* opaque: one RCCL communicator bound to one device */
+int xhist_comm_unique_id(void* id, size_t cap);
+int xhist_comm_create(int device, int rank, int world_size, const void* id, size_t id_bytes, xhist_comm** out);
+/* any of rank / world_size / device / rccl_version may be NULL */
+int xhist_comm_info(const xhist_comm* comm, int* rank, int* world_size, int* device, int* rccl_version);
+/* in place; dtype XHIST_I64 (counts), XHIST_F64 or XHIST_F32 (weighted sums; min / max of the data
+ * for bins=int: the reference's np.histogram_bin_edges sees the whole array, core.py:383-388) */
+int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, int op, void* stream);
+/* recv holds world_size * count elements, rank r's block at offset r * count */
+int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
+int xhist_comm_destroy(xhist_comm* comm);
 
 /* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
 /* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),

@@ -35,3 +35,36 @@ def test_c_client_matches_scalar_loop_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("OK")
+
+
+def _build_comm(tmp_path):
+    exe = str(tmp_path / "capi_comm_client")
+    lib = os.path.join(ROOT, "xhistogram_amd")
+    subprocess.run(
+        ["gcc", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+         os.path.join(ROOT, "tests", "capi_comm_client.c"), "-o", exe, "-L", lib, "-lxhist_amd", "-Wl,-rpath," + lib,
+         "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm"],
+        check=True,
+    )
+    return exe
+
+
+def test_c_comm_client_builds_and_refuses_loudly_without_a_gpu(tmp_path):
+    from xhistogram_amd import _native
+
+    exe = _build_comm(tmp_path)
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 77, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_comm_client_one_process_per_gpu(tmp_path):
+    """xhist_comm_* from plain C (RCCL dlopen-ed by the library, no torch in the process): one forked
+    process per visible GPU, sharded samples, one all-reduce; every rank checks the whole-data histogram"""
+    exe = _build_comm(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("OK")

@@ -133,3 +133,110 @@ def test_single_rank_nccl_group_uses_hip_path():
         np.testing.assert_array_equal(h.cpu().numpy(), want)
     finally:
         dist.destroy_process_group()
+
+
+def _native_cases(xd, onp, comm, rank, world, dev):
+    """the three exchange shapes through the C ABI's own RCCL communicator, data sharded by rank"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((16, 5000)).astype(np.float32)
+    w = rng.uniform(0, 1, (16, 5000))
+    edges = np.linspace(-4, 4, 51)
+
+    def shard(a, axis):
+        lo, hi = xd.shard_bounds(a.shape[axis], world, rank)
+        sl = [slice(None)] * a.ndim
+        sl[axis] = slice(lo, hi)
+        return torch.as_tensor(np.ascontiguousarray(a[tuple(sl)])).to(dev)
+
+    h, _ = xd.histogram(shard(x, 0), bins=edges, axis=1, shard_axis=0, group=comm)  # kept-axis shards -> all-gather
+    np.testing.assert_array_equal(h.cpu().numpy(), onp.histogram(x, bins=edges, axis=1)[0])
+    h, _ = xd.histogram(shard(x, 1), bins=edges, weights=shard(w, 1), shard_axis=1, group=comm)  # -> all-reduce (f64)
+    np.testing.assert_allclose(h.cpu().numpy(), onp.histogram(x, bins=edges, weights=w)[0], rtol=1e-6)
+    h, e = xd.histogram(shard(x, 1), bins=23, shard_axis=1, group=comm)  # min / max all-reduce, then int64 all-reduce
+    want, we = onp.histogram(x, bins=23)
+    np.testing.assert_array_equal(e[0], we[0])
+    np.testing.assert_array_equal(h.cpu().numpy(), want)
+    h, _ = xd.histogram(x[:, : 100 * (rank + 1)], bins=edges, shard_axis=1, group=comm)  # numpy in (host route)
+    assert isinstance(h, np.ndarray)
+
+
+@pytest.mark.gpu
+def test_single_rank_native_comm():
+    """xhist_comm_* (RCCL dlopen-ed by libxhist_amd.so) end to end on one GPU: id, create, all-reduce of
+    int64 / float64, min / max, all-gather, destroy"""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_np as onp
+    from xhistogram_amd import _native
+    from xhistogram_amd import distributed as xd
+
+    torch.cuda.set_device(0)
+    comm = _native.Comm(0, 0, 1, _native.comm_unique_id())
+    try:
+        assert comm.rccl_version() > 20000
+        t = torch.arange(1000, dtype=torch.int64, device="cuda")
+        comm.allreduce(t.data_ptr(), t.numel(), _native.I64, _native.REDUCE_SUM, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.int64))
+        with pytest.raises(ValueError):
+            comm.allreduce(t.data_ptr(), t.numel(), _native.U8, _native.REDUCE_SUM)
+        _native_cases(xd, onp, comm, 0, 1, torch.device("cuda", 0))
+    finally:
+        comm.close()
+
+
+def _native_worker(rank, world, id_bytes, q):
+    sys.path.insert(0, ROOT)
+    try:
+        from oracle import oracle_np as onp
+        from xhistogram_amd import _native
+        from xhistogram_amd import distributed as xd
+
+        torch.cuda.set_device(rank)
+        comm = _native.Comm(rank, rank, world, id_bytes)
+        try:
+            _native_cases(xd, onp, comm, rank, world, torch.device("cuda", rank))
+        finally:
+            comm.close()
+        q.put((rank, True, ""))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+def test_world2_native_comm():
+    """two processes, two GPUs, no torch.distributed anywhere: the id travels through a pipe"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    sys.path.insert(0, ROOT)
+    from xhistogram_amd import _native
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ident = _native.comm_unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, ident, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, "rank %d: %s" % (rank, msg)
+
+
+def test_native_comm_fails_loudly_without_a_gpu():
+    sys.path.insert(0, ROOT)
+    from xhistogram_amd import _native
+
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device|not available"):
+        _native.comm_unique_id()
+    with pytest.raises(RuntimeError, match="not available"):
+        _native.Comm(0, 0, 1, b"\0" * _native.COMM_ID_BYTES)
+    with pytest.raises(ValueError):
+        _native.Comm(0, 0, 1, b"short")
+    with pytest.raises(ValueError):
+        _native.Comm(0, 3, 2, b"\0" * _native.COMM_ID_BYTES)

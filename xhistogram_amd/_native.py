@@ -18,11 +18,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DIMS = 8
 
 # status codes (xhist_status)
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_EDGES = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_EDGES, ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 
 # dtype tags (xhist_dtype)
 F64, F32, F16, I64, I32, I16, I8, U64, U32, U16, U8, BOOL = range(12)
@@ -30,6 +30,8 @@ CMP_F64, CMP_I64 = 0, 1
 CMP_PER_DIM = 0x100  # | mask: bit d set <=> input d compares in int64 (XHIST_CMP_PER_DIM)
 CMP_UNSIGNED = 0x200  # | onto CMP_I64 / CMP_PER_DIM: the int64-domain inputs are unsigned 64-bit (edges passed as uint64)
 MEM_HOST, MEM_DEVICE = 0, 1
+COMM_ID_BYTES = 128
+REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
 
 _NP_TAG = {
     np.dtype(np.float64): F64, np.dtype(np.float32): F32, np.dtype(np.float16): F16,
@@ -68,7 +70,8 @@ EXPORTS = (
     "xhist_abi_version", "xhist_last_error", "xhist_device_count", "xhist_device_info",
     "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
     "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
-    "xhist_shutdown",
+    "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
+    "xhist_comm_destroy", "xhist_shutdown",
 )
 
 
@@ -108,6 +111,12 @@ def load():
         lib.xhist_plan_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.xhist_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.xhist_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        lib.xhist_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xhist_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.xhist_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.xhist_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        lib.xhist_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        lib.xhist_comm_destroy.argtypes = [C.c_void_p]
         for name in EXPORTS:
             getattr(lib, name)  # AttributeError here = header and library disagree
         if lib.xhist_abi_version() != ABI_VERSION:
@@ -252,6 +261,50 @@ def minmax(view, n_rows, n_cols, mem_kind, device=0, stream=0):
     out = (C.c_double * 2)()
     check(load().xhist_minmax(int(device), C.byref(view), int(n_rows), int(n_cols), out, int(mem_kind), C.c_void_p(stream or 0)))
     return out[0], out[1]
+
+
+def comm_unique_id():
+    """128 opaque bytes from RCCL (rank 0 calls this and hands them to every rank out of band)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(load().xhist_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class Comm:
+    """One RCCL communicator bound to one GPU (xhist_comm): the exchange step of sharded inputs for
+    hosts without torch.distributed.  ``Comm(device, rank, world_size, unique_id)`` is collective —
+    it returns once every rank has joined.  Buffers are device pointers; calls are asynchronous on
+    ``stream`` and must be issued in the same order on every rank."""
+
+    def __init__(self, device, rank, world_size, unique_id):
+        lib = load()
+        unique_id = bytes(unique_id)
+        h = C.c_void_p()
+        check(lib.xhist_comm_create(int(device), int(rank), int(world_size), unique_id, len(unique_id), C.byref(h)))
+        self._h = h
+        self.device, self.rank, self.world_size = int(device), int(rank), int(world_size)
+
+    def rccl_version(self):
+        v = C.c_int(0)
+        check(load().xhist_comm_info(self._h, None, None, None, C.byref(v)))
+        return int(v.value)
+
+    def allreduce(self, ptr, count, tag, op=REDUCE_SUM, stream=0):
+        check(load().xhist_comm_allreduce(self._h, C.c_void_p(ptr), int(count), int(tag), int(op), C.c_void_p(stream)))
+
+    def allgather(self, send_ptr, recv_ptr, count, tag, stream=0):
+        check(load().xhist_comm_allgather(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), int(tag), C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            h, self._h = self._h, None
+            check(load().xhist_comm_destroy(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shutdown():

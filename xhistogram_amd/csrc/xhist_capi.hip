@@ -19,6 +19,7 @@
 #include "xhist_plan.hip.h"
 #include "xhist_select.hip.h"
 #include "xhist_exec_device.hip.h"
+#include "xhist_comm.hip.h"
 
 // ------------------------------------------------------------------------------------------
 // host-resident execute: stage chunks through device memory (PCIe-bound by construction)

@@ -56,6 +56,80 @@ def _comm_device(group):
     return torch.device("cpu")
 
 
+class _TorchExchange:
+    """the three collectives this module needs, on a torch.distributed process group"""
+
+    def __init__(self, group):
+        dist = _dist()
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (one process per GPU, backend 'nccl' = RCCL)")
+        self.group = group
+        self.device = _comm_device(group)
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t, op="sum"):
+        dist = _dist()
+        rop = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op]
+        dist.all_reduce(t, op=rop, group=self.group)
+
+    def all_gather(self, t):
+        import torch
+
+        parts = [torch.empty_like(t) for _ in _range(self.world)]
+        _dist().all_gather(parts, t, group=self.group)
+        return parts
+
+
+class _NativeExchange:
+    """the same collectives through the C ABI's xhist_comm_* (RCCL loaded by libxhist_amd.so itself):
+    what a host without torch.distributed binds; ``group`` is a :class:`xhistogram_amd._native.Comm`"""
+
+    def __init__(self, comm):
+        import torch
+
+        self.comm = comm
+        self.device = torch.device("cuda", comm.device)
+        self.rank = comm.rank
+        self.world = comm.world_size
+
+    def _tag(self, t):
+        import torch
+
+        from . import _native
+
+        try:
+            return {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
+        except KeyError:
+            raise TypeError("histograms exchanged between GPUs are int64, float64 or float32, not %s" % t.dtype) from None
+
+    def _stream(self):
+        import torch
+
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def all_reduce(self, t, op="sum"):
+        from . import _native
+
+        assert t.is_cuda and t.is_contiguous()
+        rop = {"sum": _native.REDUCE_SUM, "min": _native.REDUCE_MIN, "max": _native.REDUCE_MAX}[op]
+        self.comm.allreduce(t.data_ptr(), t.numel(), self._tag(t), rop, self._stream())
+
+    def all_gather(self, t):
+        import torch
+
+        assert t.is_cuda and t.is_contiguous()
+        recv = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.comm.allgather(t.data_ptr(), recv.data_ptr(), t.numel(), self._tag(t), self._stream())
+        return list(recv.unbind(0))
+
+
+def _exchange(group):
+    from . import _native
+
+    return _NativeExchange(group) if isinstance(group, _native.Comm) else _TorchExchange(group)
+
+
 def _local_extrema(a):
     """(min, max, has_nan) of a local shard without moving it off its device"""
     if core._is_torch(a):
@@ -82,11 +156,10 @@ def _local_extrema(a):
     return (np.inf if nan else lo), (-np.inf if nan else hi), nan
 
 
-def _global_edges(arrays, bins, ranges, group):
+def _global_edges(arrays, bins, ranges, ex):
     """np.histogram_bin_edges (core.py:383-388) on data that is spread over the ranks"""
     import torch
 
-    dist = _dist()
     out = []
     for a, b, r in zip(arrays, bins, ranges):
         if isinstance(b, str):
@@ -94,11 +167,10 @@ def _global_edges(arrays, bins, ranges, group):
         proto = core._np_dtype_of(a) if core._is_torch(a) else np.asarray(a).dtype
         if np.ndim(b) == 0 and r is None:
             lo, hi, nan = _local_extrema(a)
-            dev = _comm_device(group)
-            mn = torch.tensor([lo], dtype=torch.float64, device=dev)
-            mx = torch.tensor([hi, nan], dtype=torch.float64, device=dev)
-            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+            mn = torch.tensor([lo], dtype=torch.float64, device=ex.device)
+            mx = torch.tensor([hi, nan], dtype=torch.float64, device=ex.device)
+            ex.all_reduce(mn, "min")
+            ex.all_reduce(mx, "max")
             glo, ghi, gnan = float(mn[0]), float(mx[0]), float(mx[1])
             if gnan:
                 glo = ghi = np.nan
@@ -125,14 +197,13 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     broadcasting).  Arguments as in :func:`xhistogram_amd.core.histogram`.  Returns
     ``(hist, bin_edges)`` with ``hist`` on every rank: the all-reduced full histogram when
     ``shard_axis`` is one of the histogrammed axes, else the row-gathered one (this rank's rows
-    only with ``gather=False``).  ``_local`` swaps the rank-local compute (tests run the
+    only with ``gather=False``).  ``group`` is a torch.distributed process group (None = the default
+    one) or a :class:`xhistogram_amd._native.Comm` (the C ABI's own RCCL communicator).  ``_local`` swaps the rank-local compute (tests run the
     collective logic on CPU with the oracle; production never sets it).
     """
     import torch
 
-    dist = _dist()
-    if not dist.is_initialized():
-        raise RuntimeError("torch.distributed is not initialised (one process per GPU, backend 'nccl' = RCCL)")
+    ex = _exchange(group)
     local = _local or _default_local
 
     n_inputs = len(args)
@@ -158,7 +229,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
 
     bins = core._ensure_correctly_formatted_bins(bins, n_inputs)
     range = core._ensure_correctly_formatted_range(range, n_inputs)
-    edges = _global_edges(all_arrays[:n_inputs], bins, range, group)
+    edges = _global_edges(all_arrays[:n_inputs], bins, range, ex)
 
     counts = local(all_arrays, has_weights, axis, edges, block_size)
     as_numpy = not core._is_torch(counts)
@@ -167,26 +238,24 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     keep_shape = [s for i, s in enumerate(t.shape) if i not in drop]
     t = t.reshape(keep_shape)
 
-    comm_dev = _comm_device(group)
+    comm_dev = ex.device
     back = t.device
     t = t.to(comm_dev).contiguous()
     if shard_axis in reduced:
         # the reference's `.sum(drop_axes)` over blocks (core.py:439): one all-reduce of the partial
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        ex.all_reduce(t, "sum")
     elif gather:
         # disjoint rows: concatenate along the kept axis the shards were cut on
         pos = shard_axis - sum(1 for ax in drop if ax < shard_axis)
-        world = dist.get_world_size(group)
-        sizes = torch.zeros(world, dtype=torch.int64, device=comm_dev)
-        sizes[dist.get_rank(group)] = t.shape[pos]
-        dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+        sizes = torch.zeros(ex.world, dtype=torch.int64, device=comm_dev)
+        sizes[ex.rank] = t.shape[pos]
+        ex.all_reduce(sizes, "sum")
         sizes = [int(s) for s in sizes.tolist()]
         moved = t.movedim(pos, 0).contiguous()
         cap = max(sizes)  # equal-size buffers: shards may be ragged, collectives are not
         padded = torch.zeros((cap,) + tuple(moved.shape[1:]), dtype=t.dtype, device=comm_dev)
         padded[: moved.shape[0]] = moved
-        parts = [torch.empty_like(padded) for _ in sizes]
-        dist.all_gather(parts, padded, group=group)
+        parts = ex.all_gather(padded)
         t = torch.cat([part[:s] for part, s in zip(parts, sizes)], dim=0).movedim(0, pos).contiguous()
     t = t.to(back)
     h = t.numpy() if as_numpy else t
