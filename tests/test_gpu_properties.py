@@ -181,3 +181,36 @@ def test_random_large_device_cases_match_oracle(xh, case):
     tw = None if w is None else torch.as_tensor(w).cuda()
     got, _ = xh.histogram(*targs, weights=tw, **kw)
     assert_hist_equal(got.cpu().numpy(), want, weighted=w is not None)
+
+
+def test_more_than_2_31_elements(xh):
+    """indices are 64-bit everywhere: 2.6e9 float32 samples (10.4 GB) as one row, as rows x columns,
+    over the leading axis (row-per-lane kernels) and weighted, against sums of sub-range histograms"""
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    n = 2_600_000_000
+    if free < 30 * 2**30:
+        pytest.skip("needs 30 GB of free device memory")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.empty(n, dtype=torch.float32, device=dev).uniform_(-1.1, 1.1, generator=g)
+    e = np.linspace(-1, 1, 101)
+    inside = int(((x >= -1) & (x <= 1)).sum().item())
+    h, _ = xh.histogram(x, bins=e)
+    cuts = (0, 900_000_000, 2_200_000_003, n)
+    parts = sum(xh.histogram(x[a:b], bins=e)[0] for a, b in zip(cuts, cuts[1:]))
+    assert torch.equal(h, parts) and int(h.sum().item()) == inside
+    x2 = x[: 5 * 500_000_000].view(5, 500_000_000)
+    h2, _ = xh.histogram(x2, bins=e, axis=1)
+    assert torch.equal(h2[4], xh.histogram(x2[4], bins=e)[0])
+    x3 = x.view(2600, 1_000_000)
+    e3 = np.linspace(-1, 1, 11)
+    h3, _ = xh.histogram(x3, bins=e3, axis=0)
+    assert int(h3.sum().item()) == inside
+    assert torch.equal(h3[999_999], xh.histogram(x3[:, 999_999].contiguous(), bins=e3)[0])
+    hb, eb = xh.histogram(x, bins=64)  # device min / max over the whole array
+    assert int(hb.sum().item()) == n
+    w = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0, 1, generator=g)
+    hw, _ = xh.histogram(x, bins=e, weights=w)
+    hwp = sum(xh.histogram(x[a:b], bins=e, weights=w[a:b])[0] for a, b in zip(cuts, cuts[1:]))
+    assert float((hw - hwp).abs().max() / hw.abs().max()) < 1e-12
