@@ -22,9 +22,15 @@ from oracle import oracle_np as onp
 xhx = importlib.import_module("xhistogram_amd.xarray")
 
 
+def _two_passes(*args, weights=None, **kw):
+    ha, edges = onp.histogram(*args, weights=weights[0], **kw)
+    return ha, onp.histogram(*args, weights=weights[1], **kw)[0], edges
+
+
 @pytest.fixture
 def cpu_compute(monkeypatch):
     monkeypatch.setattr(xhx, "_core_histogram", onp.histogram)
+    monkeypatch.setattr(xhx, "_core_histogram_two_weights", _two_passes)
 
 
 def _ones(dims, shape, name="T", with_coords=True):
@@ -107,6 +113,23 @@ def test_errors(cpu_compute):  # test_xarray.py:215-218, xarray.py:116-117, 126
         xhx.histogram(a, b, bins=[np.linspace(0, 2, 3)] * 2)
 
 
+def test_pair_of_weights_gives_pair_of_histograms(cpu_compute):  # the TODO at xarray.py:106
+    rng = np.random.default_rng(8)
+    t = xr.DataArray(rng.standard_normal((5, 6, 7)), dims=["time", "lat", "lon"], name="T")
+    area = xr.DataArray(rng.uniform(1, 2, (6, 7)), dims=["lat", "lon"], name="area")
+    salt = xr.DataArray(rng.uniform(30, 40, (5, 6, 7)), dims=["time", "lat", "lon"], name="S")
+    bins = np.linspace(-3, 3, 13)
+    flux = xr.DataArray(salt.values * area.values, dims=["time", "lat", "lon"], name="flux")
+    num, den = xhx.histogram(t, bins=[bins], dim=["lat", "lon"], weights=(flux, area))
+    assert list(num.dims) == list(den.dims) == ["time", "T_bin"] and num.name == den.name == "histogram_T"
+    np.testing.assert_allclose(num.values, xhx.histogram(t, bins=[bins], dim=["lat", "lon"], weights=flux).values, rtol=1e-12)
+    np.testing.assert_allclose(den.values, xhx.histogram(t, bins=[bins], dim=["lat", "lon"], weights=area).values, rtol=1e-12)
+    with pytest.raises(ValueError):
+        xhx.histogram(t, bins=[bins], weights=(area, area), density=True)
+    with pytest.raises(ValueError):
+        xhx.histogram(t, bins=[bins], weights=(area,))
+
+
 @pytest.mark.gpu
 def test_wrapper_over_hip_path():
     torch = pytest.importorskip("torch")
@@ -120,3 +143,8 @@ def test_wrapper_over_hip_path():
     dg = xr.DataArray(torch.as_tensor(t).cuda(), dims=["time", "lat", "lon"], name="T")  # GPU-resident data
     hg = xhx.histogram(dg, bins=[bins], dim=["lat", "lon"])
     np.testing.assert_array_equal(hg.values, h.values)
+    w = xr.DataArray(rng.uniform(0, 1, (40, 50)), dims=["lat", "lon"], name="w")
+    tw = xr.DataArray(t * w.values, dims=["time", "lat", "lon"], name="Tw")
+    num, den = xhx.histogram(da, bins=[bins], dim=["lat", "lon"], weights=(tw, w))  # one pass, two weights
+    np.testing.assert_allclose(num.values, onp.histogram(t, bins=bins, axis=(1, 2), weights=t * w.values)[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(den.values, onp.histogram(t, bins=bins, axis=(1, 2), weights=np.broadcast_to(w.values, t.shape))[0], rtol=1e-6)

@@ -9,6 +9,7 @@ besides the bin centres; the data arrays (numpy, dask, or GPU-resident) go strai
 from __future__ import annotations
 
 from .core import histogram as _core_histogram
+from .core import histogram_two_weights as _core_histogram_two_weights
 
 __all__ = ["histogram"]
 
@@ -32,7 +33,9 @@ def histogram(*args, bins=None, range=None, dim=None, weights=None, density=Fals
         (``join="exact"``); they are broadcast against each other by dimension name.
     bins, range, weights, density, block_size
         As in :func:`xhistogram_amd.core.histogram`.  ``weights`` is a DataArray whose dims are a
-        subset of the data's.
+        subset of the data's — or (an extension: the reference's TODO at xarray.py:106) a PAIR of
+        such DataArrays, binned in one pass over the data; the result is then a pair of
+        DataArrays (mean of ``A`` in the bins = ``h[0] / h[1]`` for ``weights=(A * w, w)``).
     dim : tuple of strings, optional
         Dimensions to histogram over; default all.
     keep_coords : bool
@@ -59,8 +62,14 @@ def histogram(*args, bins=None, range=None, dim=None, weights=None, density=Fals
     operands = list(data_args)
     if not keep_coords:  # coordinates only get in the way of alignment (xarray.py:119-123)
         operands = [a.reset_coords(drop=True) for a in operands]
-    if weights is not None:
-        operands.append(weights.reset_coords(drop=True))
+    pair = isinstance(weights, (tuple, list))
+    if pair:
+        if len(weights) != 2:
+            raise ValueError("weights must be one DataArray or a pair of them")
+        if density:
+            raise ValueError("density is not defined for a pair of weights")
+    w_ops = list(weights) if pair else ([] if weights is None else [weights])
+    operands.extend(w.reset_coords(drop=True) for w in w_ops)
     operands = list(xr.align(*operands, join="exact"))  # xarray.py:126
     first = operands[0]
     first_coords = first.coords
@@ -81,7 +90,7 @@ def histogram(*args, bins=None, range=None, dim=None, weights=None, density=Fals
             a = a.transpose(*dims_order)
         lined_up.append(a)
     arrays = [a.data for a in lined_up]
-    w_data = arrays.pop() if weights is not None else None
+    w_data = [arrays.pop() for _ in w_ops][::-1]
 
     if dim is not None:  # xarray.py:157-162
         kept_dims = [d for d in dims_order if d not in dim]
@@ -90,9 +99,16 @@ def histogram(*args, bins=None, range=None, dim=None, weights=None, density=Fals
         kept_dims = []
         axis = None
 
-    h_data, edges = _core_histogram(
-        *arrays, weights=w_data, bins=bins, range=range, axis=axis, density=density, block_size=block_size
-    )
+    if pair:
+        *h_all, edges = _core_histogram_two_weights(
+            *arrays, weights=tuple(w_data), bins=bins, range=range, axis=axis, block_size=block_size
+        )
+    else:
+        h_data, edges = _core_histogram(
+            *arrays, weights=w_data[0] if w_data else None, bins=bins, range=range, axis=axis, density=density,
+            block_size=block_size
+        )
+        h_all = [h_data]
 
     # output labels (xarray.py:174-201)
     bin_dims = [a.name + bin_dim_suffix for a in operands[:n_data]]
@@ -105,4 +121,5 @@ def histogram(*args, bins=None, range=None, dim=None, weights=None, density=Fals
             if c not in coords and set(first[c].dims).issubset(out_dims):
                 coords[c] = first[c]
     out_name = "_".join(["histogram"] + [a.name for a in operands[:n_data]])
-    return xr.DataArray(h_data, dims=out_dims, coords=coords, name=out_name)
+    out = tuple(xr.DataArray(h, dims=out_dims, coords=coords, name=out_name) for h in h_all)
+    return out if pair else out[0]
