@@ -629,6 +629,26 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     while (block < 256 && block * 2 <= want) block *= 2;
   }
   int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
+  if (!block_threads && !grid_blocks && n_rows == 1 && fast && hist == kHistLds && lds_bytes <= 40 * 1024) {
+    // One row, small histogram: every workgroup costs ~15-20 ns at the end (its flush atomics meet the
+    // other workgroups' on the same addresses), which is 15-25 % of a 10^7..10^8-sample call with 1024
+    // workgroups — so ONE workgroup per CU, as wide as the loads in flight ask for.  Measured
+    // (tools/size_ramp.py, profiles/r01_u_*): ~32 KiB per CU for 8-byte samples (f64: 512 threads),
+    // ~64 KiB for 4-byte samples, which do twice the LDS atomics per byte (f32: 1024 threads); 8-byte
+    // samples with 128 B per lane (f64 + f64 weights, two f64 inputs) only below 256 MB — above, two
+    // 256-thread workgroups per CU are 15-20 % ahead.  The block shrinks until the row has a tile for
+    // half the CUs.
+    int64_t ssz = 0, row_bytes = 0;
+    for (int d = 0; d < D; ++d) ssz = std::max<int64_t>(ssz, dtype_size(samples[d].dtype));
+    row_bytes = n_cols * (lane_bytes / ((int64_t)vec * kUnroll));
+    if (!(lane_bytes >= 128 && ssz >= 8 && row_bytes > ((int64_t)256 << 20))) {
+      const int64_t per_cu = (ssz >= 8 ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
+      block = (int)std::min<int64_t>(1024, std::max<int64_t>(256, per_cu / 256 * 256));
+      while (block > 256 && n_cols / ((int64_t)block * vec * kUnroll) < p->cus / 2) block -= 256;
+      if (block == 768) block = 512;
+      bpc = 1;
+    }
+  }
   bpc = std::min<int>(bpc, 2048 / block);
   if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
   // one row: the segs workgroups share the row's tiles round-robin, so exactly one resident wave
@@ -637,10 +657,10 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc * (n_rows > 1 ? 8 : 1);
   if (!grid_blocks && n_rows == 1) {
     // small inputs: every workgroup ends with one global atomic per non-empty bin, and atomics on
-    // one address serialise at ~12 ns; streaming gains ~25 GB/s per workgroup.  The sum of the
+    // one address serialise at ~12 ns; streaming gains ~25 GB/s per 256 threads.  The sum of the
     // two is minimal at sqrt(bytes / (25 GB/s * 12 ns)) workgroups (10^6 f64 samples: 18 -> 9 us)
     const double bytes = (double)n_cols * (double)(lane_bytes / (fast ? (int64_t)vec * kUnroll : 4));
-    target = std::max<int64_t>(1, std::min<int64_t>(target, (int64_t)std::sqrt(bytes / 300.0)));
+    target = std::max<int64_t>(1, std::min<int64_t>(target, (int64_t)std::sqrt(bytes / (300.0 * block / 256))));
   }
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
   const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
