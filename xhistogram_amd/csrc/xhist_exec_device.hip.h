@@ -629,38 +629,70 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     while (block < 256 && block * 2 <= want) block *= 2;
   }
   int bpc = (int)std::max<int64_t>(1, std::min<int64_t>(8, (64 * 1024 + block * lane_bytes / 2) / (block * lane_bytes)));
-  if (!block_threads && !grid_blocks && n_rows == 1 && fast && hist == kHistLds && lds_bytes <= 40 * 1024) {
-    // One row, small histogram: every workgroup costs ~15-20 ns at the end (its flush atomics meet the
-    // other workgroups' on the same addresses), which is 15-25 % of a 10^7..10^8-sample call with 1024
-    // workgroups — so ONE workgroup per CU, as wide as the loads in flight ask for.  Measured
+  // Many rows: a workgroup is tied to one row, so the tail is balanced by OVERSUBSCRIBING the chip 8x
+  // with small workgroups (C4 shape: 5.6 -> 6.5 TB/s) — as long as their flushes are cheap: every
+  // workgroup ends with one global atomic per non-empty bin (runs of consecutive bins: ~2*10^11 per
+  // second for the chip), and the workgroups of one row meet on the same addresses (~25 ns each).  The
+  // factor is halved until the flushes would take under 20 % of the streaming time; a few rows are one
+  // row in a few parts and never oversubscribe.
+  // (2 x 5*10^7 f32, 50 bins: 8192 workgroups 149 us, 2 x 128 of 1024 threads 65 us;
+  //  32 x 312500 f64, 1000 bins: 4896 workgroups 45 us, 32 x 8 of 512 threads 19 us.)
+  const int64_t sample_bytes = lane_bytes / (fast ? (int64_t)vec * kUnroll : 4);
+  const double total_samples = (double)n_rows * (double)n_cols;
+  int over = n_rows <= 16 ? 1 : 8;
+  if (!grid_blocks && over > 1) {
+    const double t_stream = total_samples * (double)sample_bytes / 6.0e12;
+    while (over > 1) {
+      const double wgs = std::max<double>((double)n_rows, (double)p->cus * bpc * over);
+      const double dense = wgs * std::min<double>((double)p->n_bins, total_samples / wgs) / 2.0e11;
+      const double serial = wgs / (double)n_rows * 25e-9;
+      if (std::max(dense, serial) <= 0.2 * t_stream) break;
+      over /= 2;
+    }
+  }
+  const bool exact = over == 1;  // exactly the workgroups that are resident at once, a whole number per row
+  if (!block_threads && !grid_blocks && exact && n_cols >= 65536 && fast && hist == kHistLds && lds_bytes <= 40 * 1024) {
+    // Small histogram, long rows: ONE workgroup per CU, as wide as the loads in flight ask for.  Measured
     // (tools/size_ramp.py, profiles/r01_u_*): ~32 KiB per CU for 8-byte samples (f64: 512 threads),
     // ~64 KiB for 4-byte samples, which do twice the LDS atomics per byte (f32: 1024 threads); 8-byte
     // samples with 128 B per lane (f64 + f64 weights, two f64 inputs) only below 256 MB — above, two
-    // 256-thread workgroups per CU are 15-20 % ahead.  The block shrinks until the row has a tile for
-    // half the CUs.
-    int64_t ssz = 0, row_bytes = 0;
+    // 256-thread workgroups per CU are 15-20 % ahead.  The block shrinks until there is a tile for half
+    // the CUs, and to whatever size lets a whole number of workgroups per row fill the chip best.
+    int64_t ssz = 0;
     for (int d = 0; d < D; ++d) ssz = std::max<int64_t>(ssz, dtype_size(samples[d].dtype));
-    row_bytes = n_cols * (lane_bytes / ((int64_t)vec * kUnroll));
-    if (!(lane_bytes >= 128 && ssz >= 8 && row_bytes > ((int64_t)256 << 20))) {
+    int64_t threads_per_cu = (int64_t)bpc * 256;  // (block is 64..256 here, bpc was sized for 256)
+    block = 256;
+    if (!(lane_bytes >= 128 && ssz >= 8 && total_samples * (double)sample_bytes > (double)((int64_t)256 << 20))) {
       const int64_t per_cu = (ssz >= 8 ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
-      block = (int)std::min<int64_t>(1024, std::max<int64_t>(256, per_cu / 256 * 256));
-      while (block > 256 && n_cols / ((int64_t)block * vec * kUnroll) < p->cus / 2) block -= 256;
+      threads_per_cu = std::min<int64_t>(1024, std::max<int64_t>(256, per_cu / 256 * 256));
+      block = (int)threads_per_cu;
+      while (block > 256 && n_rows * (n_cols / ((int64_t)block * vec * kUnroll)) < p->cus / 2) block -= 256;
       if (block == 768) block = 512;
-      bpc = 1;
+    }
+    const int64_t slots = (int64_t)p->cus * threads_per_cu;  // threads the launch should keep resident
+    int best = 256;
+    int64_t best_used = -1;
+    for (int b = block; b >= 256; b /= 2) {
+      const int64_t used = n_rows * (slots / (n_rows * b)) * b;
+      if (used > best_used + best_used / 16) { best_used = used; best = b; }  // a smaller block must fill 6 % more
+    }
+    if (best_used > 0) {
+      block = best;
+      bpc = (int)std::max<int64_t>(1, threads_per_cu / block);
+    } else {
+      block = 256;  // more rows than the chip holds workgroups: one 256-thread workgroup each
     }
   }
   bpc = std::min<int>(bpc, 2048 / block);
   if (lds_bytes) bpc = std::max<int>(1, std::min<int64_t>(bpc, (int64_t)(160 * 1024 / lds_bytes)));
-  // one row: the segs workgroups share the row's tiles round-robin, so exactly one resident wave
-  // of workgroups is balanced by construction.  Many rows: a workgroup is tied to one row, so the
-  // tail is balanced by making 8x more, smaller workgroups (C4 shape: 5.6 -> 6.5 TB/s)
-  int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc * (n_rows > 1 ? 8 : 1);
-  if (!grid_blocks && n_rows == 1) {
-    // small inputs: every workgroup ends with one global atomic per non-empty bin, and atomics on
-    // one address serialise at ~12 ns; streaming gains ~25 GB/s per 256 threads.  The sum of the
-    // two is minimal at sqrt(bytes / (25 GB/s * 12 ns)) workgroups (10^6 f64 samples: 18 -> 9 us)
-    const double bytes = (double)n_cols * (double)(lane_bytes / (fast ? (int64_t)vec * kUnroll : 4));
-    target = std::max<int64_t>(1, std::min<int64_t>(target, (int64_t)std::sqrt(bytes / (300.0 * block / 256))));
+  int64_t target = grid_blocks ? grid_blocks : (int64_t)p->cus * bpc * over;
+  if (!grid_blocks && exact) {
+    // small inputs: streaming gains ~25 GB/s per 256 threads, every workgroup of a row costs ~12 ns at the
+    // end.  The sum of the two is minimal at sqrt(bytes / (25 GB/s * 12 ns)) workgroups per row
+    // (10^6 f64 samples: 18 -> 9 us)
+    const double bytes = (double)n_cols * (double)sample_bytes;
+    const int64_t per_row = std::min<int64_t>(std::max<int64_t>(1, target / n_rows), (int64_t)std::sqrt(bytes / (300.0 * block / 256)));
+    target = std::max<int64_t>(1, per_row) * n_rows;  // a whole number per row, never more than are resident at once
   }
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
   const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
