@@ -239,4 +239,30 @@ __global__ void __launch_bounds__(256) transpose_2d(const T* __restrict__ in, in
   }
 }
 
+// The other direction for a FEW rows: a view whose rows are the contiguous direction ([N, k] reduced over
+// its leading axis: element (r, c) at in[c * cs + r]) -> k dense rows of N.  Tiles of `tc` columns through
+// LDS: the tile is read in memory order (one run of tc * k elements when cs == k) and written as k runs of
+// tc elements.
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ in, int64_t cs, int n_rows, int64_t n_cols, T* __restrict__ out, int tc) {
+  T* tile = reinterpret_cast<T*>(xhist_smem);
+  const int pitch = tc + 1;
+  const int64_t n_tiles = (n_cols + tc - 1) / tc;
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t c0 = tl * tc;
+    const int cols_here = (int)min<int64_t>((int64_t)tc, n_cols - c0);
+    const int n_el = cols_here * n_rows;
+    for (int i = threadIdx.x; i < n_el; i += 256) {
+      const int cl = i / n_rows, r = i - cl * n_rows;
+      tile[r * pitch + cl] = in[(c0 + cl) * cs + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_el; i += 256) {
+      const int r = i / cols_here, cl = i - r * cols_here;
+      out[(int64_t)r * n_cols + c0 + cl] = tile[r * pitch + cl];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace xhist
