@@ -713,9 +713,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   const bool exact = over == 1;  // exactly the workgroups that are resident at once, a whole number per row
   if (!block_threads && !grid_blocks && exact && n_cols >= 65536 && fast && hist == kHistLds && lds_bytes <= 40 * 1024) {
     // Small histogram, long rows: ONE workgroup per CU, as wide as the loads in flight ask for.  Measured
-    // (tools/size_ramp.py, profiles/r01_u_*): ~32 KiB per CU for 8-byte samples (f64: 512 threads),
-    // ~64 KiB for 4-byte samples, which do twice the LDS atomics per byte (f32: 1024 threads); 8-byte
-    // samples with 128 B per lane (f64 + f64 weights, two f64 inputs) only below 256 MB — above, two
+    // (tools/size_ramp.py, profiles/r01_u_*): ~32 KiB per CU for 8-byte samples with the one-compare
+    // digitize (f64, uniform-style edges: 512 threads), ~64 KiB for 4-byte samples, which do twice the LDS
+    // atomics per byte, and for every heavier digitize (f32, non-uniform edges, int64 domain: 1024; 8-byte
+    // geometric edges at 512 threads: 300 us per 10^8, at 1024: 234).  8-byte samples with 128 B per lane
+    // (f64 + f64 weights, two f64 inputs) only below 256 MB — above, two
     // 256-thread workgroups per CU are 15-20 % ahead.  The block shrinks until there is a tile for half
     // the CUs, and to whatever size lets a whole number of workgroups per row fill the chip best.
     int64_t ssz = 0;
@@ -723,7 +725,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     int64_t threads_per_cu = (int64_t)bpc * 256;  // (block is 64..256 here, bpc was sized for 256)
     block = 256;
     if (!(lane_bytes >= 128 && ssz >= 8 && total_samples * (double)sample_bytes > (double)((int64_t)256 << 20))) {
-      const int64_t per_cu = (ssz >= 8 ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
+      const int64_t per_cu = (ssz >= 8 && scan == 1 && float_samples ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
       threads_per_cu = std::min<int64_t>(1024, std::max<int64_t>(256, per_cu / 256 * 256));
       block = (int)threads_per_cu;
       while (block > 256 && n_rows * (n_cols / ((int64_t)block * vec * kUnroll)) < p->cus / 2) block -= 256;
