@@ -609,7 +609,15 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const int part_shift = weighted ? 14 : 15;
     const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) &&
                          ((p->n_bins + ((int64_t)1 << part_shift) - 1) >> part_shift) <= kPartMaxParts;
-    const bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 13 * S * B <= 20 * (B + 8 + 2 * rec) : S <= 16));
+    bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 13 * S * B <= 20 * (B + 8 + 2 * rec) : S <= 16));
+    if (choose && slices_pref == 0) {
+      // few samples: S launches cost S x ~13 us before they stream anything, memory-side atomics 2.4-2.7 x 10^10
+      // per second (10^5 samples, 256 x 256 weighted bins: 4 slices 54 us, global atomics 13 us)
+      const double n_tot = (double)n_rows * (double)n_cols;
+      const double t_global = 8e-6 + n_tot / (weighted ? 2.4e10 : 2.7e10);
+      const double t_slices = (double)S * (13e-6 + n_tot * (double)B / 4.0e12);
+      choose = t_slices <= t_global;
+    }
     if (choose && S >= 1) {
       const int shist = weighted ? kHistLds : kHistPacked;
       kernel_fn sfn = fast_kernel_sliced(sdt, wdt, D, scan, shist, &vec);
@@ -752,9 +760,16 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     // small inputs: streaming gains ~25 GB/s per 256 threads, every workgroup of a row costs ~12 ns at the
     // end.  The sum of the two is minimal at sqrt(bytes / (25 GB/s * 12 ns)) workgroups per row
     // (10^6 f64 samples: 18 -> 9 us)
+    // A big histogram raises the second term: a workgroup flushes min(bins, its samples) counters at
+    // ~2*10^11 per second (256 x 256 packed counters, 10^7 samples: 256 workgroups 117 us, 96: 94 us).
     const double bytes = (double)n_cols * (double)sample_bytes;
-    const int64_t per_row = std::min<int64_t>(std::max<int64_t>(1, target / n_rows), (int64_t)std::sqrt(bytes / (300.0 * block / 256)));
-    target = std::max<int64_t>(1, per_row) * n_rows;  // a whole number per row, never more than are resident at once
+    const double rate = 25e9 * block / 256;
+    const int64_t cap = std::max<int64_t>(1, target / n_rows);
+    int64_t per_row = std::max<int64_t>(1, std::min<int64_t>(cap, (int64_t)std::sqrt(bytes / (rate * 12e-9))));
+    const double flushed = std::min<double>((double)(n_slices > 1 ? slice_bins : p->n_bins), (double)n_cols / (double)per_row);
+    const double per_wg = std::max(12e-9, flushed / 2.0e11);
+    per_row = std::max<int64_t>(1, std::min<int64_t>(cap, (int64_t)std::sqrt(bytes / (rate * per_wg))));
+    target = per_row * n_rows;  // a whole number per row, never more than are resident at once
   }
   const int64_t tile = fast ? (int64_t)block * vec * kUnroll : (int64_t)block * 4;
   const int64_t tiles_per_row = (n_cols + tile - 1) / tile;
