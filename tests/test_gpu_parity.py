@@ -1336,10 +1336,10 @@ def test_more_than_65535_edges_per_dimension(xh, weighted):
 
 
 @pytest.mark.parametrize("dtype,k", [(np.float32, 2), (np.float64, 3), (np.float64, 32), (np.int32, 17), (np.uint8, 32), (np.float16, 5)])
-def test_few_rows_along_the_contiguous_direction_are_gathered(dtype, k):
-    """(N, k) reduced over its leading axis, k small: the k rows are gathered into dense ones on the device
-    (gather_rows) and take the row kernels; with and without weights, dense and padded column stride,
-    device-resident and host arrays."""
+def test_few_rows_along_the_contiguous_direction(dtype, k):
+    """(N, k) reduced over its leading axis, k small (columns of a table): the row-per-lane kernels split
+    their 256 lanes into 256 / R groups of R >= k rows, every group on its own columns; with and without
+    weights, dense and padded column stride, device-resident and host arrays."""
     from xhistogram_amd import _native, core
 
     rng = np.random.default_rng(k)
@@ -1355,15 +1355,15 @@ def test_few_rows_along_the_contiguous_direction_are_gathered(dtype, k):
     for xd in (_dev(np.ascontiguousarray(x_pad[:, :k])), _dev(x_pad)[:, :k]):  # column stride k, then k + 3
         got = core.histogram(xd, bins=edges, axis=0)[0]
         desc = core._get_plan([edges], _native.CMP_F64, 0).describe()
-        assert "gather_rows=1" in desc, desc
+        assert "family=lanes" in desc or np.dtype(dtype).kind != "f" or np.dtype(dtype).itemsize < 4, desc
         assert_hist_equal(got.cpu().numpy(), want, weighted=False)
         gotw = core.histogram(xd, bins=edges, axis=0, weights=_dev(w))[0]
         assert_hist_equal(gotw.cpu().numpy(), wantw, weighted=True)
-    got_host = core.histogram(x_pad[:, :k], bins=edges, axis=0)[0]  # numpy in: staged as it lies, then gathered
+    got_host = core.histogram(x_pad[:, :k], bins=edges, axis=0)[0]  # numpy in: staged as it lies
     assert_hist_equal(got_host, onp.histogram(x_pad[:, :k], bins=edges, axis=0)[0], weighted=False)
     if k != 3:
         return
-    # a per-row broadcast weight stays a broadcast (nothing to gather for it)
+    # a per-row broadcast weight stays a broadcast
     wrow = rng.uniform(0, 1, (n, 1))
     gotb = core.histogram(_dev(x_pad)[:, :k], bins=edges, axis=0, weights=_dev(wrow))[0]
     assert_hist_equal(gotb.cpu().numpy(), onp.histogram(x_pad[:, :k], bins=edges, axis=0, weights=np.broadcast_to(wrow, (n, k)))[0], weighted=True)

@@ -326,7 +326,10 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   kp.n_bins = p->n_bins;
   kp.out = out;
 
-  const int64_t row_blocks = (n_rows + kLaneBlock - 1) / kLaneBlock;
+  int lane_rows = kLaneBlock;  // the smallest power of two that holds the rows when there are fewer than 256
+  while (lane_rows > 1 && lane_rows / 2 >= n_rows) lane_rows /= 2;
+  kp.lane_rows = lane_rows;
+  const int64_t row_blocks = (n_rows + lane_rows - 1) / lane_rows;
   // unweighted and few enough columns per workgroup: uint16 counters, half the LDS
   size_t lds_use = lds_bytes;
   bool packed16 = false;
@@ -397,66 +400,6 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
     lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref;
-  }
-
-  // ---- a few rows that are the contiguous direction ([N, k] over its leading axis, k <= 32) ----
-  // The row-per-lane kernels below would use k of every 64 lanes (10^7 x 2 f32: 1.39 ms); gathering the k
-  // rows into dense ones costs one read and one write of the data and gives them to the row-streaming
-  // kernels (0.10 ms; 5*10^6 x 16: 0.76 -> 0.25 ms; even at 2*10^6 x 32, behind at 48 rows or below
-  // ~4*10^6 elements).
-  if (lanes == 0 && !two && n_rows >= 2 && n_rows <= 32 && n_rows * n_cols >= ((int64_t)1 << 22)) {
-    bool ok = true, any = false;
-    for (int d = 0; d <= D && ok; ++d) {
-      if (d == D && !weighted) break;
-      const xhist_array& a = d < D ? samples[d] : *weights;
-      if (a.row_stride == 0 || a.col_stride == 0 || a.col_stride == 1) continue;  // broadcast or dense rows: stay as they are
-      ok = a.inner_rows == 0 && a.col_stride >= n_rows && a.row_stride == 1 && dtype_size(a.dtype) > 0;
-      any = true;
-    }
-    if (ok && any) {
-      void* scratch[kMaxDims + 1] = {nullptr};
-      xhist_array dense[kMaxDims + 1];
-      int rc = XHIST_OK;
-      for (int d = 0; d <= D && rc == XHIST_OK; ++d) {
-        if (d == D && !weighted) break;
-        const xhist_array& a = d < D ? samples[d] : *weights;
-        dense[d] = a;
-        if (a.row_stride == 0 || a.col_stride == 0 || a.col_stride == 1) continue;
-        const int es = dtype_size(a.dtype);
-        if (hipMallocAsync(&scratch[d], (size_t)n_rows * (size_t)n_cols * es, stream) != hipSuccess) {
-          (void)hipGetLastError();
-          rc = XHIST_ERR_NOMEM;
-          break;
-        }
-        // tile: <= 32 KiB of LDS, a multiple of 64 columns
-        const int tc = (int)std::max<int64_t>(64, std::min<int64_t>(1024, (32 * 1024 / ((int64_t)n_rows * es)) / 64 * 64));
-        const size_t lds = (size_t)(tc + 1) * (size_t)n_rows * es;
-        const unsigned grid = (unsigned)std::min<int64_t>((n_cols + tc - 1) / tc, (int64_t)p->cus * 8);
-        switch (es) {
-          case 8: hipLaunchKernelGGL(gather_rows<uint64_t>, dim3(grid), dim3(256), lds, stream, (const uint64_t*)a.data, a.col_stride, (int)n_rows, n_cols, (uint64_t*)scratch[d], tc); break;
-          case 4: hipLaunchKernelGGL(gather_rows<uint32_t>, dim3(grid), dim3(256), lds, stream, (const uint32_t*)a.data, a.col_stride, (int)n_rows, n_cols, (uint32_t*)scratch[d], tc); break;
-          case 2: hipLaunchKernelGGL(gather_rows<uint16_t>, dim3(grid), dim3(256), lds, stream, (const uint16_t*)a.data, a.col_stride, (int)n_rows, n_cols, (uint16_t*)scratch[d], tc); break;
-          default: hipLaunchKernelGGL(gather_rows<uint8_t>, dim3(grid), dim3(256), lds, stream, (const uint8_t*)a.data, a.col_stride, (int)n_rows, n_cols, (uint8_t*)scratch[d], tc); break;
-        }
-        if (hipGetLastError() != hipSuccess) rc = fail(XHIST_ERR_HIP, "gather_rows launch failed");
-        dense[d].data = scratch[d];
-        dense[d].row_stride = n_cols;
-        dense[d].col_stride = 1;
-        dense[d].inner_rows = dense[d].outer_stride = 0;
-      }
-      if (rc == XHIST_ERR_NOMEM) {
-        rc = XHIST_ERR_UNSUPPORTED;  // no room for the copy: the views are served as they lie
-      } else if (rc == XHIST_OK) {
-        rc = execute_device(p, dense, weighted ? &dense[D] : nullptr, n_rows, n_cols, out, accumulate, stream);
-        if (rc == XHIST_OK) {
-          std::lock_guard<std::mutex> lk(p->mu);
-          p->desc = "gather_rows=1 " + p->desc;
-        }
-      }
-      for (auto s : scratch)
-        if (s) (void)hipFreeAsync(s, stream);
-      if (rc != XHIST_ERR_UNSUPPORTED) return rc;
-    }
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------

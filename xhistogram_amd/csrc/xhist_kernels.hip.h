@@ -79,6 +79,7 @@ struct Params {
   // bin slice of the SLICED variant: this launch accumulates flat bins [slice_lo, slice_lo + slice_n) only
   int64_t slice_lo;
   int32_t slice_n;
+  int32_t lane_rows;       // hist_lanes: rows per workgroup (64 / 128 / 256; 0 = 256) — fewer rows, more column streams
   int64_t row0;            // first logical row of this launch (inputs only; `out` is pre-advanced)
   int32_t n_dims;
   DimTable dim[kMaxDims];

@@ -39,9 +39,14 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   constexpr int kPitch = PACKED16 ? kLaneBlock / 2 + 1 : kLanePitch;  // LDS words per bin
 
   const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * kLaneBlock;
-  const int rows_here = (int)min<int64_t>(kLaneBlock, p.n_rows - r0);
-  const int64_t r = r0 + min(tid, rows_here - 1);  // lanes past the last row shadow it; never written out
+  // R rows per workgroup, G = 256 / R lane groups: with fewer than 256 rows in all, the idle lanes take
+  // every G-th column instead of shadowing the last row (10^6 x 64 f64: G = 4; 10^7 x 2: G = 128)
+  const int R = p.lane_rows ? p.lane_rows : kLaneBlock;  // power of two, 1 ... 256
+  const int G = kLaneBlock / R;
+  const int lane_row = tid & (R - 1), g = tid / R;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int rows_here = (int)min<int64_t>(R, p.n_rows - r0);
+  const int64_t r = r0 + min(lane_row, rows_here - 1);  // lanes past the last row shadow it; never written out
   const uint64_t* tab = stage_tables(p);
   cnt_t* hist = reinterpret_cast<cnt_t*>(xhist_smem + (size_t)p.table_words * 8);
   const uint32_t nb = (uint32_t)p.n_bins;
@@ -88,20 +93,23 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
     else atomicAdd(reinterpret_cast<uint32_t*>(slot), ok ? my_inc : 0u);
   };
 
-  int64_t c = c_lo;
-  for (; c + UNROLL <= c_hi; c += UNROLL) {
+  // columns are dealt to the groups one at a time (column base + u * G + g): with R rows being the contiguous
+  // direction, a wavefront's load covers consecutive (column, row) elements whatever R is
+  const int64_t chunk = (int64_t)G * UNROLL;
+  const int64_t tail_lo = c_lo + (c_hi - c_lo) / chunk * chunk;
+  for (int64_t c = c_lo + g; c < tail_lo; c += chunk) {  // (tail_lo - c_lo is a whole number of chunks)
     ST xv[UNROLL][D];
     wscalar wv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) xv[u][d] = __builtin_nontemporal_load(sp[d] + (c + u) * scs[d]);
-      if (kWeighted) wv[u] = __builtin_nontemporal_load(wp + (c + u) * p.w_cs);
+      for (int d = 0; d < D; ++d) xv[u][d] = __builtin_nontemporal_load(sp[d] + (c + (int64_t)u * G) * scs[d]);
+      if (kWeighted) wv[u] = __builtin_nontemporal_load(wp + (c + (int64_t)u * G) * p.w_cs);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) bin_and_add(xv[u], kWeighted ? wv[u] : (wscalar)0);
   }
-  for (; c < c_hi; ++c) {
+  for (int64_t c = tail_lo + g; c < c_hi; c += G) {
     ST x[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = sp[d][c * scs[d]];
@@ -114,9 +122,12 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   const uint32_t total = (uint32_t)rows_here * nb;
   for (uint32_t j = tid; j < total; j += kLaneBlock) {
     const uint32_t row = j / nb, b = j - row * nb;
-    cnt_t v;
-    if constexpr (PACKED16) v = (hist[b * kPitch + (row >> 1)] >> ((row & 1) << 4)) & 0xffffu;
-    else v = hist[b * kPitch + row];
+    cnt_t v = (cnt_t)0;
+    for (int gg = 0; gg < G; ++gg) {
+      const uint32_t lane = (uint32_t)gg * (uint32_t)R + row;
+      if constexpr (PACKED16) v += (hist[b * kPitch + (lane >> 1)] >> ((lane & 1) << 4)) & 0xffffu;
+      else v += hist[b * kPitch + lane];
+    }
     if (direct_store) {
       out[j] = (out_t)v;
     } else if (v != (cnt_t)0) {
@@ -236,32 +247,6 @@ __global__ void __launch_bounds__(256) transpose_2d(const T* __restrict__ in, in
   for (int k = 0; k < 16; ++k) {
     const int64_t cc = c0 + ty + 4 * k, rr = r0 + tx;
     if (rr < n_rows && cc < n_cols) out[cc * n_rows + rr] = tile[tx][ty + 4 * k];
-  }
-}
-
-// The other direction for a FEW rows: a view whose rows are the contiguous direction ([N, k] reduced over
-// its leading axis: element (r, c) at in[c * cs + r]) -> k dense rows of N.  Tiles of `tc` columns through
-// LDS: the tile is read in memory order (one run of tc * k elements when cs == k) and written as k runs of
-// tc elements.
-template <typename T>
-__global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ in, int64_t cs, int n_rows, int64_t n_cols, T* __restrict__ out, int tc) {
-  T* tile = reinterpret_cast<T*>(xhist_smem);
-  const int pitch = tc + 1;
-  const int64_t n_tiles = (n_cols + tc - 1) / tc;
-  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
-    const int64_t c0 = tl * tc;
-    const int cols_here = (int)min<int64_t>((int64_t)tc, n_cols - c0);
-    const int n_el = cols_here * n_rows;
-    for (int i = threadIdx.x; i < n_el; i += 256) {
-      const int cl = i / n_rows, r = i - cl * n_rows;
-      tile[r * pitch + cl] = in[(c0 + cl) * cs + r];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_el; i += 256) {
-      const int r = i / cols_here, cl = i - r * cols_here;
-      out[(int64_t)r * n_cols + c0 + cl] = tile[r * pitch + cl];
-    }
-    __syncthreads();
   }
 }
 
