@@ -1355,12 +1355,23 @@ def test_few_rows_along_the_contiguous_direction(dtype, k):
     for xd in (_dev(np.ascontiguousarray(x_pad[:, :k])), _dev(x_pad)[:, :k]):  # column stride k, then k + 3
         got = core.histogram(xd, bins=edges, axis=0)[0]
         desc = core._get_plan([edges], _native.CMP_F64, 0).describe()
-        assert "family=lanes" in desc or np.dtype(dtype).kind != "f" or np.dtype(dtype).itemsize < 4, desc
+        assert "family=lanes" in desc, desc
         assert_hist_equal(got.cpu().numpy(), want, weighted=False)
         gotw = core.histogram(xd, bins=edges, axis=0, weights=_dev(w))[0]
         assert_hist_equal(gotw.cpu().numpy(), wantw, weighted=True)
     got_host = core.histogram(x_pad[:, :k], bins=edges, axis=0)[0]  # numpy in: staged as it lies
     assert_hist_equal(got_host, onp.histogram(x_pad[:, :k], bins=edges, axis=0)[0], weighted=False)
+    # more rows than one workgroup holds, non-uniform edges (binary search for the integer / half kernels)
+    x2 = (rng.standard_normal((5000, 300)) * (30 if np.dtype(dtype).kind in "iu" else 1)).astype(dtype)
+    if np.dtype(dtype).kind == "u":
+        x2 = np.abs(x2)
+    e2 = np.unique(np.round(_nonuniform_edges(rng, 41) * (15 if np.dtype(dtype).kind in "iu" else 0.75), 3))
+    w2 = rng.uniform(0, 1, x2.shape)
+    got2 = core.histogram(_dev(x2), bins=e2, axis=0)[0]
+    assert "family=lanes" in core._get_plan([e2], _native.CMP_F64, 0).describe()
+    assert_hist_equal(got2.cpu().numpy(), onp.histogram(x2, bins=e2, axis=0)[0], weighted=False)
+    got2w = core.histogram(_dev(x2), bins=e2, axis=0, weights=_dev(w2))[0]
+    assert_hist_equal(got2w.cpu().numpy(), onp.histogram(x2, bins=e2, axis=0, weights=w2)[0], weighted=True)
     if k != 3:
         return
     # a per-row broadcast weight stays a broadcast

@@ -184,7 +184,12 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const bool weighted = weights != nullptr;
   if (p->cmp != XHIST_CMP_F64 || D > 3 || n_cols >= ((int64_t)1 << 31) || p->n_bins >= (1 << 16) || p->huge) return XHIST_ERR_UNSUPPORTED;
   const int sdt = samples[0].dtype, wdt = weighted ? weights->dtype : -1;
-  if ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)) return XHIST_ERR_UNSUPPORTED;
+  // integer / half-precision samples: one input, unweighted or float64 weights, and only as views whose rows
+  // are the contiguous direction (10^6 x 100 int32 over the leading axis: generic family 1.70 ms)
+  const bool small = sdt == XHIST_I32 || sdt == XHIST_I64 || sdt == XHIST_I16 || sdt == XHIST_U8 || sdt == XHIST_F16;
+  if (small ? !(D == 1 && (wdt == -1 || wdt == XHIST_F64))
+            : ((sdt != XHIST_F64 && sdt != XHIST_F32) || (wdt != -1 && wdt != XHIST_F64 && wdt != XHIST_F32)))
+    return XHIST_ERR_UNSUPPORTED;
   // shape class of every array: natural (row stride 0/1, any column stride) or needs a transpose
   // (unit column stride, dense-ish rows)
   bool all_natural = true, all_rowmajor = true, grouped_any = false;
@@ -201,11 +206,17 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   }
   const bool use_f32 = sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
   int scan = 0;
-  const TableSet& tset = pick_tables(p, use_f32, &scan);
+  const TableSet* picked = &pick_tables(p, use_f32, &scan);
+  if (small && scan > 1) {  // their kernels exist for the one-compare scan and the binary search only
+    picked = &p->ts[0][0];
+    scan = 0;
+  }
+  const TableSet& tset = *picked;
   const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
   if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   bool transpose = false;
+  if (small && !(all_natural && samples[0].row_stride == 1)) return XHIST_ERR_UNSUPPORTED;
   if (all_natural && (samples[0].row_stride == 1 || prefer)) {
     // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
   } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 400 : 80)))) {

@@ -50,7 +50,16 @@ struct LaunchRecord {
 // (SCAN 1) or binary search (SCAN 0); everything else takes the generic family.
 template <typename ST>
 static kernel_fn small_pick(int wdt, int D, int scan, int hist) {
-  if (D != 1 || (scan != 0 && scan != 1) || (hist != kHistLds && hist != kHistGlobal)) return nullptr;
+  if (D != 1 || (scan != 0 && scan != 1)) return nullptr;
+  if (hist == kHistLanes || hist == kHistLanes16) {  // row-per-lane kernels: leading-axis reductions of such arrays
+    if (wdt == -1) {
+      if (hist == kHistLanes16) return scan ? (kernel_fn)hist_lanes<ST, NoWeight, 1, 1, 8, true> : (kernel_fn)hist_lanes<ST, NoWeight, 1, 0, 8, true>;
+      return scan ? (kernel_fn)hist_lanes<ST, NoWeight, 1, 1, 8, false> : (kernel_fn)hist_lanes<ST, NoWeight, 1, 0, 8, false>;
+    }
+    if (wdt == XHIST_F64 && hist == kHistLanes) return scan ? (kernel_fn)hist_lanes<ST, double, 1, 1, 8, false> : (kernel_fn)hist_lanes<ST, double, 1, 0, 8, false>;
+    return nullptr;
+  }
+  if (hist != kHistLds && hist != kHistGlobal) return nullptr;
   if (wdt == -1) {
     constexpr int VEC = 16 / (int)sizeof(ST);
     constexpr int U0 = unroll_for(1, VEC, 0), U1 = unroll_for(1, VEC, 1);
