@@ -1378,3 +1378,31 @@ def test_few_rows_along_the_contiguous_direction(dtype, k):
     wrow = rng.uniform(0, 1, (n, 1))
     gotb = core.histogram(_dev(x_pad)[:, :k], bins=edges, axis=0, weights=_dev(wrow))[0]
     assert_hist_equal(gotb.cpu().numpy(), onp.histogram(x_pad[:, :k], bins=edges, axis=0, weights=np.broadcast_to(wrow, (n, k)))[0], weighted=True)
+
+
+@pytest.mark.parametrize("case", ["f32_x_f64", "i32_x_i32", "u8_x_f32_w_int", "i32_1d_50000_bins", "i64_x_f64_int_edges"])
+def test_odd_dtype_mixtures_with_histograms_beyond_lds(case):
+    """device-resident inputs only the generic family takes, histogram beyond its LDS: promoted to float64 on
+    the device where the comparison runs in float64 anyway (core._promote_for_big_histograms), exact otherwise"""
+    from xhistogram_amd import _native, core
+
+    rng = np.random.default_rng(len(case))
+    n = 300_000
+    e = np.linspace(-4, 4, 257)
+    w = None
+    if case == "f32_x_f64":
+        xs, es = [rng.standard_normal(n).astype(np.float32), rng.standard_normal(n)], [e, _nonuniform_edges(rng, 257)]
+    elif case == "i32_x_i32":
+        xs, es = [rng.integers(-150, 150, n).astype(np.int32), rng.integers(-150, 150, n).astype(np.int32)], [np.arange(-128, 129), np.arange(-128, 129) - 0.5]
+    elif case == "u8_x_f32_w_int":
+        xs, es = [rng.integers(0, 256, n).astype(np.uint8), rng.standard_normal(n).astype(np.float32)], [np.arange(257), e]
+        w = rng.integers(0, 5, n).astype(np.int16)
+    elif case == "i32_1d_50000_bins":
+        xs, es = [rng.integers(-30000, 30000, n).astype(np.int32)], [np.arange(-25000, 25001)]
+    else:  # an exact int64 axis next to a float axis: stays in its domains
+        xs, es = [rng.integers(-2**40, 2**40, n), rng.standard_normal(n)], [np.linspace(-2**40, 2**40, 257).astype(np.int64), e]
+    want = onp.histogram(*xs, bins=es, weights=w)[0]
+    got = core.histogram(*[_dev(x) for x in xs], bins=es, weights=None if w is None else _dev(w))[0]
+    assert_hist_equal(got.cpu().numpy(), want, weighted=w is not None)
+    got_host = core.histogram(*xs, bins=es, weights=w)[0]
+    assert_hist_equal(got_host, want, weighted=w is not None)

@@ -537,7 +537,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       break;
     }
     fn = fast ? (i64dom ? int64_domain_kernel(wdt, D, scan, hist, &vec) : fast_kernel(sdt, wdt, D, scan, hist, &vec))
-              : generic_kernel(p->cmp, weighted, lds_hist);
+              : generic_kernel(p->cmp, weighted, lds_hist, tables_in_lds);
   }
   if (two && !accumulate) {
     if (int zrc = zero_output(out, out_elems, stream)) return zrc;

@@ -661,7 +661,9 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 // GENERIC family: any dtype per input, any element strides (broadcast rows/cols), 1..8 inputs,
 // float64 or int64 compare domain, tables in LDS or read through L2.  Scalar coalesced loads.
 // ---------------------------------------------------------------------------------------------
-template <int CMP, bool WEIGHTED, bool LDS_HIST>
+// TLDS: the tables are staged in LDS (nearly always) — a template parameter so that the table reads compile to
+// ds_read instead of flat loads through a pointer that could be either (2 x 10^8 f64 samples: 0.63 -> see DESIGN)
+template <int CMP, bool WEIGHTED, bool LDS_HIST, bool TLDS>
 __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
   using WT = typename std::conditional<WEIGHTED, double, NoWeight>::type;
   using A = Acc<WT>;
@@ -673,11 +675,13 @@ __global__ void __launch_bounds__(1024) hist_generic(const Params p) {
   const int64_t row = blockIdx.x / p.segs;
   const int seg = blockIdx.x % p.segs;
 
-  const uint64_t* tab = p.tables;  // generic (flat) pointer: LDS copy or global blob
+  const uint64_t* tab;
   size_t hist_off = 0;
-  if (p.tables_in_lds) {
+  if constexpr (TLDS) {
     tab = stage_tables(p);
     hist_off = (size_t)p.table_words * 8;
+  } else {
+    tab = p.tables;  // the blob in global memory (tables beyond the LDS capacity)
   }
   lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem + hist_off);
   const uint32_t cmask = (1u << p.copies_log2) - 1u;

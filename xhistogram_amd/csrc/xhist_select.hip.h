@@ -165,16 +165,21 @@ static kernel_fn_rows1 rows1_kernel(int sdt, int scan) {
   return nullptr;
 }
 
-static kernel_fn generic_kernel(int cmp, bool weighted, bool lds) {
+template <bool TLDS>
+static kernel_fn generic_kernel_t(int cmp, bool weighted, bool lds) {
   if (cmp == XHIST_CMP_F64) {
-    if (weighted) return lds ? (kernel_fn)hist_generic<0, true, true> : (kernel_fn)hist_generic<0, true, false>;
-    return lds ? (kernel_fn)hist_generic<0, false, true> : (kernel_fn)hist_generic<0, false, false>;
+    if (weighted) return lds ? (kernel_fn)hist_generic<0, true, true, TLDS> : (kernel_fn)hist_generic<0, true, false, TLDS>;
+    return lds ? (kernel_fn)hist_generic<0, false, true, TLDS> : (kernel_fn)hist_generic<0, false, false, TLDS>;
   }
   if (cmp == XHIST_CMP_I64) {
-    if (weighted) return lds ? (kernel_fn)hist_generic<1, true, true> : (kernel_fn)hist_generic<1, true, false>;
-    return lds ? (kernel_fn)hist_generic<1, false, true> : (kernel_fn)hist_generic<1, false, false>;
+    if (weighted) return lds ? (kernel_fn)hist_generic<1, true, true, TLDS> : (kernel_fn)hist_generic<1, true, false, TLDS>;
+    return lds ? (kernel_fn)hist_generic<1, false, true, TLDS> : (kernel_fn)hist_generic<1, false, false, TLDS>;
   }
   // per-input domains (XHIST_CMP_PER_DIM | mask)
-  if (weighted) return lds ? (kernel_fn)hist_generic<3, true, true> : (kernel_fn)hist_generic<3, true, false>;
-  return lds ? (kernel_fn)hist_generic<3, false, true> : (kernel_fn)hist_generic<3, false, false>;
+  if (weighted) return lds ? (kernel_fn)hist_generic<3, true, true, TLDS> : (kernel_fn)hist_generic<3, true, false, TLDS>;
+  return lds ? (kernel_fn)hist_generic<3, false, true, TLDS> : (kernel_fn)hist_generic<3, false, false, TLDS>;
+}
+
+static kernel_fn generic_kernel(int cmp, bool weighted, bool lds, bool tables_in_lds) {
+  return tables_in_lds ? generic_kernel_t<true>(cmp, weighted, lds) : generic_kernel_t<false>(cmp, weighted, lds);
 }
