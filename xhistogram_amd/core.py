@@ -439,6 +439,14 @@ def _view_of(a, desc, backend, both_strided_limit=1 << 16):
     return a.ctypes.data, _native.dtype_tag(a.dtype), rs, cs, ir, os_, a
 
 
+def _beyond_lds(bins, weighted):
+    """the histogram is bigger than the LDS of the kernels that take any dtype / stride (uint32 or float64 counters)"""
+    n_bins = 1
+    for b in bins:
+        n_bins *= max(len(b) - 1, 1)
+    return n_bins * (8 if weighted else 4) > 144 * 1024
+
+
 def _promote_for_big_histograms(arrays, w_array, dtypes, bins):
     """Device-resident inputs whose dtype mixture only the generic kernel family takes (float32 next to float64,
     integers in a joint histogram, integer weights) AND whose histogram is beyond its LDS: that family then has
@@ -446,11 +454,8 @@ def _promote_for_big_histograms(arrays, w_array, dtypes, bins):
     the device is exact wherever the comparison runs in float64 anyway (numpy promotes the same way inside
     searchsorted, and bincount casts weights to double) and opens the packed / sliced / partitioned modes of the vector
     kernels (1.1 ms).  Small histograms stay as they are: the conversion pass would cost more than it saves."""
-    n_bins = 1
-    for b in bins:
-        n_bins *= max(len(b) - 1, 1)
     weighted = w_array is not None
-    if n_bins * (8 if weighted else 4) <= 144 * 1024:
+    if not _beyond_lds(bins, weighted):
         return arrays, w_array, dtypes
     torch = _torch()
     fast_floats = (np.dtype(np.float32), np.dtype(np.float64))
@@ -506,6 +511,11 @@ def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, bl
     counts = None
     order = _reduced_order(arrays[0], list(_range(ndim)) if do_full_array else axis)
     descs = [_collapse(a, axis, do_full_array, order) for a in arrays + w_list]
+    if backend == "torch" and _beyond_lds(bins, weights) and any(d is not None and d[1] > 1 and d[3] != 1 for d in descs):
+        # columns that are not unit-stride (strided or broadcast views, leading-axis reductions) go to kernels that
+        # keep their histogram in LDS or, beyond it, in memory-side atomics: for a big histogram the reference's
+        # copy into [rows, cols] blocks (core.py:211-229), made on the device, is far cheaper than those atomics
+        descs = [None]
     if all(d is not None for d in descs) and len({d[:2] for d in descs}) == 1:
         views = [_view_of(a, d, backend) for a, d in zip(arrays + w_list, descs)]
         if all(v is not None for v in views):
