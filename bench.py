@@ -7,18 +7,28 @@ resident batch (output memset + histogram kernel, and for N > 1 the RCCL all-red
 [100] float64 partial that replaces the reference's dask `.sum(drop_axes)`, core.py:439).
 Inputs are generated on the device before the timed region (data = synthetic N(0,1) samples,
 U[0,1) weights).  N GPUs = N processes (torch.distributed/RCCL), each with its own 10^9-sample
-shard (weak scaling); `value` is samples/s of the whole job.
+shard (weak scaling: the line's `value`); with N > 1 the same run also times the STRONG leg
+(10^9 samples in total, 10^9 / N per GPU: SURVEY.md 8e case 1) and reports it under `"strong"`
+(`--scaling strong` makes it the line's `value` instead).  `value` is samples/s of the whole job.
+
+Launch: `python bench.py --gpus N` spawns its own N ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1) when it is not already running under a launcher; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
 
 Also reported on the same JSON line:
   roofline     achieved algorithmic GB/s of the histogram kernel (16 B/sample x 10^9 samples /
                mean kernel duration, HIP events recorded by the library on the launch stream
                around exactly the kernel, every timed step) against the 8 TB/s HBM peak
   cpu_baseline the numpy restatement of the reference path (oracle/, verified against the
-               reference's golden vectors) timed on this box's host cores on a bounded sample
+               reference's golden vectors) timed on this box's host cores on a bounded sample:
+               one thread, and a thread pool over sample chunks on every host core
+               (os.cpu_count() and the CPU model are reported)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,31 +52,77 @@ def parse():
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config (default c2 = the headline the driver measures); the others print the "
                          "same JSON line for their shape so every row of DESIGN.md's table can be reproduced")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="which leg the line's `value` reports: weak = --samples per GPU (default), strong = --samples in total, "
+                         "split over the GPUs; with N > 1 the other leg is measured too and reported under its own key")
+    ap.add_argument("--full", action="store_true",
+                    help="c4 / c5 at the FULL size of BASELINE.json on ONE GPU: (3650, 720, 1440) f32 = 15.1 GB; 4*10^9 samples x 24 B = 96 GB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     return ap.parse_args()
 
 
-def cpu_baseline(xs_host, w_host, edges):
-    """oracle (numpy searchsorted + bincount, per-chunk + sum like the reference's dask-threaded
-    path) on all host cores; bounded sample of the same workload.  xs_host: list of 1-D arrays"""
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run
+    (rendezvous on 127.0.0.1, a free port); rank 0's JSON line is the only thing they write to stdout"""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: spawning %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(xs_host, w_host, edges, one_chunk=False):
+    """oracle (numpy searchsorted + bincount) on a bounded sample of the same workload, two legs as BASELINE.md
+    section 4 asks: (1) ONE thread over the sample prefix; (2) a thread pool over contiguous sample chunks, partials
+    summed — what the reference's dask-threaded path does (core.py:429-439) — on every host core.  `value` is leg 2
+    (leg 1 for C1, whose 10^6 samples are a single chunk).  xs_host: list of 1-D arrays"""
     from oracle import oracle_np as onp
 
-    threads = min(os.cpu_count() or 1, 32)
-    chunk = 2_500_000
-    onp.chunked_threaded([x[:chunk] for x in xs_host], edges, None if w_host is None else w_host[:chunk], chunk, 1)  # warm
+    n = xs_host[0].shape[0]
+    ncpu = os.cpu_count() or 1
+    nin = "%d input array%s%s" % (len(xs_host), "s" if len(xs_host) > 1 else "", "" if w_host is None else " + weights")
+    warm = min(n, 1_000_000)
+    onp.chunked_threaded([x[:warm] for x in xs_host], edges, None if w_host is None else w_host[:warm], warm, 1)
+    # leg 1: one thread, one block (block_size=None semantics), on a prefix that takes a few seconds
+    n1 = min(n, 20_000_000)
+    t0 = time.perf_counter()
+    onp.chunked_threaded([x[:n1] for x in xs_host], edges, None if w_host is None else w_host[:n1], n1, 1)
+    dt1 = time.perf_counter() - t0
+    single = {"value": n1 / dt1, "unit": "samples/s", "cores": 1,
+              "sample": "%d of the same samples (%s), one block on one thread, %.2f s" % (n1, nin, dt1)}
+    base = {"kind": "port", "os_cpu_count": ncpu, "cpu_model": cpu_model(), "single_thread": single}
+    if one_chunk or n <= n1:
+        return dict(single, **base)
+    # leg 2: every host core; chunks of <= 10^7 samples, at least four per thread
+    threads = ncpu
+    chunk = int(min(10_000_000, max(250_000, n // (4 * threads))))
     t0 = time.perf_counter()
     onp.chunked_threaded(xs_host, edges, w_host, chunk, threads)
     dt = time.perf_counter() - t0
-    n = xs_host[0].shape[0]
-    return {
+    return dict({
         "value": n / dt,
         "unit": "samples/s",
         "cores": threads,
-        "kind": "port",
-        "sample": "%d of the same samples (%d input array%s%s), %d-sample chunks on %d threads, %.2f s"
-        % (n, len(xs_host), "s" if len(xs_host) > 1 else "", "" if w_host is None else " + weights", chunk, threads, dt),
-    }
+        "sample": "%d of the same samples (%s), %d-sample chunks on a pool of %d threads (= os.cpu_count()), partial histograms summed, %.2f s"
+        % (n, nin, chunk, threads, dt),
+    }, **base)
 
 
 def build_workload(cfg, args, torch, dev, rank):
@@ -100,21 +156,22 @@ def build_workload(cfg, args, torch, dev, rank):
             workload="C3: 2-D joint histogram, two %d-sample f64 arrays per GPU, 256x256 non-uniform edges, unweighted" % n,
             dtype="f64", data="synthetic (two independent N(0,1) arrays, generated on device; edges = sorted U(-4,4), ends forced to +-4)")
     if cfg == "c4":
-        rows, cols = 456, 720 * 1440  # 3650 time steps over 8 GPUs
+        rows, cols = (3650 if args.full else 456), 720 * 1440  # 3650 time steps: all on one GPU (--full), or 456 = 1/8 per GPU
         x = torch.empty((rows, cols), dtype=f32, device=dev).normal_(generator=g)
         return dict(
             arrays=[x], weights=None, edges=[np.linspace(-4.0, 4.0, 51)], rows=rows, cols=cols, reduce="none",
-            metric="samples/s binned (f32), (time,lat,lon) histogram over lat,lon, 50 bins, 456 time steps per GPU",
-            workload="C4: (456, 720, 1440) f32 per GPU (= 3650 time steps over 8 GPUs), dim=[lat, lon], 50 uniform bins; ranks own disjoint time rows",
+            metric="samples/s binned (f32), (time,lat,lon) histogram over lat,lon, 50 bins, %d time steps per GPU" % rows,
+            workload=("C4 at full size on one GPU: (3650, 720, 1440) f32 = 15.1 GB, dim=[lat, lon], 50 uniform bins" if args.full else
+                      "C4: (456, 720, 1440) f32 per GPU (= 3650 time steps over 8 GPUs), dim=[lat, lon], 50 uniform bins; ranks own disjoint time rows"),
             dtype="f32", data="synthetic (N(0,1) f32, generated on device)")
-    n = min(args.samples, 500_000_000)  # c5: 4e9 samples over 8 GPUs
+    n = 4_000_000_000 if args.full else min(args.samples, 500_000_000)  # c5: 4e9 samples, all on one GPU (--full: 96 GB) or over 8
     x = torch.empty(n, dtype=f64, device=dev).normal_(generator=g)
     y = torch.empty(n, dtype=f64, device=dev).normal_(generator=g)
     w = torch.empty(n, dtype=f64, device=dev).uniform_(generator=g)
     return dict(
         arrays=[x, y], weights=w, edges=[np.linspace(-4.0, 4.0, 1025)] * 2, rows=1, cols=n, reduce="allreduce",
         density=True,
-        metric="samples/s binned (2 x f64 + f64 weights), 2D weighted density, 1024x1024 bins, 5*10^8 samples per GPU",
+        metric="samples/s binned (2 x f64 + f64 weights), 2D weighted density, 1024x1024 bins, %s samples per GPU" % ("4*10^9" if args.full else "5*10^8"),
         workload="C5: 2-D weighted density histogram, %d samples per GPU (4*10^9 over 8), 1024x1024 uniform bins (beyond LDS: "
                  "partitioned multi-pass); density epilogue (core.py:444-462) on the reduced result of every step" % n,
         dtype="f64", data="synthetic (two N(0,1) arrays + U[0,1) weights, generated on device)")
@@ -122,6 +179,8 @@ def build_workload(cfg, args, torch, dev, rank):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_spawn(args))
     # stdout carries exactly ONE line (the JSON result of rank 0): whatever libraries print there — RCCL
     # writes a five-line version banner to stdout when the communicator is created — goes to stderr
     sys.stdout.flush()
@@ -137,9 +196,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run (any N)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+        raise SystemExit("bench.py rank %d: --gpus %d does not match WORLD_SIZE %d" % (rank, args.gpus, world))
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if local >= visible:
+        raise SystemExit("bench.py rank %d of %d: needs GPU %d, but this host shows %d MI355X device(s) to the process "
+                         "(torch.cuda.device_count()); one rank per GPU" % (rank, world, local, visible))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or launched
@@ -151,119 +212,178 @@ def main():
     wl = build_workload(args.config, args, torch, dev, rank)
     arrays, w, edges = wl["arrays"], wl["weights"], wl["edges"]
     weighted = w is not None
-    n_rows, n_cols = wl["rows"], wl["cols"]
-    n = n_rows * n_cols  # samples per GPU and step
+    n_rows = wl["rows"]
     tag = {torch.float64: _native.F64, torch.float32: _native.F32}
     plan = core._get_plan(edges, _native.CMP_F64, local)
     # two result buffers: the RCCL all-reduce of step k runs while step k+1's kernel streams
     out_shape = (n_rows,) + plan.bins_shape
     outs = [torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=dev) for _ in range(2)]
-    pending = [None, None]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    xv = [_native.make_view(a.data_ptr(), tag[a.dtype], n_cols, 1) for a in arrays]
-    wv = _native.make_view(w.data_ptr(), tag[w.dtype], n_cols, 1) if weighted else None
     reduce_partials = use_dist and wl["reduce"] == "allreduce"
     density = bool(wl.get("density"))
-    dens = [None]
-    counter = [0]
-
-    def finish(k):
-        """what follows a step's kernel once its all-reduce is done: the density epilogue (C5)"""
-        if pending[k] is not None:
-            pending[k].wait()
-            pending[k] = None
-            if density:
-                dens[0] = core._density(outs[k], edges, len(edges))
-
-    def step():
-        k = counter[0] & 1
-        counter[0] += 1
-        finish(k)  # the reduction that last used this buffer must be done
-        out = outs[k]
-        plan.execute(xv, wv, n_rows, n_cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False, stream=stream)
-        if reduce_partials:
-            pending[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
-        elif density:
-            dens[0] = core._density(out, edges, len(edges))
+    bytes_per_sample = sum(a.element_size() for a in arrays) + (w.element_size() if weighted else 0)
 
     def fence():
-        for k in (0, 1):
-            finish(k)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    plan.set_param("profile", min(args.steps, 4096))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    out = outs[(counter[0] - 1) & 1]
-    kernel_ms = plan.profile_read()
-    plan.set_param("profile", 0)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run_leg(n_cols, steps, warmup):
+        """`warmup` untimed + `steps` timed passes over the first n_cols samples of every row of this rank's
+        resident arrays; returns what the JSON line needs.  A step = output zeroing + histogram kernel(s)
+        (+ all-reduce of the partial over RCCL, overlapped with the next step's kernel; + the density epilogue)"""
+        xv = [_native.make_view(a.data_ptr(), tag[a.dtype], wl["cols"], 1) for a in arrays]
+        wv = _native.make_view(w.data_ptr(), tag[w.dtype], wl["cols"], 1) if weighted else None
+        pending = [None, None]
+        dens = [None]
+        counter = [0]
 
-    # sanity: the result of the last step is a real histogram of this rank's shard (all ranks summed)
-    total = float(out.sum().item())
-    assert total > 0
+        def finish(k):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+                if density:
+                    dens[0] = core._density(outs[k], edges, len(edges))
+
+        def step():
+            k = counter[0] & 1
+            counter[0] += 1
+            finish(k)  # the reduction that last used this buffer must be done
+            out = outs[k]
+            plan.execute(xv, wv, n_rows, n_cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False, stream=stream)
+            if reduce_partials:
+                pending[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
+            elif density:
+                dens[0] = core._density(out, edges, len(edges))
+
+        def drain():
+            for k in (0, 1):
+                finish(k)
+            fence()
+
+        for _ in range(warmup):
+            step()
+        drain()
+        plan.set_param("profile", min(steps, 4096))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        dt = time.perf_counter() - t0
+        kernel_ms = plan.profile_read()
+        plan.set_param("profile", 0)
+        out = outs[(counter[0] - 1) & 1]
+        k_mean = float(np.mean(kernel_ms))
+        per_rank = [k_mean]
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            ks = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(ks, torch.tensor([k_mean], dtype=torch.float64, device=dev))
+            per_rank = [float(k.item()) for k in ks]
+        # sanity: the result of the last step is a real histogram (of all ranks' shards when reduced)
+        total = float(out.sum().item())
+        assert total > 0
+        # the exchange on its own: `steps` all-reduces of the partial, nothing else on the GPU
+        allreduce_ms = None
+        if reduce_partials:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(dev)
+            allreduce_ms = (time.perf_counter() - t0) / steps * 1e3
+            fence()
+        n = n_rows * n_cols
+        return dict(dt=dt, n=n, kernel_ms=kernel_ms, kernel_ms_per_rank=per_rank, allreduce_ms=allreduce_ms,
+                    value=world * n * steps / dt, ms_per_step=dt / steps * 1e3, last=out, dens=dens[0])
+
+    cols_weak = wl["cols"]
+    cols_strong = max(1, wl["cols"] // world)
+    legs = {}
+    main_leg = args.scaling
+    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup)
+    if world > 1:  # the other leg rides along (N = 1: the two legs are the same run)
+        other = "strong" if main_leg == "weak" else "weak"
+        legs[other] = run_leg(cols_weak if other == "weak" else cols_strong, args.steps, args.warmup)
+    m = legs[main_leg]
 
     if rank == 0:
-        bytes_per_sample = sum(a.element_size() for a in arrays) + (w.element_size() if weighted else 0)
-        k_ms = float(np.mean(kernel_ms))
-        achieved = bytes_per_sample * n / (k_ms * 1e-3) / 1e9
-        traffic = None
+        def roofline(leg):
+            k_ms = float(np.mean(leg["kernel_ms"]))
+            achieved = bytes_per_sample * leg["n"] / (k_ms * 1e-3) / 1e9
+            return {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_mean": k_ms,
+                "kernel_ms_min": float(np.min(leg["kernel_ms"])),
+                "kernel_launches_timed": len(leg["kernel_ms"]),
+                "algorithmic_bytes_per_launch": bytes_per_sample * leg["n"],
+            }
+
+        roof = roofline(m)
+        # HBM traffic of one launch from the PMC counters: a rocprofv3 --pmc pass cannot run inside this process, so
+        # the figure comes from profiles/traffic.json (written by tools/pmc_traffic.py from --pmc FETCH_SIZE / WRITE_SIZE
+        # passes over THIS command) and is reported only when it was taken on the kernel and size this run used —
+        # `traffic_source` says where and on which code state; otherwise null
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if args.config == "c2" and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_weighted" if weighted else "hbm_bytes_per_launch_unweighted")
-            except Exception:
-                traffic = None
+        try:
+            entry = json.load(open(tpath)).get("configs", {}).get(args.config + ("_full" if args.full else ""))
+        except Exception:
+            entry = None
+        if entry and entry.get("kernel") == plan.describe() and entry.get("samples_per_launch") == m["n"] and not args.unweighted:
+            roof["traffic"] = entry["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/traffic.json: %s (code state %s)" % (entry.get("source", "?"), entry.get("code_state", "?"))
+        else:
+            roof["traffic_source"] = None
+
+        def leg_summary(leg):
+            return {
+                "value": leg["value"], "unit": "samples/s", "ms_per_step": leg["ms_per_step"], "samples_per_gpu": leg["n"],
+                "samples_total": leg["n"] * world, "kernel_ms_per_rank": leg["kernel_ms_per_rank"],
+                "allreduce_ms_alone": leg["allreduce_ms"], "roofline_frac_rank0": roofline(leg)["frac"],
+            }
+
         line = {
             "metric": wl["metric"],
-            "value": world * n * args.steps / dt,
+            "value": m["value"],
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": main_leg,
             "vs_baseline": None,
             "dtype": wl["dtype"],
             "data": wl["data"],
             "config": {
                 "workload": wl["workload"],
-                "samples_per_gpu": n,
+                "samples_per_gpu": m["n"],
+                "samples_total": m["n"] * world,
                 "bins": [int(b) for b in plan.bins_shape],
                 "weighted": weighted,
                 "kernel": plan.describe(),
                 "parallelism": ("sample-axis shards, one per GPU" if wl["reduce"] == "allreduce" else "kept-axis (time) shards, one per GPU, disjoint output rows")
                 + ("; all-reduce(sum) of the partial histogram over RCCL each step, overlapped with the next step's kernel" if reduce_partials else ""),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms_mean": k_ms,
-                "kernel_ms_min": float(np.min(kernel_ms)),
-                "kernel_launches_timed": len(kernel_ms),
-                "algorithmic_bytes_per_launch": bytes_per_sample * n,
-            },
+            "roofline": roof,
+            "kernel_ms_per_rank": m["kernel_ms_per_rank"],
+            "allreduce_ms_alone": m["allreduce_ms"],
         }
+        for name, leg in legs.items():
+            if name != main_leg:
+                line[name] = leg_summary(leg)
         if world == 1 and not args.no_cpu_baseline:
-            m = min(args.cpu_sample // max(1, len(arrays)), n)
-            flat = [a.reshape(-1)[:m].double().cpu().numpy() if args.config != "c4" else a.reshape(-1)[:m].cpu().numpy() for a in arrays]
-            line["cpu_baseline"] = cpu_baseline(flat, w.reshape(-1)[:m].cpu().numpy() if weighted else None, edges)
+            nflat = arrays[0].numel()
+            k = min(args.cpu_sample // max(1, len(arrays)), nflat)
+            flat = [a.reshape(-1)[:k].cpu().numpy() for a in arrays]
+            line["cpu_baseline"] = cpu_baseline(flat, w.reshape(-1)[:k].cpu().numpy() if weighted else None, edges, one_chunk=args.config == "c1")
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 4
+#define XHIST_ABI_VERSION 5
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -109,7 +109,11 @@ int xhist_plan_destroy(xhist_plan* plan);
  *   accumulate != 0: add into `out` instead of overwriting it — this is the reference's
  *     "sum over blocks" (dask `.sum(drop_axes)`, core.py:439) fused into the kernel's flush.
  *   stream: hipStream_t (NULL = default stream).  XHIST_MEM_DEVICE calls are asynchronous on
- *     `stream`; XHIST_MEM_HOST calls stage through device memory and return when `out` is final.
+ *     `stream`; XHIST_MEM_HOST calls stage through device memory and return when `out` is final
+ *     (with stream NULL they run on the calling thread's own stream, so concurrent host callers —
+ *     dask's threaded scheduler — overlap one block's staging copy with another block's kernel).
+ * Named roctx ranges wrap plan creation, execute and the exchange calls when a roctx library is
+ * mapped in the process (rocprofv3 --marker-trace) or XHIST_AMD_ROCTX=1.
  */
 int xhist_plan_execute(xhist_plan* plan, const xhist_array* samples, const xhist_array* weights,
                        int64_t n_rows, int64_t n_cols, void* out, int out_dtype, int mem_kind,
@@ -161,6 +165,19 @@ int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, 
 /* recv holds world_size * count elements, rank r's block at offset r * count */
 int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
 int xhist_comm_destroy(xhist_comm* comm);
+
+/* ---- device buffers ------------------------------------------------------------------------ */
+/* Partial histograms that stay on their GPU between the kernel and the exchange, for hosts without a
+ * device allocator of their own (the Python shim with numpy inputs; a C host).  What they carry is the
+ * per-block result of `_bincount` (core.py:197-247) on its way into the sum over blocks (core.py:439).
+ *   xhist_buffer_copy direction: 0 host -> device, 1 device -> host (both final when the call returns),
+ *   2 device -> device on `device` (asynchronous on `stream`).
+ *   xhist_buffer_add: dst[i] += src[i] on `device`, int64 or float64, asynchronous on `stream` — the sum
+ *   of the partials of the blocks one GPU processed, before the all-reduce adds up the GPUs. */
+int xhist_buffer_alloc(int device, size_t bytes, void** dptr);
+int xhist_buffer_free(int device, void* dptr);
+int xhist_buffer_copy(int device, void* dst, const void* src, size_t bytes, int direction, void* stream);
+int xhist_buffer_add(int device, void* dst, const void* src, int64_t count, int dtype, void* stream);
 
 /* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
 /* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),

@@ -81,5 +81,59 @@ def compute():
     print("COMPUTE-OK")
 
 
+def spread():
+    """block -> GPU mapping of the dask branch on the CPU: the block adapter is swapped for the oracle (test
+    double) and the GPUs are virtual device numbers; what runs for real is the reference-shaped graph, the
+    least-busy-GPU assignment of every block task and dask's sum over the reduced chunk dims.  Chunkings as in
+    the reference's test_chunking.py:8-146 (aligned / unaligned between the arguments), C2- and C4-shaped."""
+    import threading
+
+    from oracle import oracle_np as onp
+    from xhistogram_amd import core, multigpu
+
+    seen, lock = [], threading.Lock()
+
+    def oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+        arrays = [np.asarray(a) for a in all_arrays]
+        w = arrays.pop() if weights else None
+        nd = arrays[0].ndim
+        ax = tuple(range(nd)) if axis is None else tuple(int(a) for a in axis)
+        with lock:
+            seen.append(core._host_device())
+        h, _ = onp.histogram(*arrays, bins=bins if len(arrays) > 1 else bins[0], weights=w, axis=ax)
+        kept = tuple(1 if i in ax else arrays[0].shape[i] for i in range(nd))
+        return np.asarray(h).reshape(kept + tuple(len(b) - 1 for b in bins))
+
+    core._bincount = oracle_bincount
+    multigpu.set_devices([0, 1, 2, 3, 4, 5, 6, 7])
+    rng = np.random.default_rng(1)
+    # C2-shaped: one long sample axis in 16 chunks, full reduction, weights chunked differently (unaligned)
+    x, w = rng.standard_normal(40_000), rng.uniform(0, 1, 40_000)
+    e = np.linspace(-4, 4, 101)
+    for sched in ("threads", "synchronous"):
+        seen.clear()
+        h, _ = histogram(dsa.from_array(x, chunks=2500), bins=e, weights=dsa.from_array(w, chunks=3000))
+        assert not seen, "graph construction must not compute"
+        np.testing.assert_allclose(h.compute(scheduler=sched), np.histogram(x, bins=e, weights=w)[0], rtol=1e-10)
+        assert sorted(set(seen)) == list(range(8)), (sched, sorted(set(seen)))  # every GPU got blocks
+    # C4-shaped: (time, lat, lon) chunked on time, histogram over lat / lon: disjoint output rows
+    t = rng.standard_normal((24, 18, 36)).astype(np.float32)
+    e4 = np.linspace(-4, 4, 51)
+    want = np.stack([np.histogram(t[i], bins=e4)[0] for i in range(24)])
+    for chunks in ((3, 18, 36), (5, 18, 36), (4, 9, 36)):  # aligned, ragged last chunk, chunked along a reduced dim too
+        seen.clear()
+        h, _ = histogram(dsa.from_array(t, chunks=chunks), bins=e4, axis=[1, 2])
+        got = h.compute(scheduler="threads")
+        np.testing.assert_array_equal(got, want)
+        assert got.dtype == np.int64 and len(set(seen)) >= min(8, len(seen)) - 1, (chunks, seen)
+    # two arguments chunked differently (dask rechunks inside blockwise), density on top
+    a, b = rng.standard_normal((30, 40)), rng.standard_normal((30, 40))
+    ea, eb = np.linspace(-4, 4, 9), np.linspace(-4, 4, 7)
+    h, _ = histogram(dsa.from_array(a, chunks=(7, 40)), dsa.from_array(b, chunks=(11, 13)), bins=[ea, eb], density=True)
+    np.testing.assert_allclose(h.compute(), np.histogram2d(a.ravel(), b.ravel(), bins=[ea, eb], density=True)[0], rtol=1e-10)
+    assert all(v == 0 for v in multigpu._inflight.values())
+    print("SPREAD-OK")
+
+
 if __name__ == "__main__":
-    {"lazy": lazy, "compute": compute}[sys.argv[1]]()
+    {"lazy": lazy, "compute": compute, "spread": spread}[sys.argv[1]]()

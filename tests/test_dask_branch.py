@@ -36,6 +36,11 @@ def test_dask_graph_is_lazy_and_shaped_like_the_reference():
 
 
 @needs
+def test_dask_blocks_are_spread_over_the_gpus_of_the_node():
+    assert "SPREAD-OK" in _run("spread")
+
+
+@needs
 @pytest.mark.gpu
 def test_dask_blocks_compute_on_gpu():
     assert "COMPUTE-OK" in _run("compute")

@@ -217,3 +217,23 @@ def test_host_side_rewrites_around_the_block_adapter(monkeypatch):
     got, _ = core.histogram(q, bins=e, axis=(0, 2, 3), weights=wq)
     assert calls == [(True, (2, 3))], calls
     np.testing.assert_allclose(got, onp.histogram(q, bins=e, axis=(0, 2, 3), weights=wq)[0], rtol=1e-12)
+
+
+def test_overlapping_rows_and_unaligned_fields_take_the_copying_route():
+    """Layouts the pitched staging copy cannot express: sliding windows (rows overlap in memory)
+    and a float64 field of a packed record whose byte stride is no multiple of 8."""
+    x = np.arange(40.0)
+    win = np.lib.stride_tricks.sliding_window_view(x, 8)  # (33, 8), strides (8, 8) bytes
+    d = core._collapse(win, [1], False, [1])
+    assert d == (33, 8, 1, 1, 0, 0)
+    assert core._view_of(win, d, "numpy") is None
+    d0 = core._collapse(win, [0], False, [0])  # histogram over the window START axis: same overlap, transposed
+    assert core._view_of(win, d0, "numpy") is None
+    ok = x.reshape(5, 8)
+    assert core._view_of(ok, core._collapse(ok, [1], False, [1]), "numpy") is not None
+    rec = np.zeros(7, dtype=np.dtype([("a", "<f8"), ("b", "<i4")]))  # itemsize 12
+    rec["a"] = np.arange(7.0)
+    col = rec["a"].reshape(7, 1)
+    ptr, tag, rs, cs, _, _, keep = core._strided_view(col, "numpy")
+    assert keep is not col and keep.flags.c_contiguous and (rs, cs) == (1, 1)
+    np.testing.assert_array_equal(keep.ravel(), np.arange(7.0))

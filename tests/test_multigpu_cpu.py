@@ -1,0 +1,219 @@
+"""In-call multi-GPU path (xhistogram_amd.multigpu) on the CPU: shard planning, block -> GPU assignment, the
+per-GPU host threads and the reduce logic run here with the rank-local compute swapped for the oracle (a test
+double for `core._bincount`; the product default is the HIP path, covered by the gpu-marked tests) and with
+"virtual" device numbers — nothing below touches a GPU."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from xhistogram_amd import core, multigpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_bincount(seen):
+    def fn(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+        arrays = [a.numpy() if hasattr(a, "numpy") else np.asarray(a) for a in all_arrays]
+        w = arrays.pop() if weights else None
+        nd = arrays[0].ndim
+        ax = tuple(range(nd)) if axis is None else tuple(int(a) for a in axis)
+        seen.append((core._host_device(), threading.current_thread().name, tuple(arrays[0].shape)))
+        h, _ = onp.histogram(*arrays, bins=bins if len(arrays) > 1 else bins[0], weights=w, axis=ax)
+        kept = tuple(1 if i in ax else arrays[0].shape[i] for i in range(nd))
+        return np.asarray(h).reshape(kept + tuple(len(b) - 1 for b in bins))
+
+    return fn
+
+
+def test_plan_shards_prefers_kept_axes_then_reduced_ones():
+    # C4: (time, lat, lon) over lat, lon -> rows of the kept time axis, no arithmetic
+    mode, ax, b = multigpu.plan_shards((3650, 720, 1440), (1, 2), 8)
+    assert (mode, ax) == ("rows", 0) and b[0] == (0, 457) and b[-1][1] == 3650 and len(b) == 8
+    assert sum(hi - lo for lo, hi in b) == 3650 and all(b[k][1] == b[k + 1][0] for k in range(7))
+    # C2 / C5: one long sample axis, fully reduced -> partial histograms, summed
+    mode, ax, b = multigpu.plan_shards((10**9,), (0,), 8)
+    assert (mode, ax) == ("sum", 0) and b[3] == (375_000_000, 500_000_000)
+    # kept axis too short for the GPUs: the reduced axis takes the shards
+    assert multigpu.plan_shards((3, 10**6), (1,), 8)[:2] == ("sum", 1)
+    # the outermost long-enough kept axis wins (contiguous shards)
+    assert multigpu.plan_shards((4, 100, 200, 50), (3,), 8)[:2] == ("rows", 1)
+    # nothing is long enough: as many shards as the longest axis has indices
+    mode, ax, b = multigpu.plan_shards((3, 5), (1,), 8)
+    assert (mode, ax, len(b)) == ("sum", 1, 5)
+
+
+CASES = {
+    # name: (shape, n_args, kwargs, weights: None | "full" | broadcastable shape)
+    "c2_full_reduce_weighted": ((100_003,), 1, dict(bins=np.linspace(-4, 4, 101)), "full"),
+    "c3_joint_2d": ((50_001,), 2, dict(bins=[np.sort(np.random.default_rng(5).uniform(-4, 4, 33)), np.linspace(-3, 3, 17)]), None),
+    "c4_time_rows": ((23, 18, 36), 1, dict(bins=np.linspace(-4, 4, 51), axis=(1, 2)), None),
+    "c4_rows_lat_weights": ((23, 18, 36), 1, dict(bins=np.linspace(-4, 4, 51), axis=(1, 2)), (1, 18, 1)),
+    "c4_rows_time_weights": ((23, 18, 36), 1, dict(bins=np.linspace(-4, 4, 11), axis=(1, 2)), (23, 1, 1)),
+    "reduced_axis_short_kept": ((2, 4001), 1, dict(bins=np.linspace(-4, 4, 21), axis=1, density=True), "full"),
+    "middle_axis_kept": ((6, 9, 7), 1, dict(bins=np.linspace(-4, 4, 9), axis=(0, 2)), None),
+    "bins_int_density": ((4001,), 1, dict(bins=13, density=True), None),
+}
+
+
+@pytest.mark.parametrize("n_dev", [2, 3, 8])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_host_inputs_sharded_over_virtual_gpus(monkeypatch, case, n_dev):
+    shape, n_args, kw, wspec = CASES[case]
+    rng = np.random.default_rng(11)
+    args = [rng.standard_normal(shape) for _ in range(n_args)]
+    if not isinstance(kw["bins"], int):
+        args[0].flat[::97] = np.nan  # (an integer `bins` needs finite data, as in numpy)
+    w = None if wspec is None else rng.uniform(0.1, 1, shape if wspec == "full" else wspec)
+    seen = []
+    monkeypatch.setattr(core, "_bincount", _oracle_bincount(seen))
+    monkeypatch.setattr(multigpu, "MIN_SHARD_BYTES", 1)
+    multigpu.set_devices(list(range(10, 10 + n_dev)))  # virtual device numbers: nothing is launched
+    try:
+        got, edges = core.histogram(*args, weights=w, **kw)
+    finally:
+        multigpu.set_devices(None)
+    want, wedges = onp.histogram(*args, weights=w, **kw)
+    for e, we in zip(edges, wedges):
+        np.testing.assert_array_equal(e, we)
+    assert got.shape == np.asarray(want).shape and got.dtype == np.asarray(want).dtype
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)
+    if w is None and not kw.get("density"):
+        np.testing.assert_array_equal(got, want)  # int64 counts: exact, whatever the shard layout
+    # every shard ran on its own GPU's thread, bound to that GPU
+    devs = sorted({d for d, _, _ in seen})
+    assert devs == list(range(10, 10 + len(devs))) and len(devs) >= min(n_dev, 2)
+    for d, tname, _ in seen:
+        assert tname.startswith("xhist-gpu%d" % d)
+
+
+def test_small_host_inputs_stay_on_one_gpu(monkeypatch):
+    seen = []
+    monkeypatch.setattr(core, "_bincount", _oracle_bincount(seen))
+    multigpu.set_devices([0, 1, 2, 3])
+    try:
+        x = np.random.default_rng(0).standard_normal(1000)
+        got, _ = core.histogram(x, bins=np.linspace(-4, 4, 11))
+    finally:
+        multigpu.set_devices(None)
+    np.testing.assert_array_equal(got, onp.histogram(x, bins=np.linspace(-4, 4, 11))[0])
+    assert len(seen) == 1 and not seen[0][1].startswith("xhist-gpu")  # the caller's own thread, default device
+
+
+def test_a_rank_of_a_launcher_keeps_to_its_gpu(monkeypatch):
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert multigpu.get_devices() == [3]
+    monkeypatch.setenv("XHIST_AMD_DEVICES", "1,2")
+    assert multigpu.get_devices() == [1, 2]
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.setenv("XHIST_AMD_DEVICES", "5")
+    assert multigpu.get_devices() == [5]
+
+
+def test_block_device_hands_out_the_least_busy_gpu():
+    multigpu.set_devices([0, 1, 2, 3])
+    try:
+        # a serial scheduler (one block at a time) still visits every GPU
+        order = []
+        for _ in range(8):
+            with multigpu.block_device() as d:
+                order.append(d)
+                assert core._host_device() == d
+        assert sorted(order[:4]) == [0, 1, 2, 3] and sorted(order[4:]) == [0, 1, 2, 3]
+        assert getattr(core._tls, "device", None) is None
+        # concurrent blocks: never two on one GPU while another GPU is idle
+        gate, lock, live, worst = threading.Barrier(4), threading.Lock(), {}, [0]
+
+        def block():
+            with multigpu.block_device() as d:
+                with lock:
+                    live[d] = live.get(d, 0) + 1
+                    worst[0] = max(worst[0], live[d])
+                gate.wait(timeout=30)
+                with lock:
+                    live[d] -= 1
+
+        ts = [threading.Thread(target=block) for _ in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert worst[0] == 1
+        assert all(v == 0 for v in multigpu._inflight.values())
+        # a thread that already owns a GPU (a shard worker) keeps it
+        with multigpu.on_device(7):
+            with multigpu.block_device() as d:
+                assert d == 7
+    finally:
+        multigpu.set_devices(None)
+
+
+def test_errors_in_one_shard_surface_after_all_threads_finished(monkeypatch):
+    def boom(*a, **k):
+        if core._host_device() == 21:
+            raise RuntimeError("GPU 21 fell over")
+        return _oracle_bincount([])(*a, **k)
+
+    monkeypatch.setattr(core, "_bincount", boom)
+    monkeypatch.setattr(multigpu, "MIN_SHARD_BYTES", 1)
+    multigpu.set_devices([20, 21, 22])
+    try:
+        with pytest.raises(RuntimeError, match="GPU 21 fell over"):
+            core.histogram(np.zeros(3000), bins=np.linspace(-1, 1, 5))
+    finally:
+        multigpu.set_devices(None)
+
+
+# ---- device-resident shards (torch): sharding + exchange logic with CPU tensors --------------------
+torch = pytest.importorskip("torch")
+
+
+def _local_oracle(arrays, has_weights, axis, edges, block_size):
+    arrs = [a.numpy() if hasattr(a, "numpy") else np.asarray(a) for a in arrays]
+    w = arrs.pop() if has_weights else None
+    return torch.from_numpy(np.ascontiguousarray(onp.block_adapter(arrs, edges, w, axis)))
+
+
+def _cpu_shards(a, n, axis):
+    parts = [torch.from_numpy(np.ascontiguousarray(multigpu._take(a, axis, *multigpu.shard_bounds(a.shape[axis], n, k)))) for k in range(n)]
+    return multigpu.Sharded(parts, axis, devices=list(range(30, 30 + n)))
+
+
+@pytest.mark.parametrize("case", ["c2_full_reduce_weighted", "c4_time_rows", "reduced_axis_short_kept", "middle_axis_kept", "bins_int_density"])
+def test_sharded_tensors_reduce_and_gather_logic(case):
+    shape, n_args, kw, wspec = CASES[case]
+    rng = np.random.default_rng(21)
+    full = [rng.standard_normal(shape) for _ in range(n_args)]
+    w = None if wspec is None else rng.uniform(0.1, 1, shape)
+    for shard_axis in range(len(shape)):
+        if shape[shard_axis] < 3:
+            continue
+        args = [_cpu_shards(a, 3, shard_axis) for a in full]
+        ws = None if w is None else _cpu_shards(w, 3, shard_axis)
+        got, edges = multigpu.histogram(*args, weights=ws, _local=_local_oracle, _reduce=lambda parts: sum(parts[1:], parts[0].clone()), **kw)
+        want, _ = onp.histogram(*full, weights=w, **kw)
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-12, equal_nan=True)
+        assert tuple(got.shape) == np.asarray(want).shape
+
+
+def test_sharded_inputs_must_match():
+    a = _cpu_shards(np.zeros((6, 4)), 2, 0)
+    b = _cpu_shards(np.zeros((6, 4)), 2, 1)
+    with pytest.raises(ValueError):
+        multigpu.histogram(a, b, bins=[np.arange(3.0)] * 2, _local=_local_oracle)
+    with pytest.raises(TypeError):
+        multigpu.histogram(np.zeros(4), bins=3)
+
+
+# ---- bench.py --gpus N spawns its own ranks -------------------------------------------------------
+def test_bench_spawns_its_ranks_and_fails_per_rank_without_gpus():
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the spawn path would run for real")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "spawning 2 ranks" in r.stderr
+    assert "rank 1 of 2: needs GPU 1" in r.stderr
+    assert r.stdout.strip() == ""  # stdout carries the JSON line of a successful run, nothing else

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -71,7 +71,7 @@ EXPORTS = (
     "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
     "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
-    "xhist_comm_destroy", "xhist_shutdown",
+    "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_shutdown",
 )
 
 
@@ -117,6 +117,10 @@ def load():
         lib.xhist_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         lib.xhist_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         lib.xhist_comm_destroy.argtypes = [C.c_void_p]
+        lib.xhist_buffer_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.xhist_buffer_free.argtypes = [C.c_int, C.c_void_p]
+        lib.xhist_buffer_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        lib.xhist_buffer_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         for name in EXPORTS:
             getattr(lib, name)  # AttributeError here = header and library disagree
         if lib.xhist_abi_version() != ABI_VERSION:
@@ -299,6 +303,45 @@ class Comm:
         if getattr(self, "_h", None):
             h, self._h = self._h, None
             check(load().xhist_comm_destroy(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Device memory owned by the library (xhist_buffer_*): a partial histogram that stays on its GPU between
+    the kernel and the exchange, for callers without a device allocator of their own (numpy inputs)."""
+
+    def __init__(self, device, nbytes):
+        h = C.c_void_p()
+        check(load().xhist_buffer_alloc(int(device), int(nbytes), C.byref(h)))
+        self.device, self.nbytes, self.ptr = int(device), int(nbytes), h.value
+
+    def upload(self, host):
+        """contiguous numpy array -> the buffer (final on return)"""
+        assert host.flags.c_contiguous and host.nbytes <= self.nbytes
+        check(load().xhist_buffer_copy(self.device, C.c_void_p(self.ptr), C.c_void_p(host.ctypes.data), host.nbytes, 0, None))
+
+    def download(self, host):
+        """the buffer -> a contiguous numpy array (final on return; waits for work queued on the NULL stream)"""
+        assert host.flags.c_contiguous and host.nbytes <= self.nbytes
+        check(load().xhist_buffer_copy(self.device, C.c_void_p(host.ctypes.data), C.c_void_p(self.ptr), host.nbytes, 1, None))
+
+    def add(self, other, count, tag, stream=0):
+        """self[i] += other[i] for `count` int64 / float64 elements, on the device"""
+        check(load().xhist_buffer_add(self.device, C.c_void_p(self.ptr), C.c_void_p(other.ptr), int(count), int(tag), C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        """wait for the NULL stream of the buffer's device (exchange calls queued there)"""
+        check(load().xhist_buffer_copy(self.device, None, None, 0, 1, None))
+
+    def close(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p and _lib is not None:
+            _lib.xhist_buffer_free(self.device, C.c_void_p(p))
 
     def __del__(self):
         try:

@@ -86,6 +86,16 @@ def default_device():
     return 0
 
 
+_tls = threading.local()
+
+
+def _host_device():
+    """GPU the calling thread stages host (numpy) inputs to: the one its multi-GPU driver bound it to
+    (multigpu.on_device: a shard worker, or one dask block), else default_device()"""
+    d = getattr(_tls, "device", None)
+    return default_device() if d is None else d
+
+
 def _np_dtype_of(a):
     """numpy dtype describing the element type of a numpy array or torch tensor."""
     if _is_torch(a):
@@ -205,8 +215,8 @@ def _strided_view(a2d, backend):
     item = a2d.dtype.itemsize
     rs, cs = (s // item for s in a2d.strides)
     ok = rs >= 0 and cs in (0, 1) and all(s % item == 0 for s in a2d.strides) and (rs == 0 or rs >= a2d.shape[1] * cs)
-    if a2d.shape[1] <= 1 and rs >= 0:
-        ok, cs = True, 1
+    if a2d.shape[1] <= 1 and rs >= 0 and a2d.strides[0] % item == 0:
+        ok, cs = True, 1  # (a byte stride that is no multiple of the item size — a field of a packed record — is copied)
     if rs == 1 and cs >= a2d.shape[0] and all(s % item == 0 for s in a2d.strides):
         ok = True  # rows are the contiguous direction (leading-axis reduction): staged as it lies
     if not ok or not a2d.dtype.isnative:
@@ -222,7 +232,7 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
     cmp_domain, edges, _ = _compare_domain(sample_dtypes, bins)
     weighted = wview is not None
     if backend == "numpy":
-        device = default_device()
+        device = _host_device()
         stream = 0
         mem = _native.MEM_HOST
     else:
@@ -434,6 +444,11 @@ def _view_of(a, desc, backend, both_strided_limit=1 << 16):
         return None
     if a.dtype.kind in "mM":
         a = a.view(np.int64)
+    # rows that overlap in memory (sliding windows: row stride below the row's extent) cannot be staged
+    # as a pitched 2-D copy; the reference's reshape copies them, and so does the copying route here
+    rows_side_by_side = ir if ir else m  # rows that follow each other at stride rs
+    if m > 1 and c > 1 and rs != 0 and cs != 0 and ((cs == 1 and rs < c) or (rs == 1 and cs < rows_side_by_side)):
+        return None
     if ir == 0 and not (cs in (0, 1) or rs in (0, 1)):
         ir, os_ = m, 0  # one group: makes the library stage the bytes as they lie, strides intact
     return a.ctypes.data, _native.dtype_tag(a.dtype), rs, cs, ir, os_, a
@@ -476,6 +491,16 @@ def _promote_for_big_histograms(arrays, w_array, dtypes, bins):
     if weighted and not w_ok:
         w_array = w_array.to(torch.float64)
     return arrays, w_array, dtypes
+
+
+def _bincount_spread(*all_arrays, **kwargs):
+    """One dask block (core.py:429-437): the block adapter on whichever of the node's GPUs has the fewest
+    blocks in flight — dask's threaded scheduler runs many blocks at once, and each one is staged over
+    its own GPU's PCIe link and binned there (multigpu.block_device)."""
+    from . import multigpu
+
+    with multigpu.block_device():
+        return _bincount(*all_arrays, **kwargs)
 
 
 def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
@@ -542,31 +567,34 @@ def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, bl
 # L3: public API                                                       (core.py:250-466)
 # ---------------------------------------------------------------------------------------------
 def _ensure_correctly_formatted_bins(bins, N_expected):
-    """core.py:37-48."""
+    """One bin specification per input array (the reference helper of the same name, core.py:37-48):
+    a single int / estimator name / edge array serves every input; a sequence must have one entry
+    per input."""
     if bins is None:
         raise ValueError("bins must be provided")
-    if isinstance(bins, (int, str, np.ndarray)):
-        bins = N_expected * [bins]
-    if len(bins) == N_expected:
-        return bins
-    raise ValueError("The number of bin definitions doesn't match the number of args")
+    shared = isinstance(bins, (int, str, np.ndarray))
+    per_input = [bins] * N_expected if shared else bins
+    if len(per_input) != N_expected:
+        raise ValueError("The number of bin definitions doesn't match the number of args")
+    return per_input
 
 
 def _ensure_correctly_formatted_range(range_, N_expected):
-    """core.py:51-70."""
+    """One (lower, upper) pair — or None — per input array (core.py:51-70): a single pair serves every
+    input; a sequence of pairs must have one per input."""
     if range_ is None:
-        return N_expected * [range_]
-    nested = all(isinstance(i, Iterable) for i in range_)
-    if (len(range_) == 2) and not nested:
-        return N_expected * [range_]
-    if N_expected == len(range_):
-        if all(len(x) == 2 for x in range_):
-            return range_
+        return [None] * N_expected
+    entries_are_sequences = [isinstance(entry, Iterable) for entry in range_]
+    if len(range_) == 2 and not all(entries_are_sequences):
+        return [range_] * N_expected  # one (lower, upper) pair for all
+    if len(range_) != N_expected:
+        raise ValueError("The number of ranges doesn't match the number of args")
+    if any(len(pair) != 2 for pair in range_):
         raise ValueError(
             "range should be provided as (lower_range, upper_range). In the "
             "case of multiple args, range should be a list of such tuples"
         )
-    raise ValueError("The number of ranges doesn't match the number of args")
+    return range_
 
 
 def _device_bin_edges(a, b, r, has_weights):
@@ -734,6 +762,60 @@ def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None,
     return ha[0], ha[1], bins_out
 
 
+def _normalise_axis(axis, ndim):
+    """None, or the list of non-negative axis numbers to histogram over (core.py:346-355)"""
+    if axis is None:
+        return None
+    requested = np.atleast_1d(axis)
+    assert requested.ndim == 1
+    out = []
+    for ax in requested:
+        ax = int(ax)
+        if ax < 0:
+            ax += ndim
+        assert ax < ndim, "axis must be less than ndim"
+        out.append(ax)
+    return out
+
+
+def _counts_one_device(all_arrays, w_raw, n_inputs, has_weights, two, drop_axes, bins, bincount_kwargs, backend):
+    """Partial / full histogram of numpy or torch inputs on ONE GPU, reduced axes kept as size-1 dims
+    (+ a leading pair axis for two weight arrays): the block adapter, or one of the rewrites around it."""
+    block_size = bincount_kwargs["block_size"]
+    counts = None
+    if not two and has_weights:
+        counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
+    if counts is None and not two:
+        counts = _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend)
+    if counts is None:
+        counts = _bincount(*all_arrays, **bincount_kwargs)
+    return counts
+
+
+def _dask_graph(all_arrays, has_weights, drop_axes, bins, bincount_kwargs):
+    """The lazy graph of the reference's dask branch (core.py:403-439): ONE block-adapter task per block of
+    the (rechunk-aligned) inputs, whose output block keeps every input axis — reduced ones as single-element
+    chunks — and appends one unchunked axis per bin dimension; then a sum over the reduced axes adds the
+    partial histograms of the blocks that share output rows.  What differs from the reference is where a
+    block runs: `_bincount_spread` puts it on the least busy of the node's GPUs."""
+    import dask.array as dsa
+
+    ndim = all_arrays[0].ndim
+    data_index = tuple(_range(ndim))
+    bin_index = tuple(_range(ndim, ndim + len(bins)))
+    operands = [item for arr in all_arrays for item in (arr, data_index)]
+    partials = dsa.blockwise(
+        _bincount_spread,
+        data_index + bin_index,
+        *operands,
+        new_axes={ax: len(b) - 1 for ax, b in zip(bin_index, bins)},
+        adjust_chunks={ax: (lambda extent: 1) for ax in drop_axes},
+        meta=np.array((), "i8" if not has_weights else all_arrays[-1].dtype),
+        **bincount_kwargs,
+    )
+    return partials.sum(drop_axes)
+
+
 def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", _second_weights=None):
     """Histogram applied along specified axis / axes, computed on an MI355X.
 
@@ -765,98 +847,63 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     int64 counts, or float64 when weighted / density.  numpy in -> numpy out, torch in -> torch
     out (same device), dask in -> lazy dask array.
     """
-    a0 = args[0]
-    ndim = a0.ndim if hasattr(a0, "ndim") else np.ndim(a0)
     n_inputs = len(args)
-
-    is_dask_array = any(_is_dask(a) for a in list(args) + [weights])
-
-    if axis is not None:
-        axis = np.atleast_1d(axis)
-        assert axis.ndim == 1
-        axis_normed = []
-        for ax in axis:
-            ax_positive = ax if ax >= 0 else ndim + ax
-            assert ax_positive < ndim, "axis must be less than ndim"
-            axis_normed.append(ax_positive)
-        axis = [int(i) for i in axis_normed]
-
-    all_arrays = list(args)
+    axis = _normalise_axis(axis, args[0].ndim if hasattr(args[0], "ndim") else np.ndim(args[0]))  # (np.ndim would compute a dask array)
     has_weights = weights is not None
-    if has_weights:
-        all_arrays.append(weights)
     two = _second_weights is not None  # histogram_two_weights: the second weight array rides along
-    if two:
-        all_arrays.append(_second_weights)
+    all_arrays = list(args) + ([weights] if has_weights else []) + ([_second_weights] if two else [])
 
-    # ---- bring every input to one backend and broadcast (core.py:366) -------------------------
-    if is_dask_array:
+    # ---- one backend for every input, then broadcast against each other (core.py:366) -----------
+    w_raw = None
+    if any(_is_dask(a) for a in all_arrays):
         import dask.array as dsa
 
-        all_arrays = [a if _is_dask(a) else dsa.asarray(np.asarray(a)) for a in all_arrays]
-        all_arrays = list(dsa.broadcast_arrays(*all_arrays))
         backend = "dask"
+        all_arrays = list(dsa.broadcast_arrays(*[a if _is_dask(a) else dsa.asarray(np.asarray(a)) for a in all_arrays]))
     elif any(_is_torch(a) for a in all_arrays):
         torch = _torch()
-        dev = next(a.device for a in all_arrays if _is_torch(a) and a.device.type == "cuda")
+        backend = "torch"
+        dev = next((a.device for a in all_arrays if _is_torch(a) and a.device.type == "cuda"), None)
+        if dev is None:
+            raise RuntimeError("torch inputs must live on an MI355X (device='cuda'); every tensor given is on the CPU")
         all_arrays = [a.to(dev) if _is_torch(a) else torch.as_tensor(np.asarray(a)).to(dev) for a in all_arrays]
         w_raw = all_arrays[n_inputs] if has_weights else None  # as given, before broadcasting
         all_arrays = list(torch.broadcast_tensors(*all_arrays))
-        backend = "torch"
     else:
+        backend = "numpy"
         all_arrays = [np.asarray(a) for a in all_arrays]
         w_raw = all_arrays[n_inputs] if has_weights else None
         all_arrays = list(np.broadcast_arrays(*all_arrays))
-        backend = "numpy"
-    input_axes = tuple(_range(all_arrays[0].ndim))
-
-    bins = _ensure_correctly_formatted_bins(bins, n_inputs)
-    range = _ensure_correctly_formatted_range(range, n_inputs)
+    drop_axes = tuple(axis) if axis is not None else tuple(_range(all_arrays[0].ndim))
 
     # ---- bin edges (core.py:377-388) ---------------------------------------------------------
-    if is_dask_array:
+    bins = _ensure_correctly_formatted_bins(bins, n_inputs)
+    range = _ensure_correctly_formatted_range(range, n_inputs)
+    if backend == "dask":
         if not all(isinstance(b, np.ndarray) for b in bins):
             raise TypeError("When using dask arrays, bins must be provided as numpy array(s) of edges")
     elif backend == "torch":
         bins = [_device_bin_edges(a, b, r, has_weights) for a, b, r in zip(all_arrays, bins, range)]
     else:
-        bins = [
-            np.histogram_bin_edges(a, bins=b, range=r, weights=all_arrays[n_inputs] if has_weights else None)
-            for a, b, r in zip(all_arrays, bins, range)
-        ]
+        w_for_edges = all_arrays[n_inputs] if has_weights else None
+        bins = [np.histogram_bin_edges(a, bins=b, range=r, weights=w_for_edges) for a, b, r in zip(all_arrays, bins, range)]
     bincount_kwargs = dict(weights=has_weights, axis=axis, bins=bins, density=density, block_size=block_size)
 
-    drop_axes = tuple(axis) if axis is not None else input_axes
-
+    # ---- counts ------------------------------------------------------------------------------
     if backend == "dask":
-        # the reference's graph (core.py:403-439): one _bincount task per block, reduced axes kept
-        # as singleton block dims, then a sum over them
-        import dask.array as dsa
-
-        dtype = "i8" if not has_weights else all_arrays[-1].dtype
-        adjust_chunks = {i: (lambda x: 1) for i in drop_axes}
-        new_axes_start = max(input_axes) + 1
-        new_axes = {new_axes_start + i: len(b) - 1 for i, b in enumerate(bins)}
-        out_index = input_axes + tuple(new_axes)
-        blockwise_args = []
-        for arg in all_arrays:
-            blockwise_args.append(arg)
-            blockwise_args.append(input_axes)
-        bin_counts = dsa.blockwise(
-            _bincount, out_index, *blockwise_args, new_axes=new_axes, adjust_chunks=adjust_chunks,
-            meta=np.array((), dtype), **bincount_kwargs,
-        )
-        bin_counts = bin_counts.sum(drop_axes)
+        bin_counts = _dask_graph(all_arrays, has_weights, drop_axes, bins, bincount_kwargs)
     else:
-        bin_counts = None
         if two:
             bincount_kwargs["second_weights"] = True
-        elif has_weights:
-            bin_counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
-        if bin_counts is None and not two:
-            bin_counts = _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend)
+        bin_counts = None
+        if backend == "numpy":
+            # host inputs big enough to be worth it are cut into shards, one per visible GPU: every shard is
+            # staged over its own GPU's PCIe link by that GPU's host thread, the partials are added up
+            from . import multigpu
+
+            bin_counts = multigpu.host_sharded_counts(all_arrays, w_raw, n_inputs, has_weights, two, drop_axes, bins, bincount_kwargs)
         if bin_counts is None:
-            bin_counts = _bincount(*all_arrays, **bincount_kwargs)
+            bin_counts = _counts_one_device(all_arrays, w_raw, n_inputs, has_weights, two, drop_axes, bins, bincount_kwargs, backend)
         squeeze_axes = tuple(int(i) + (1 if two else 0) for i in drop_axes)  # (two: a leading pair axis)
         if backend == "torch":
             keep = [s for i, s in enumerate(bin_counts.shape) if i not in squeeze_axes]

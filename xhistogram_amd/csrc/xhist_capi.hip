@@ -4,12 +4,16 @@
 // fails with XHIST_ERR_NO_DEVICE.
 #include "xhist_pick.hip.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -206,8 +210,16 @@ extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, con
   DeviceGuard g;
   if (int rc = g.set(p->device)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mem_kind == XHIST_MEM_DEVICE) return execute_device(p, samples, weights, n_rows, n_cols, out, accumulate, s);
-  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s);
+  if (mem_kind == XHIST_MEM_DEVICE) {
+    Range r("xhist_plan_execute[device]");
+    return execute_device(p, samples, weights, n_rows, n_cols, out, accumulate, s);
+  }
+  // Host calls are synchronous and self-contained.  With no stream given each calling thread gets its
+  // own (hipStreamPerThread) instead of the device's one NULL stream: concurrent callers — dask's
+  // threaded scheduler runs many blocks at once — then overlap one block's staging copy with another
+  // block's kernel instead of queueing behind each other.
+  Range r("xhist_plan_execute[host: stage + bin]");
+  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s ? s : hipStreamPerThread);
 }
 
 extern "C" int xhist_plan_execute_two_weights(xhist_plan* p, const xhist_array* samples, const xhist_array* weights_a,
@@ -231,8 +243,10 @@ extern "C" int xhist_plan_execute_two_weights(xhist_plan* p, const xhist_array* 
 // ------------------------------------------------------------------------------------------
 // one-shot form with a plan cache
 // ------------------------------------------------------------------------------------------
+// Cached plans are shared: the cache holds one reference, every call in flight holds another, so
+// evicting (or xhist_shutdown) while another thread is still executing never frees a plan in use.
 static std::mutex g_cache_mu;
-static std::map<std::string, xhist_plan*> g_cache;
+static std::map<std::string, std::shared_ptr<xhist_plan>> g_cache;
 
 static std::string cache_key(int device, int n_inputs, const void* const* edges, const int64_t* n_edges, int cmp) {
   std::string k;
@@ -251,7 +265,7 @@ extern "C" int xhist_bincount_rows(int device, int n_inputs, const xhist_array* 
   if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS || !edges || !n_edges) return fail(XHIST_ERR_INVALID, "bad n_inputs / edges");
   for (int d = 0; d < n_inputs; ++d)
     if (!edges[d] || n_edges[d] < 1) return fail(XHIST_ERR_INVALID, "edges[%d] is NULL or empty", d);
-  xhist_plan* plan = nullptr;
+  std::shared_ptr<xhist_plan> plan;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     const std::string key = cache_key(device, n_inputs, edges, n_edges, cmp_domain);
@@ -259,21 +273,77 @@ extern "C" int xhist_bincount_rows(int device, int n_inputs, const xhist_array* 
     if (it != g_cache.end()) {
       plan = it->second;
     } else {
-      if (int rc = xhist_plan_create(device, n_inputs, edges, n_edges, cmp_domain, &plan)) return rc;
-      if (g_cache.size() >= 64) {  // bounded: drop everything rather than track recency
-        for (auto& kv : g_cache) xhist_plan_destroy(kv.second);
-        g_cache.clear();
-      }
+      xhist_plan* raw = nullptr;
+      if (int rc = xhist_plan_create(device, n_inputs, edges, n_edges, cmp_domain, &raw)) return rc;
+      plan.reset(raw, [](xhist_plan* q) { (void)xhist_plan_destroy(q); });
+      if (g_cache.size() >= 64) g_cache.clear();  // bounded: drop the cache's references rather than track recency
       g_cache[key] = plan;
     }
   }
-  return xhist_plan_execute(plan, samples, weights, n_rows, n_cols, out, out_dtype, mem_kind, accumulate, stream);
+  return xhist_plan_execute(plan.get(), samples, weights, n_rows, n_cols, out, out_dtype, mem_kind, accumulate, stream);
 }
 
 extern "C" int xhist_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
-  for (auto& kv : g_cache) xhist_plan_destroy(kv.second);
   g_cache.clear();
+  return XHIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device buffers of the library: partial histograms that stay on their GPU between the kernel and the
+// exchange (xhist_comm_*), for hosts that have no device allocator of their own
+// ------------------------------------------------------------------------------------------
+extern "C" int xhist_buffer_alloc(int device, size_t bytes, void** dptr) {
+  if (!dptr) return fail(XHIST_ERR_INVALID, "dptr is NULL");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available", device);
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(XHIST_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+  }
+  *dptr = d;
+  return XHIST_OK;
+}
+
+extern "C" int xhist_buffer_free(int device, void* dptr) {
+  if (!dptr) return XHIST_OK;
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  HIPC(hipFree(dptr));
+  return XHIST_OK;
+}
+
+extern "C" int xhist_buffer_copy(int device, void* dst, const void* src, size_t bytes, int direction, void* stream) {
+  if ((!dst || !src) && bytes) return fail(XHIST_ERR_INVALID, "dst / src is NULL");
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const hipMemcpyKind kind = direction == 0 ? hipMemcpyHostToDevice : direction == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (direction < 0 || direction > 2) return fail(XHIST_ERR_INVALID, "direction must be 0 (to device), 1 (to host) or 2 (on device)");
+  if (bytes) HIPC(hipMemcpyAsync(dst, src, bytes, kind, s));
+  if (direction != 2) HIPC(hipStreamSynchronize(s));  // host memory is involved: final when the call returns
+  return XHIST_OK;
+}
+
+__global__ void __launch_bounds__(256) buffer_add_kernel(uint64_t* dst, const uint64_t* src, int64_t n, int is_f64) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (is_f64) reinterpret_cast<double*>(dst)[i] += reinterpret_cast<const double*>(src)[i];
+    else dst[i] += src[i];
+  }
+}
+
+extern "C" int xhist_buffer_add(int device, void* dst, const void* src, int64_t count, int dtype, void* stream) {
+  if (dtype != XHIST_I64 && dtype != XHIST_F64) return fail(XHIST_ERR_INVALID, "partial histograms are int64 or float64");
+  if (count < 0 || ((!dst || !src) && count)) return fail(XHIST_ERR_INVALID, "bad dst / src / count");
+  if (!count) return XHIST_OK;
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  const int grid = (int)std::min<int64_t>((count + 255) / 256, 4096);
+  hipLaunchKernelGGL(buffer_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<uint64_t*>(dst),
+                     static_cast<const uint64_t*>(src), count, dtype == XHIST_F64 ? 1 : 0);
+  HIPC(hipGetLastError());
   return XHIST_OK;
 }
 

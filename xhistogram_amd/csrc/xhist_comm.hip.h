@@ -98,6 +98,7 @@ extern "C" int xhist_comm_unique_id(void* id, size_t cap) {
 }
 
 extern "C" int xhist_comm_create(int device, int rank, int world_size, const void* id, size_t id_bytes, xhist_comm** out) {
+  Range range_("xhist_comm_create[RCCL init]");
   if (!id || !out) return fail(XHIST_ERR_INVALID, "id / out is NULL");
   if (id_bytes != XHIST_COMM_ID_BYTES) return fail(XHIST_ERR_INVALID, "id must be the XHIST_COMM_ID_BYTES bytes rank 0 got from xhist_comm_unique_id");
   if (world_size < 1 || rank < 0 || rank >= world_size) return fail(XHIST_ERR_INVALID, "rank %d of %d", rank, world_size);
@@ -136,6 +137,7 @@ extern "C" int xhist_comm_info(const xhist_comm* comm, int* rank, int* world_siz
 }
 
 extern "C" int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, int op, void* stream) {
+  Range range_("xhist_comm_allreduce[partials]");
   if (!comm || !comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
   if (count < 0 || (count > 0 && !buf)) return fail(XHIST_ERR_INVALID, "buffer is NULL / count < 0");
   ncclDataType_t dt;
@@ -157,6 +159,7 @@ extern "C" int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, 
 }
 
 extern "C" int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream) {
+  Range range_("xhist_comm_allgather[rows]");
   if (!comm || !comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
   if (count < 0 || (count > 0 && (!send || !recv))) return fail(XHIST_ERR_INVALID, "buffer is NULL / count < 0");
   ncclDataType_t dt;

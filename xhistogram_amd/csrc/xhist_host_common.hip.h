@@ -39,6 +39,44 @@ struct DeviceGuard {  // set the plan's device for this call, restore the caller
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// roctx ranges (plan build / execute / exchange show up as named ranges in rocprofv3
+// --marker-trace timelines).  The marker library is not linked: a copy the process has mapped already
+// (the profiler preloads it) is used, or one is loaded when XHIST_AMD_ROCTX=1; otherwise ranges cost
+// one predictable branch.
+// ------------------------------------------------------------------------------------------
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    const char* want = getenv("XHIST_AMD_ROCTX");
+    void* h = nullptr;
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h && want && want[0] == '1')
+      for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static const Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+struct Range {  // RAII: a named range on the calling thread
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~Range() {
+    if (on) roctx().pop();
+  }
+};
+
 static int n_devices() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -145,6 +145,7 @@ static int build_domain(xhist_plan* p, int dom_all, bool lut16, int n_inputs, co
 
 extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
                                  int cmp_domain, xhist_plan** out_plan) {
+  Range range_("xhist_plan_create[edge tables]");
   if (!out_plan) return fail(XHIST_ERR_INVALID, "plan out-pointer is NULL");
   *out_plan = nullptr;
   if (n_inputs < 1 || n_inputs > XHIST_MAX_DIMS)

@@ -212,7 +212,8 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     if has_weights:
         all_arrays.append(weights)
     if any(core._is_torch(a) for a in all_arrays):
-        dev = next(a.device for a in all_arrays if core._is_torch(a))
+        tdevs = [a.device for a in all_arrays if core._is_torch(a)]
+        dev = next((d for d in tdevs if d.type == "cuda"), tdevs[0])  # a GPU tensor decides; CPU tensors follow it
         all_arrays = [a.to(dev) if core._is_torch(a) else torch.as_tensor(np.asarray(a)).to(dev) for a in all_arrays]
         all_arrays = list(torch.broadcast_tensors(*all_arrays))
     else:
