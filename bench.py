@@ -237,6 +237,8 @@ def main():
         pending = [None, None]
         dens = [None]
         counter = [0]
+        # prepared calls (ctypes arguments built once), one per result buffer
+        launch = [plan.bind(xv, wv, n_rows, n_cols, o.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False, stream=stream) for o in outs]
 
         def finish(k):
             if pending[k] is not None:
@@ -250,7 +252,7 @@ def main():
             counter[0] += 1
             finish(k)  # the reduction that last used this buffer must be done
             out = outs[k]
-            plan.execute(xv, wv, n_rows, n_cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False, stream=stream)
+            launch[k]()
             if reduce_partials:
                 pending[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
             elif density:

@@ -1406,3 +1406,52 @@ def test_odd_dtype_mixtures_with_histograms_beyond_lds(case):
     assert_hist_equal(got.cpu().numpy(), want, weighted=w is not None)
     got_host = core.histogram(*xs, bins=es, weights=w)[0]
     assert_hist_equal(got_host, want, weighted=w is not None)
+
+
+# ---------------------------------------------------------------------------------------------
+# the short cut for plain device-resident calls must be indistinguishable from the general path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_resident_short_cut_equals_the_general_path(xh, dtype):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((6, 7, 500)).astype(dtype)
+    y = rng.standard_normal((6, 7, 500)).astype(dtype)
+    w = rng.uniform(0, 1, x.shape)
+    x[0, 0, :5] = np.nan
+    e1, e2 = np.linspace(-3, 3, 31), np.sort(rng.uniform(-3, 3, 12))
+    xt, yt, wt = _dev(x), _dev(y), _dev(w)
+    cases = [
+        ((xt,), dict(bins=e1)),
+        ((xt,), dict(bins=e1, axis=2)),
+        ((xt,), dict(bins=e1, axis=(1, 2), weights=wt)),
+        ((xt, yt), dict(bins=[e1, e2], axis=(1, 2), weights=wt, density=True)),
+        ((xt, yt), dict(bins=[e1, e2], density=True)),
+        ((xt,), dict(bins=e1.astype(np.float32), axis=-1)),
+    ]
+    for args, kw in cases:
+        assert xh._resident_fast_path(args, kw["bins"], None, xh._normalise_axis(kw.get("axis"), 3), kw.get("weights"), kw.get("density", False), "auto") is not None
+        fast, fe = xh.histogram(*args, **kw)
+        slow, se = xh.histogram(*args, block_size=1 << 40, **kw)  # an explicit block size: the general path
+        oargs = [a.cpu().numpy() for a in args]
+        okw = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in kw.items()}
+        want, _ = onp.histogram(*oargs, **okw)
+        assert fast.dtype == slow.dtype and tuple(fast.shape) == tuple(slow.shape) == np.asarray(want).shape
+        assert_hist_equal(fast.cpu().numpy(), want, weighted="weights" in kw or kw.get("density", False))
+        assert_hist_equal(slow.cpu().numpy(), want, weighted="weights" in kw or kw.get("density", False))
+        for a, b in zip(fe, se):
+            np.testing.assert_array_equal(a, b)
+    # what the short cut must leave alone
+    assert xh._resident_fast_path((xt[:, :, ::2],), e1, None, None, None, False, "auto") is None      # not contiguous
+    assert xh._resident_fast_path((xt,), 10, None, None, None, False, "auto") is None                 # integer bins
+    assert xh._resident_fast_path((xt,), e1, None, [0], None, False, "auto") is None                  # leading axis
+    assert xh._resident_fast_path((xt,), e1, None, None, wt[0], False, "auto") is None                # broadcast weights
+    assert xh._resident_fast_path((xt.to(torch.float16),), e1, None, None, None, False, "auto") is None
+    with pytest.raises(ValueError):
+        xh.histogram(xt, bins=np.array([0.0, 2.0, 1.0]))  # numpy's monotonicity check still runs
+    # in-place edits of an edge array are seen (the cache is keyed on the bytes)
+    e = np.linspace(-1, 1, 5)
+    h1, _ = xh.histogram(xt, bins=e)
+    e[:] = np.linspace(-2, 2, 5)
+    h2, _ = xh.histogram(xt, bins=e)
+    np.testing.assert_array_equal(h2.cpu().numpy(), onp.histogram(x, bins=np.linspace(-2, 2, 5))[0])
+    assert int(h2.sum()) > int(h1.sum())

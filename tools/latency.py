@@ -19,11 +19,14 @@ def main():
             core.histogram(x, bins=edges)
         def raw():
             plan.execute(xv, None, 1, n, out.data_ptr(), False, _native.MEM_DEVICE, stream=stream)
+        bound = plan.bind(xv, None, 1, n, out.data_ptr(), False, _native.MEM_DEVICE, stream=stream)
+        def general():
+            core.histogram(x, bins=edges, block_size=1 << 40)  # an explicit block size takes the general path (same result)
         def host():
             core.histogram(xh, bins=edges)
         def ref():
             np.histogram(xh, bins=edges)
-        for name, fn, reps in (("core.histogram(torch)", api, 200), ("plan.execute", raw, 200), ("core.histogram(numpy)", host, 20), ("numpy.histogram_cpu", ref, 5)):
+        for name, fn, reps in (("core.histogram(torch)", api, 200), ("core.histogram(torch, general path)", general, 200), ("plan.execute", raw, 200), ("plan.bind()()", bound, 200), ("core.histogram(numpy)", host, 20), ("numpy.histogram_cpu", ref, 5)):
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps): fn()

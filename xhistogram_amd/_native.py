@@ -245,6 +245,26 @@ class Plan:
         )
 
 
+    def bind(self, sample_views, weight_view, n_rows, n_cols, out_ptr, weighted, mem_kind, accumulate=False, stream=0):
+        """A prepared execute: the ctypes arguments are built once and the returned callable only makes the
+        native call — for loops over the same buffers (one call costs ~3 us of Python instead of ~8)."""
+        d = self.n_dims
+        if len(sample_views) != d:
+            raise ValueError("plan was built for %d inputs, got %d" % (d, len(sample_views)))
+        fn = load().xhist_plan_execute
+        arr = (XhistArray * d)(*sample_views)
+        w = C.byref(weight_view) if weight_view is not None else None
+        call_args = (self._h, arr, w, C.c_int64(int(n_rows)), C.c_int64(int(n_cols)), C.c_void_p(out_ptr), F64 if weighted else I64,
+                     int(mem_kind), 1 if accumulate else 0, C.c_void_p(stream or 0))
+        keep = (sample_views, weight_view)  # the structs the pointers refer to stay alive with the callable
+
+        def run(_keep=keep):
+            rc = fn(*call_args)
+            if rc:
+                _raise(rc)
+
+        return run
+
     def execute_two_weights(self, sample_views, wa_view, wb_view, n_rows, n_cols, out_a_ptr, out_b_ptr, mem_kind,
                             accumulate=False, stream=0):
         """two float64 histograms [n_rows, bins] of the same samples, weighted by wa / wb, in one pass

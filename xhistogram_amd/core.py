@@ -762,6 +762,105 @@ def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None,
     return ha[0], ha[1], bins_out
 
 
+# ---------------------------------------------------------------------------------------------
+# short cut for the plain device-resident call
+# ---------------------------------------------------------------------------------------------
+# `histogram(x, bins=edges)` on a contiguous GPU tensor spends 9 us in its kernel (10^6 float64 samples) and
+# used to spend 42 us in the layers above it: backend detection, broadcasting, numpy's validation of the edges,
+# dtype promotion rules, stride analysis, plan lookup.  None of that can change between two calls with the same
+# edges and the same kind of input, so the outcome is cached per signature and the call goes straight to the
+# plan.  Everything this path does not recognise falls through to the general code below it.
+_FAST = OrderedDict()  # (device, bins signature) -> (plan, validated edge arrays)
+_FAST_TAGS = None
+
+
+def _fast_signature(bins, n_inputs):
+    """hashable identity of explicit float bin edges (their bytes: in-place edits are seen), or None"""
+    if type(bins) is np.ndarray:
+        per_input = (bins,) * n_inputs
+    elif type(bins) in (list, tuple) and len(bins) == n_inputs:
+        per_input = tuple(bins)
+    else:
+        return None, None
+    sig = []
+    for b in per_input:
+        if type(b) is not np.ndarray or b.ndim != 1 or b.dtype.kind != "f" or b.dtype.itemsize > 8 or b.size < 2:
+            return None, None
+        sig.append((b.dtype.str, b.tobytes()))
+    return tuple(sig), per_input
+
+
+def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
+    """(hist, edges) for contiguous float32 / float64 GPU tensors of one shape and dtype, explicit float edges,
+    full or trailing-axes reduction, optional same-shape float weights — or None (take the general path)."""
+    global _FAST_TAGS
+    a0 = args[0]
+    if type(a0).__module__ != "torch" or range_ is not None or block_size not in ("auto", None) or not 1 <= len(args) <= 3:
+        return None
+    torch = _torch()
+    if _FAST_TAGS is None:
+        _FAST_TAGS = {torch.float64: _native.F64, torch.float32: _native.F32}
+    tag = _FAST_TAGS.get(a0.dtype)
+    if tag is None or not a0.is_cuda or not a0.is_contiguous() or a0.numel() == 0:
+        return None
+    shape, device, dtype = a0.shape, a0.device, a0.dtype
+    for a in args[1:]:
+        if type(a) is not type(a0) or a.dtype != dtype or a.shape != shape or a.device != device or not a.is_contiguous():
+            return None
+    wtag = None
+    if weights is not None:
+        if type(weights) is not type(a0) or weights.shape != shape or weights.device != device or not weights.is_contiguous():
+            return None
+        wtag = _FAST_TAGS.get(weights.dtype)
+        if wtag is None:
+            return None
+    ndim = a0.ndim
+    if axis is None:
+        kept = 0
+    else:
+        k = len(axis)
+        if k == 0 or sorted(axis) != list(_range(ndim - k, ndim)):
+            return None  # (non-trailing reductions have their own view logic)
+        kept = ndim - k
+    sig, per_input = _fast_signature(bins, len(args))
+    if sig is None:
+        return None
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, sig)
+    with _plans_lock:
+        hit = _FAST.get(key)
+        if hit is not None:
+            _FAST.move_to_end(key)
+    if hit is None:
+        # first call with these edges: numpy validates them exactly as in the general path
+        edges = [np.histogram_bin_edges(np.zeros(0, np.float64), bins=b, range=None) for b in per_input]
+        cmp_domain, conv, _ = _compare_domain([np.dtype(np.float64)] * len(args), edges)
+        if cmp_domain != _native.CMP_F64:
+            return None
+        _native.require_device(dev_index)
+        hit = (_get_plan(conv, cmp_domain, dev_index), edges)
+        with _plans_lock:
+            _FAST[key] = hit
+            while len(_FAST) > _PLAN_CACHE:
+                _FAST.popitem(last=False)
+    plan, edges = hit
+    weighted = weights is not None
+    rows = 1
+    for n in shape[:kept]:
+        rows *= int(n)
+    cols = a0.numel() // rows
+    out = torch.empty((rows,) + plan.bins_shape, dtype=torch.float64 if weighted else torch.int64, device=device)
+    if out.numel():
+        views = [_native.make_view(a.data_ptr(), tag, cols, 1) for a in args]
+        wview = _native.make_view(weights.data_ptr(), wtag, cols, 1) if weighted else None
+        plan.execute(views, wview, rows, cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False,
+                     stream=torch.cuda.current_stream(dev_index).cuda_stream)
+    h = out.reshape(tuple(shape[:kept]) + plan.bins_shape)
+    if density:
+        h = _density(h, edges, len(args))
+    return h, list(edges)
+
+
 def _normalise_axis(axis, ndim):
     """None, or the list of non-negative axis numbers to histogram over (core.py:346-355)"""
     if axis is None:
@@ -849,6 +948,10 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     """
     n_inputs = len(args)
     axis = _normalise_axis(axis, args[0].ndim if hasattr(args[0], "ndim") else np.ndim(args[0]))  # (np.ndim would compute a dask array)
+    if _second_weights is None:
+        fast = _resident_fast_path(args, bins, range, axis, weights, density, block_size)
+        if fast is not None:
+            return fast
     has_weights = weights is not None
     two = _second_weights is not None  # histogram_two_weights: the second weight array rides along
     all_arrays = list(args) + ([weights] if has_weights else []) + ([_second_weights] if two else [])

@@ -33,23 +33,6 @@ struct Staged {
   size_t cap = 0;
 };
 
-// Scratch of the host route comes from the device's stream-ordered pool (as the partitioned mode's
-// does): a call ends with a stream synchronise, at which the pool gives back everything above its
-// release threshold — zero by default, i.e. every call would pay a fresh device allocation
-// (~100 us of the 465 us a 10^6-sample numpy call takes).  Keep up to 2 GiB cached.
-static void keep_pool_warm(int device) {
-  static std::mutex mu;
-  static bool done[64] = {false};
-  std::lock_guard<std::mutex> lk(mu);
-  if (device < 0 || device >= 64 || done[device]) return;
-  done[device] = true;
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess) return;
-  uint64_t cur = 0, want = (uint64_t)2 << 30;
-  if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur >= want) return;
-  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want);
-}
-
 static void stage_free(Staged& st, hipStream_t stream) {
   if (st.dptr) (void)hipFreeAsync(st.dptr, stream);
   st.dptr = nullptr;
@@ -125,7 +108,6 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
   void* d_out = nullptr;
   Staged st[kMaxDims + 1];
   int rc = XHIST_OK;
-  keep_pool_warm(p->device);
   auto done = [&](int code) {
     for (auto& s : st) stage_free(s, stream);
     if (d_out) (void)hipFreeAsync(d_out, stream);
@@ -284,8 +266,11 @@ extern "C" int xhist_bincount_rows(int device, int n_inputs, const xhist_array* 
 }
 
 extern "C" int xhist_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_cache_mu);
-  g_cache.clear();
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.clear();
+  }
+  trim_pools();  // scratch kept in the stream-ordered pools goes back to the driver
   return XHIST_OK;
 }
 
@@ -358,12 +343,12 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
   if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available; this library has no CPU path", device);
   DeviceGuard g;
   if (int rc = g.set(device)) return rc;
+  keep_pool_warm(device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   Staged st;
   xhist_array view = *a;
   if (mem_kind == XHIST_MEM_HOST) {
     if (n_rows * n_cols > ((int64_t)1 << 31)) return fail(XHIST_ERR_UNSUPPORTED, "host min/max above 2^31 elements: reduce on the host");
-    keep_pool_warm(device);
     if (int rc = stage_chunk(*a, 0, n_rows, 0, n_cols, st, &view, s)) { stage_free(st, s); return rc; }
   }
   const int grid = 1024;

@@ -86,6 +86,48 @@ static int n_devices() {
   return n;
 }
 
+// Scratch (staging of host inputs, the partitioned mode's record streams, transposes) comes from the device's
+// stream-ordered pool, so concurrent callers never share it.  By default that pool gives everything back to
+// the driver at the next synchronisation and the following call pays for fresh allocations: 100 us of a
+// 465 us numpy call of 10^6 samples — and 1.1 to 1.6 SECONDS per call for the 56 GB of record streams of
+// C5 at 4*10^9 samples, against 40 ms of kernels (profiles/r02_c_alloc_probe.jsonl).  So the pool keeps what
+// it was given, up to half of the device's memory ($XHIST_AMD_POOL_KEEP_GB overrides; xhist_shutdown trims).
+static std::mutex g_pool_mu;
+static bool g_pool_done[64] = {false};
+
+static void keep_pool_warm(int device) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (device < 0 || device >= 64 || g_pool_done[device]) return;
+  g_pool_done[device] = true;
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess) return;
+  size_t free_b = 0, total_b = 0;
+  uint64_t want = (uint64_t)2 << 30;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) want = std::max<uint64_t>(want, (uint64_t)total_b / 2);
+  if (const char* env = getenv("XHIST_AMD_POOL_KEEP_GB")) {
+    const double gb = atof(env);
+    if (gb >= 0) want = (uint64_t)(gb * 1073741824.0);
+  }
+  uint64_t cur = 0;
+  if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur >= want) return;
+  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want);
+}
+
+static void trim_pools() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) return;
+  for (int d = 0; d < 64; ++d) {
+    if (!g_pool_done[d]) continue;
+    hipMemPool_t pool;
+    if (hipSetDevice(d) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemPoolTrimTo(pool, 0);
+    }
+  }
+  (void)hipSetDevice(prev);
+}
+
 static int dtype_size(int dt) {
   switch (dt) {
     case XHIST_F64: case XHIST_I64: case XHIST_U64: return 8;
