@@ -57,6 +57,8 @@ def parse():
                          "split over the GPUs; with N > 1 the other leg is measured too and reported under its own key")
     ap.add_argument("--full", action="store_true",
                     help="c4 / c5 at the FULL size of BASELINE.json on ONE GPU: (3650, 720, 1440) f32 = 15.1 GB; 4*10^9 samples x 24 B = 96 GB")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="xhist_plan_set_param override for A/B runs, e.g. --tune fused=-1 (not for the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     return ap.parse_args()
@@ -215,6 +217,9 @@ def main():
     n_rows = wl["rows"]
     tag = {torch.float64: _native.F64, torch.float32: _native.F32}
     plan = core._get_plan(edges, _native.CMP_F64, local)
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        plan.set_param(key, int(val))
     # two result buffers: the RCCL all-reduce of step k runs while step k+1's kernel streams
     out_shape = (n_rows,) + plan.bins_shape
     outs = [torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=dev) for _ in range(2)]

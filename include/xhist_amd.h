@@ -182,6 +182,7 @@ int xhist_buffer_add(int device, void* dst, const void* src, int64_t count, int 
 /* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
 /* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),
  *       "partition" (0 auto / 1 prefer / -1 never: multi-pass mode for histograms beyond LDS),
+ *       "fused" (0 auto / -1 never: that mode in one routing pass instead of count + prefix + scatter),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),

@@ -174,6 +174,130 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   return release(XHIST_OK);
 }
 
+// Partitioned mode in one routing pass (xhist_route.hip.h): zero the chunk counters -> part_route ->
+// part_accumulate_chunks, all on `stream`.  Returns XHIST_ERR_UNSUPPORTED (nothing launched) for what only
+// the multi-pass form takes: more than 128 partitions, tables that do not fit LDS next to the sort buffers,
+// in-bucket scans of 3 or 4 edges, integer samples.
+static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan) {
+  if (sdt == XHIST_F64) return xhist_pick_route_f64(wdt, D, scan);
+  if (sdt == XHIST_F32) return xhist_pick_route_f32(wdt, D, scan);
+  return nullptr;
+}
+
+static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
+                                     hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
+                                     int n_parts, int profile, LaunchRecord& rec, bool first, bool last) {
+  const int D = p->n_dims;
+  const bool weighted = weights != nullptr;
+  if (n_cols >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
+  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan);
+  if (!k_route) return XHIST_ERR_UNSUPPORTED;
+  const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
+  const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted);
+  const bool rec_f32 = wdt == XHIST_F32;
+  const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
+  const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
+  if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  const int64_t n_tiles = (n_cols + kRouteTile - 1) / kRouteTile;
+  const int per_cu = std::max<int>(1, std::min<int>(4, (int)((size_t)160 * 1024 / lds_route)));
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
+  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_cols + 65535) / 65536));
+  // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
+  int lg = 10;
+  while (lg < 14 && ((n_cols / G) >> lg) + 2 * n_parts > kRouteListCap / 2) ++lg;
+  const int64_t GP = (int64_t)G * n_parts;
+  // every chunk but the one in use by its (workgroup, partition) owner is full; at most 7 padding records are added
+  // per owner; a workgroup may leave two batches of chunk ids (and a few ids at batch ends) unused
+  const int64_t pool_chunks = ((n_cols + 7 * GP) >> lg) + GP + (int64_t)G * (2 * route_batch(n_parts) + 16) + 2;
+  if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
+
+  uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
+  uint16_t* d_codes = nullptr;
+  void* d_w = nullptr;
+  auto release = [&](int rc) {
+    if (d_ctr) (void)hipFreeAsync(d_ctr, stream);
+    if (d_plist) (void)hipFreeAsync(d_plist, stream);
+    if (d_cmeta) (void)hipFreeAsync(d_cmeta, stream);
+    if (d_codes) (void)hipFreeAsync(d_codes, stream);
+    if (d_w) (void)hipFreeAsync(d_w, stream);
+    return rc;
+  };
+#define HIPR(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [2 .. 2 + P) chunks filed per partition
+  HIPR(hipMallocAsync((void**)&d_ctr, (size_t)ctr_words * 8, stream));
+  HIPR(hipMallocAsync((void**)&d_plist, (size_t)n_parts * pool_chunks * 4, stream));
+  HIPR(hipMallocAsync((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
+  HIPR(hipMallocAsync((void**)&d_codes, ((size_t)pool_chunks << lg) * 2, stream));
+  if (weighted) HIPR(hipMallocAsync(&d_w, ((size_t)pool_chunks << lg) * (rec_f32 ? 4 : 8), stream));
+
+  Params kp;
+  memset(&kp, 0, sizeof kp);
+  const DimTable* dims = tset.dim;
+  for (int d = 0; d < D; ++d) {
+    kp.s_ptr[d] = samples[d].data;
+    kp.s_rs[d] = samples[d].row_stride;
+    kp.s_cs[d] = 1;
+    kp.s_dt[d] = samples[d].dtype;
+    kp.dim[d] = dims[d];
+  }
+  if (weighted) {
+    kp.w_ptr = weights->data;
+    kp.w_rs = weights->row_stride;
+    kp.w_cs = 1;
+    kp.w_dt = weights->dtype;
+  }
+  kp.n_dims = D;
+  kp.tables = tset.blob;
+  kp.table_words = table_words;
+  kp.tables_in_lds = 1;
+  kp.n_rows = 1;
+  kp.n_cols = n_cols;
+  kp.n_bins = p->n_bins;
+  kp.out = out;
+  kp.segs = G;
+  kp.part_shift = shift;
+  kp.n_parts = n_parts;
+  RouteArgs ra;
+  ra.pool = d_ctr;
+  ra.pcount = d_ctr + 2;
+  ra.plist = d_plist;
+  ra.cmeta = d_cmeta;
+  ra.codes = d_codes;
+  ra.wrec = d_w;
+  ra.list_cap = (uint32_t)pool_chunks;
+  ra.chunk_log2 = lg;
+
+  if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
+  kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
+                                                   : (kernel_fn_acc_chunks)part_accumulate_chunks<true, double>)
+                                        : (kernel_fn_acc_chunks)part_accumulate_chunks<false, double>;
+  if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+
+  if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
+    if (int rrc = rec.begin(profile)) return release(rrc);
+  if (int zrc = zero_output(d_ctr, ctr_words, stream)) return release(zrc);
+  hipLaunchKernelGGL(k_route, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);
+  HIPR(hipGetLastError());
+  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts);
+  HIPR(hipGetLastError());
+  {
+    char desc[384];
+    snprintf(desc, sizeof desc,
+             "family=fast hist=partitioned route=fused parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
+             n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, kRouteTile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
+             (int)weighted, D, use_f32 ? "f32thr" : "f64");
+    if (last)
+      if (int rrc = rec.end(desc)) return release(rrc);
+  }
+#undef HIPR
+  return release(XHIST_OK);
+}
+
 // Row-per-lane mode (xhist_lanes.hip.h).  Takes (a) views whose ROWS are the contiguous direction
 // (row stride 1: reductions over leading axes) as they are, and (b) many short contiguous rows
 // after transposing them into a [cols, rows] scratch.  Returns XHIST_ERR_UNSUPPORTED when the
@@ -409,12 +533,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     return XHIST_OK;
   }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref, fused_pref;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
-    lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref;
+    lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref; fused_pref = p->fused_pref;
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
@@ -604,6 +728,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         if (int zrc = zero_output(out, out_elems, stream)) return zrc;
       LaunchRecord rec(p, stream);
       int rc = XHIST_OK;
+      // the routing pass keeps the digitize tables in LDS next to its sort buffers; where they do not fit (or cost a
+      // workgroup per CU) and the edges are arithmetic (C5: 2 x 1025 np.linspace edges, 32 KiB of tables) it
+      // digitizes table-free
+      int r_scan = scan;
+      const TableSet* r_tset = tset;
+      bool r_f32 = use_f32;
+      const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted), lds_notab = part_route_lds(0, (int)n_parts, weighted);
+      if (p->arith && arith_pref >= 0 && scan != kScanArith && n_parts <= 128 &&
+          (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab)) {
+        r_scan = kScanArith;
+        r_tset = &p->ts[0][0];
+        r_f32 = false;
+      }
       for (int64_t r = 0; r < n_rows && rc == XHIST_OK; ++r) {
         xhist_array row_s[XHIST_MAX_DIMS], row_w;
         for (int d = 0; d < D; ++d) {
@@ -616,8 +753,15 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
           row_w.data = const_cast<void*>(advance(weights->data, weights->dtype,
                                                  row_offset(r, weights->row_stride, weights->inner_rows, weights->outer_stride)));
         }
-        rc = execute_partitioned(p, row_s, weighted ? &row_w : nullptr, n_cols, static_cast<char*>(out) + (size_t)r * p->n_bins * 8, stream,
-                                 sdt, wdt, scan, use_f32, *tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1);
+        void* row_out = static_cast<char*>(out) + (size_t)r * p->n_bins * 8;
+        // one routing pass (44 B per C5 sample) where it applies, else count + prefix + scatter (52.5 B); the
+        // choice depends on the plan and the dtypes only, so every row of a call takes the same route
+        rc = fused_pref >= 0 ? execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan,
+                                                         r_f32, *r_tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1)
+                             : XHIST_ERR_UNSUPPORTED;
+        if (rc == XHIST_ERR_UNSUPPORTED)
+          rc = execute_partitioned(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream,
+                                   sdt, wdt, scan, use_f32, *tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1);
         if (rc == XHIST_ERR_UNSUPPORTED && r > 0) rc = fail(XHIST_ERR_HIP, "internal: partitioned mode refused row %lld after accepting row 0", (long long)r);
       }
       if (rc != XHIST_ERR_UNSUPPORTED) return rc;  // UNSUPPORTED (from row 0, nothing launched) = fall through to global atomics

@@ -6,6 +6,7 @@
 
 #include "xhist_kernels.hip.h"
 #include "xhist_partition.hip.h"
+#include "xhist_route.hip.h"
 #include "xhist_lanes.hip.h"
 
 #include <type_traits>
@@ -19,6 +20,8 @@ typedef void (*kernel_fn_acc)(const uint16_t*, const void*, const uint64_t*, voi
 typedef void (*kernel_fn_count)(const Params, uint32_t*);
 typedef void (*kernel_fn_lanes)(const Params, int32_t, int64_t);
 typedef void (*kernel_fn_scatter)(const uint32_t*, const void*, int64_t, const uint64_t*, uint16_t*, void*, int, int);
+typedef void (*kernel_fn_route)(const Params, const RouteArgs);
+typedef void (*kernel_fn_acc_chunks)(const RouteArgs, void*, int64_t, int, int);
 
 // Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
 // sample and dimension the batch keeps the value, its running count and (linear scan) up to
@@ -138,9 +141,41 @@ static kernel_fn sliced_pick_ds(int D, int scan, int hist) {
 }
 
 // ------------------------------------------------------------------------------------------
+// one-pass routing of the partitioned mode (xhist_route.hip.h): binary search, <= 2 edges per bucket, or
+// arithmetic edges; up to three inputs; any of the three weight kinds
+template <typename ST, typename WT>
+static kernel_fn_route route_pick_ds(int D, int scan) {
+#define XH_ROUTE_CASE(DD)                                                        \
+  case DD:                                                                       \
+    if (scan == 0) return (kernel_fn_route)part_route<ST, WT, DD, 0>;            \
+    if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1>;            \
+    if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2>;            \
+    if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith>; \
+    return nullptr;
+  switch (D) {
+    XH_ROUTE_CASE(1)
+    XH_ROUTE_CASE(2)
+    XH_ROUTE_CASE(3)
+    default: return nullptr;
+  }
+#undef XH_ROUTE_CASE
+}
+
+template <typename ST>
+static kernel_fn_route route_pick(int wdt, int D, int scan) {
+  if (wdt == -1) return route_pick_ds<ST, NoWeight>(D, scan);
+  if (wdt == XHIST_F64) return route_pick_ds<ST, double>(D, scan);
+  if (wdt == XHIST_F32) return route_pick_ds<ST, float>(D, scan);
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
 // what the two picker translation units export (sample type fixed, everything else a run-time choice);
 // nullptr = no such kernel
 kernel_fn xhist_pick_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
+// (xhist_route_f64.hip / xhist_route_f32.hip)
+kernel_fn_route xhist_pick_route_f64(int wdt, int D, int scan);
+kernel_fn_route xhist_pick_route_f32(int wdt, int D, int scan);

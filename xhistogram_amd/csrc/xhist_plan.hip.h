@@ -349,6 +349,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->force_global = value != 0;
   } else if (!strcmp(key, "force_generic")) {
     p->force_generic = value != 0;
+  } else if (!strcmp(key, "fused")) {
+    p->fused_pref = value < 0 ? -1 : 0;
   } else if (!strcmp(key, "partition")) {
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lanes")) {

@@ -1,0 +1,488 @@
+// xhist_route.hip.h — the partitioned mode (histograms beyond LDS, BASELINE C5) in ONE routing pass.
+//
+// xhist_partition.hip.h routes samples to their bin partition in three passes — count (re-reads the
+// samples only to size the record slots, spills a 4-byte flat index), prefix, scatter — and moves
+// 52.5 B per C5 sample for 24 algorithmic.  Here the slots are not counted in advance: record space is
+// handed out on demand in CHUNKS, so one kernel reads the samples, digitizes them, sorts each
+// 8192-sample tile by partition in LDS and writes the records; a second one adds them up.
+//
+//   part_route              reads x (, y, z), w: 24 B/sample (C5); writes (code u16, weight) records:
+//                           10 B/sample, into chunks of 2^chunk_log2 records that belong to ONE
+//                           (workgroup, partition) pair — no other workgroup writes there, so record
+//                           addresses need no atomics; a lane that owns a partition takes a new chunk
+//                           id from a global counter when its chunk is full (one atomic per chunk,
+//                           issued a whole chunk ahead so nobody waits for it) and files the id in the
+//                           partition's chunk list
+//   part_accumulate_chunks  every workgroup takes an equal share of the concatenated chunk lists
+//                           (balanced for any distribution of the samples), streams the chunks
+//                           (contiguous, 16-byte aligned), ds_adds into a 2^shift-bin LDS histogram
+//                           and flushes it at partition boundaries: 10 B/sample read
+//
+// HBM traffic 24 + 10 + 10 = 44 B per C5 sample.  What bounds it: a kernel that reads 12 GB and
+// writes 5 GB runs at 4.8-5.1 TB/s on this chip and reading 5 GB back takes 0.86 ms more, whatever the
+// chunk size and whether or not the records would fit the 256 MiB Infinity Cache
+// (tools/ubench/mall.hip, profiles/r02_a_mall.jsonl: 4.1-4.6 ms for the bare traffic of a 5*10^8-sample
+// shard).  Records keep the caller's float64 weights: 32-bit or 48-bit record weights would save
+// 4-8 B/sample but put the 1e-6 contract at the mercy of cancellation between weights of both signs.
+//
+// The LDS sort, the aligned 16-byte record groups and the records carried from tile to tile are those
+// of part_scatter (xhist_partition.hip.h), which documents them.
+#pragma once
+
+#include "xhist_partition.hip.h"
+
+namespace xhist {
+
+constexpr int kRouteGrp = 8;                  // records per aligned group: 8 codes = one 16-byte store
+constexpr uint32_t kChunkFillMask = 0xfffffu;  // cmeta[id] = partition << 20 | records in the chunk
+constexpr int kRouteCtl = 12 * 1024 + 64;      // control arrays of part_route (see the kernel)
+// workgroup of the routing pass and its tile: 8 samples per lane.  Two 512-thread workgroups share a CU (their
+// phases — load, digitize, sort in LDS, store — interleave; one 1024-thread workgroup runs them back to back
+// and leaves HBM idle while it sorts and stores)
+#ifndef XHIST_ROUTE_BLOCK
+#define XHIST_ROUTE_BLOCK 512
+#endif
+constexpr int kRouteBlock = XHIST_ROUTE_BLOCK, kRouteTile = kRouteBlock * 8;
+constexpr int kRouteLoads = kRouteTile / (kRouteBlock * 4);  // 4-sample vectors per lane and tile
+constexpr int kAccBatch = 1024;                // chunks a workgroup of part_accumulate_chunks stages at a time
+
+struct RouteArgs {
+  uint32_t* pool;       // [0]: next unused chunk id
+  uint32_t* pcount;     // [P]: chunk ids filed per partition
+  uint32_t* plist;      // [P][list_cap]: the chunk ids of each partition
+  uint32_t* cmeta;      // [pool_chunks]: partition << 20 | fill, written once when a chunk is closed
+  uint16_t* codes;      // [pool_chunks << chunk_log2]: bin index inside the partition
+  void* wrec;           // [pool_chunks << chunk_log2]: weight (float64, or float32 for float32 weights)
+  uint32_t list_cap;
+  int32_t chunk_log2;
+};
+
+__host__ __device__ constexpr int part_route_slots(int P) { return kRouteTile + 2 * (kRouteGrp - 1) * P + kRouteGrp; }
+__host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted) {
+  return ((table_bytes + 15) & ~(size_t)15) + (size_t)kRouteCtl + (size_t)P * kRouteGrp * (weighted ? 12 : 4) +
+         (size_t)part_route_slots(P) * (weighted ? 12 : 4) + 64;
+}
+
+// a 4-vector read `sh` elements before where it belongs (loads near the end of the array are pulled
+// back in bounds): element v of the result is element v + sh of what was read, `fill` past the end
+template <typename V, typename S>
+__device__ __forceinline__ V pulled_back(V q, int sh, S fill) {
+  V r;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    S x = fill;
+#pragma unroll
+    for (int k = v; k < 4; ++k) x = (v + sh == k) ? q[k] : x;
+    r[v] = x;
+  }
+  return r;
+}
+
+template <typename ST, typename WT, int D, int SCAN>
+__global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) part_route(const Params p, const RouteArgs ra) {
+  constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
+  using CT = typename Dom<CMP>::T;
+  using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  using RT = typename std::conditional<__is_same(WT, float), float, double>::type;  // record weights keep the caller's precision
+  constexpr int RV = 16 / (int)sizeof(RT);
+  typedef RT rvec __attribute__((ext_vector_type(RV)));
+  constexpr int GRP = kRouteGrp, U = kRouteLoads;
+  constexpr uint32_t kGm = GRP - 1;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef ST s4 __attribute__((ext_vector_type(4), aligned(sizeof(ST))));
+  typedef wscalar w4 __attribute__((ext_vector_type(4), aligned(sizeof(wscalar))));
+
+  const int tid = threadIdx.x;
+  const int P = p.n_parts, shift = p.part_shift, lg = ra.chunk_log2;
+  const uint32_t CH = 1u << lg;
+  const int64_t n = p.n_cols;
+  const uint64_t* tab = stage_tables(p);
+  unsigned char* ctl = xhist_smem + (((size_t)p.table_words * 8 + 15) & ~(size_t)15);
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(ctl);            // [2][256] rank counters, alternating per tile
+  uint32_t* cin2 = cnt2 + 512;                                   // [2][256] carried records per partition
+  uint64_t* delta = reinterpret_cast<uint64_t*>(ctl + 4096);     // [P] record slot of LDS slot 0 of the block (current chunk)
+  uint64_t* delta2 = delta + 256;                                // [P] the same for the part of the block that went to a new chunk
+  uint32_t* first = reinterpret_cast<uint32_t*>(ctl + 8192);     // [P] LDS slot of the first NEW record
+  uint32_t* endw = first + 256;                                  // [P] end of the whole groups of the block
+  uint32_t* enda = endw + 256;                                   // [P] end of the records of the block
+  uint32_t* split = enda + 256;                                  // [P] LDS slot from which the block continues in the new chunk
+  uint32_t* total_p = split + 256;                               // LDS slots in use this tile
+  unsigned char* dyn = ctl + kRouteCtl;
+  uint32_t* carry_key = reinterpret_cast<uint32_t*>(dyn);       // [P][GRP]
+  dyn += (size_t)P * GRP * 4;
+  RT* carry_w = reinterpret_cast<RT*>(dyn);                      // [P][GRP]
+  if (kWeighted) dyn += (size_t)P * GRP * 8;
+  const int S = part_route_slots(P);
+  RT* sw = reinterpret_cast<RT*>(dyn);                           // [S] weights of the sorted tile
+  if (kWeighted) dyn += (size_t)S * 8;
+  uint32_t* skey = reinterpret_cast<uint32_t*>(dyn);             // [S] keys: part << 16 | code
+  RT* __restrict__ wrec = static_cast<RT*>(ra.wrec);
+  uint16_t* __restrict__ codes = ra.codes;
+  const wscalar* wp = reinterpret_cast<const wscalar*>(p.w_ptr);
+  const ST* sp[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) sp[d] = reinterpret_cast<const ST*>(p.s_ptr[d]);
+  int max_steps = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
+  const uint32_t code_mask = (1u << shift) - 1u;
+  for (int i = tid; i < 256; i += blockDim.x) {
+    cnt2[i] = 0u;
+    cnt2[256 + i] = 0u;
+    cin2[i] = 0u;
+    cin2[256 + i] = 0u;
+  }
+  // The lane that owns partition `tid` holds its record cursor: [cur, cend) is what is left of the
+  // current chunk; `spare` is the chunk it will continue in, taken from the pool one chunk ahead of need
+  // (the atomics that fetch it are not waited for until the next switch) and filed in the partition's
+  // list (slot spare_pos) when it becomes current.
+  uint64_t cur = 0, cend = 0;
+  uint32_t spare = 0, spare_pos = 0;
+  bool have_spare = false;
+  if (tid < P) {
+    const uint32_t id = atomicAdd(ra.pool, 2u);
+    const uint32_t pos = atomicAdd(ra.pcount + tid, 2u);
+    ra.plist[(size_t)tid * ra.list_cap + pos] = id;
+    cur = (uint64_t)id << lg;
+    cend = cur + CH;
+    spare = id + 1;
+    spare_pos = pos + 1;
+    have_spare = true;
+  }
+  __syncthreads();
+
+  const int64_t n_tiles = (n + kRouteTile - 1) / kRouteTile;
+  const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // the grid never exceeds the number of tiles
+  auto tile_base = [&](int64_t k) { return ((int64_t)blockIdx.x + k * gridDim.x) * kRouteTile; };
+  // Loads are free of control flow (see part_scatter): a quad that would cross the end of the arrays is
+  // read 4 elements back from the end and moved into place when it is used.  Requires n >= 4.
+  auto load_samples = [&](int64_t base, s4 (&x)[D][U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = min(base + ((int64_t)u * kRouteBlock + tid) * 4, n - 4);
+#pragma unroll
+      for (int d = 0; d < D; ++d) x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(sp[d] + i));
+    }
+  };
+  s4 xv[D][U];
+  w4 w[U];
+  load_samples(tile_base(0), xv);
+  uint32_t my_carry = 0;  // lane q < P: records of partition q carried into the next tile
+  int cur_set = 0;
+  for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
+    const int64_t base = tile_base(k);
+    const bool ragged = base + kRouteTile > n;
+    uint32_t* cnt = cnt2 + (cur_set << 8);
+    const uint32_t* cin = cin2 + (cur_set << 8);
+    if (ragged) {  // positions past the end become NaN samples, which digitize drops
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + ((int64_t)u * kRouteBlock + tid) * 4;
+        const int sh = (int)min(i - min(i, n - 4), (int64_t)4);
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[d][u] = pulled_back(xv[d][u], sh, (ST)__builtin_nanf(""));
+      }
+    }
+    // ---- digitize the tile: flat bin index per sample (0xFFFFFFFF = dropped) ----------------------
+    // (one quad per input at a time: digitizing all 8 samples of a lane as one batch, as the streaming kernels
+    // do to keep table reads in flight, costs more registers than a 1024-thread workgroup has next to the
+    // sort's own state — the batch version spilled 80 VGPRs for two float64 inputs)
+    uint32_t flat[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s4 xs[D][1];
+#pragma unroll
+      for (int d = 0; d < D; ++d) xs[d][0] = xv[d][u];
+      uint32_t cntle[D][1][4];
+      if constexpr (SCAN == kScanArith) {
+        // table-free digitize has no loads to overlap, only ~6 float64 temporaries per sample: one sample at a time
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            cntle[d][0][v] = count_le_arith((double)xs[d][0][v], p.dim[d]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      } else {
+        count_le_tile<CMP, SCAN, D, 1, 4>(xs, p, tab, max_steps, cntle);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        bool ok = true;
+        uint32_t fl = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int b = bin_from_count<CMP>((CT)xs[d][0][v], p.dim[d], cntle[d][0][v]);
+          ok &= (b >= 0);
+          fl = (d == 0) ? (uint32_t)b : fl * (uint32_t)p.dim[d].nb + (uint32_t)b;
+        }
+        flat[u][v] = ok ? fl : 0xffffffffu;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t rank[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) rank[u][v] = (flat[u][v] != 0xffffffffu) ? atomicAdd(cnt + (flat[u][v] >> shift), 1u) : 0u;
+    // Loads issued here land while the block layout is worked out: this tile's weights (needed when the tile
+    // is written into LDS — they are not prefetched a tile ahead: 16 more registers than a 1024-thread
+    // workgroup can spare) and the NEXT tile's samples (the tile after the last one is the last one again: one
+    // redundant load per workgroup instead of a branch around loads).  Both are waited for when the weights
+    // are used, i.e. before this tile's record stores go out.
+    if (kWeighted) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wp + min(base + ((int64_t)u * kRouteBlock + tid) * 4, n - 4)));
+    }
+    load_samples(tile_base(k + 1 < my_tiles ? k + 1 : k), xv);
+    __syncthreads();
+    // ---- block layout (as in part_scatter) + record space of every partition's block -----------------
+    if (tid < ((P + 63) & ~63)) {
+      const int lane = tid & 63;
+      const uint32_t c_in = my_carry;
+      const uint32_t T = c_in + (tid < P ? cnt[tid] : 0u);
+      const uint32_t block = (T + kGm) & ~kGm;
+      uint32_t x = block;  // inclusive scan over the wavefront
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        x += lane >= off ? y : 0u;
+      }
+      uint32_t before = 0;  // blocks of the partitions handled by earlier wavefronts
+      for (int q = lane; q < (tid & ~63); q += 64) before += (cin[q] + cnt[q] + kGm) & ~kGm;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+      const uint32_t B = before + x - block;
+      if (tid < P) {
+        const uint32_t whole = T & ~kGm;
+        first[tid] = B + c_in;
+        endw[tid] = B + whole;
+        enda[tid] = B + T;
+        delta[tid] = cur - B;
+        const uint64_t room = cend - cur;
+        if (whole <= room) {
+          split[tid] = 0xffffffffu;
+          cur += whole;
+        } else {  // the current chunk fills up inside this block: the rest goes to the spare chunk
+          const uint32_t n1 = (uint32_t)room, rest = whole - n1;
+          const uint32_t need = (rest + CH - 1) >> lg;  // > 1 only when one tile sends more than a chunk to one partition
+          ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
+          uint32_t id0;
+          if (need == 1) {
+            id0 = spare;
+            ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
+            spare = atomicAdd(ra.pool, 1u);
+            spare_pos = atomicAdd(ra.pcount + tid, 1u);
+          } else {  // consecutive chunk ids: the rest of the block stays one contiguous run
+            id0 = atomicAdd(ra.pool, need);
+            const uint32_t pos0 = atomicAdd(ra.pcount + tid, need);
+            for (uint32_t i = 0; i < need; ++i) ra.plist[(size_t)tid * ra.list_cap + pos0 + i] = id0 + i;
+            for (uint32_t i = 0; i + 1 < need; ++i) ra.cmeta[id0 + i] = ((uint32_t)tid << 20) | CH;
+          }
+          const uint64_t nb = (uint64_t)id0 << lg;
+          split[tid] = B + n1;
+          delta2[tid] = nb - (B + n1);
+          cur = nb + rest;
+          cend = nb + ((uint64_t)need << lg);
+        }
+        my_carry = T - whole;
+        cin2[((cur_set ^ 1) << 8) + tid] = my_carry;
+        if (tid == P - 1) *total_p = B + block;
+      }
+    }
+    if (tid < 256) cnt2[((cur_set ^ 1) << 8) + tid] = 0u;
+    __syncthreads();
+    // ---- the tile, sorted by partition, into LDS -----------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      w4 wu = w[u];
+      if (kWeighted && ragged) {
+        const int64_t i = base + ((int64_t)u * kRouteBlock + tid) * 4;
+        wu = pulled_back(w[u], (int)min(i - min(i, n - 4), (int64_t)4), (wscalar)0);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (flat[u][v] != 0xffffffffu) {
+          const uint32_t part = flat[u][v] >> shift;
+          const uint32_t slot = first[part] + rank[u][v];
+          skey[slot] = (part << 16) | (flat[u][v] & code_mask);
+          if (kWeighted) sw[slot] = (RT)wu[v];
+        }
+    }
+    for (int t = tid; t < P * GRP; t += blockDim.x) {  // the carried records go to the head of their block
+      const int q = t / GRP, i = t % GRP;
+      const uint32_t c = cin[q];
+      if ((uint32_t)i < c) {
+        const uint32_t slot = first[q] - c + (uint32_t)i;
+        skey[slot] = carry_key[t];
+        if (kWeighted) sw[slot] = carry_w[t];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int d = 0; d < D; ++d) asm volatile("" : "+v"(xv[d][u]));  // the wait for the prefetch sits here, ahead of the stores
+    __syncthreads();
+    const uint32_t total = *total_p;
+    // ---- records out: one lane per group of 8 codes / per 16 bytes of weights -------------------------
+    for (uint32_t g0 = (uint32_t)tid * GRP; g0 < total; g0 += kRouteBlock * GRP) {
+      uint32_t kk[GRP];
+#pragma unroll
+      for (int i = 0; i < GRP; i += 4) {
+        const u4 q4 = *reinterpret_cast<const u4*>(skey + g0 + i);
+        kk[i] = q4[0]; kk[i + 1] = q4[1]; kk[i + 2] = q4[2]; kk[i + 3] = q4[3];
+      }
+      const uint32_t q = kk[0] >> 16;
+      if (g0 + GRP <= endw[q]) {
+        const uint64_t dst = (g0 < split[q] ? delta[q] : delta2[q]) + g0;
+        u4 c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c4[i] = (kk[2 * i] & 0xffffu) | (kk[2 * i + 1] << 16);
+        __builtin_nontemporal_store(c4, reinterpret_cast<u4*>(codes + dst));
+      } else {
+        const uint32_t left = enda[q] - g0;  // 1 .. GRP-1 records: the carry
+#pragma unroll
+        for (int i = 0; i < GRP; ++i)
+          if ((uint32_t)i < left) {
+            carry_key[q * GRP + i] = kk[i];
+            if (kWeighted) carry_w[q * GRP + i] = sw[g0 + i];
+          }
+      }
+    }
+    if (kWeighted) {
+      static_assert(GRP % RV == 0, "16-byte weight stores never straddle a group");
+      for (uint32_t t0 = (uint32_t)tid * RV; t0 < total; t0 += kRouteBlock * RV) {
+        const uint32_t g0 = t0 & ~kGm;
+        const uint32_t q = skey[g0] >> 16;
+        if (g0 + GRP <= endw[q]) {
+          const rvec wq = *reinterpret_cast<const rvec*>(sw + t0);
+          __builtin_nontemporal_store(wq, reinterpret_cast<rvec*>(wrec + (g0 < split[q] ? delta[q] : delta2[q]) + t0));
+        }
+      }
+    }
+    // no barrier here: the next tile's ranking touches only the other counter set, and nobody passes
+    // that tile's first barrier before every lane has finished this write-out
+  }
+  __syncthreads();
+  // the last group of each partition (carried records padded with neutral ones), then the books are
+  // closed: fill of the chunk in use, and the spare chunk filed as empty
+  if (tid < P) {
+    if (my_carry != 0u) {
+      if (cur == cend) {
+        ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
+        ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
+        cur = (uint64_t)spare << lg;
+        cend = cur + CH;
+        have_spare = false;
+      }
+      for (int i = 0; i < GRP; ++i) {
+        const bool real = (uint32_t)i < my_carry;
+        codes[cur + i] = real ? (uint16_t)(carry_key[tid * GRP + i] & 0xffffu) : (uint16_t)(kWeighted ? 0u : (1u << shift));
+        if (kWeighted) wrec[cur + i] = real ? carry_w[tid * GRP + i] : (RT)0;
+      }
+      cur += GRP;
+    }
+    ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | (uint32_t)(cur - (cend - CH));
+    if (have_spare) {
+      ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
+      ra.cmeta[spare] = (uint32_t)tid << 20;  // filed, empty
+    }
+  }
+}
+
+// The adding-up pass over chunk lists.  Chunk k of the concatenation of all partitions' lists belongs to the
+// partition whose offset range holds k; every workgroup takes an equal range of k.  Chunks hold whole
+// groups of 8 records and start 2^chunk_log2-aligned, so every load is an aligned quad.
+template <bool WEIGHTED, typename RT = double>
+__global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs ra, void* out_v, int64_t n_bins, int shift, int P) {
+  using lds_t = typename std::conditional<WEIGHTED, double, uint32_t>::type;
+  using out_t = typename std::conditional<WEIGHTED, double, unsigned long long>::type;
+  lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem);
+  out_t* out = reinterpret_cast<out_t*>(out_v);
+  const RT* wrec = static_cast<const RT*>(ra.wrec);
+  const uint16_t* codes = ra.codes;
+  const uint32_t bpp = 1u << shift;
+  const int tid = threadIdx.x, lg = ra.chunk_log2;
+  unsigned char* after = xhist_smem + (((size_t)(bpp + 1) * sizeof(lds_t) + 15) & ~(size_t)15);
+  uint64_t* tbl = reinterpret_cast<uint64_t*>(after);          // [kAccBatch] chunk id | fill << 32
+  uint32_t* offs = reinterpret_cast<uint32_t*>(tbl + kAccBatch);  // [P + 1] first chunk index of each partition
+  for (uint32_t c = tid; c <= bpp; c += blockDim.x) hist[c] = (lds_t)0;  // [bpp] = trash slot of padding records
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int q = 0; q < P; ++q) {
+      offs[q] = run;
+      run += ra.pcount[q];
+    }
+    offs[P] = run;
+  }
+  __syncthreads();
+  const uint32_t total = offs[P];
+  uint32_t lo = total / gridDim.x * blockIdx.x + min((uint32_t)blockIdx.x, total % gridDim.x);
+  const uint32_t hi = lo + total / gridDim.x + (blockIdx.x < total % gridDim.x ? 1u : 0u);
+  int part = 0;
+  typedef uint16_t c4 __attribute__((ext_vector_type(4)));
+  typedef RT w4 __attribute__((ext_vector_type(4)));
+  constexpr int kGroups = 2;
+  const int qlg = lg - 2;  // quads per chunk, log2
+  while (lo < hi) {
+    while (part + 1 < P && offs[part + 1] <= lo) ++part;
+    const uint32_t pend = min(hi, offs[part + 1]);
+    for (uint32_t b0 = lo; b0 < pend; b0 += kAccBatch) {
+      const uint32_t nb = min((uint32_t)kAccBatch, pend - b0);
+      for (uint32_t j = tid; j < nb; j += blockDim.x) {
+        const uint32_t id = ra.plist[(size_t)part * ra.list_cap + (b0 + j - offs[part])];
+        tbl[j] = (uint64_t)id | ((uint64_t)(ra.cmeta[id] & kChunkFillMask) << 32);
+      }
+      __syncthreads();
+      const uint32_t totalq = nb << qlg;
+      for (uint32_t Q = tid; Q < totalq; Q += 1024 * kGroups) {
+        c4 cv[kGroups];
+        w4 wq[kGroups];
+        bool live[kGroups];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+          const uint32_t Qg = Q + (uint32_t)g * 1024u;
+          live[g] = false;
+          if (Qg < totalq) {
+            const uint64_t e = tbl[Qg >> qlg];
+            const uint32_t within = (Qg & ((1u << qlg) - 1u)) << 2;
+            if (within < (uint32_t)(e >> 32)) {
+              const uint64_t at = ((uint64_t)(uint32_t)e << lg) + within;
+              cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
+              if (WEIGHTED) wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
+              live[g] = true;
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g)
+          if (live[g]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
+              else atomicAdd(reinterpret_cast<uint32_t*>(hist) + cv[g][k], 1u);
+            }
+          }
+      }
+      __syncthreads();
+    }
+    for (uint32_t c = tid; c < bpp; c += blockDim.x) {
+      const lds_t v = hist[c];
+      if (v != (lds_t)0) {
+        const int64_t bin = ((int64_t)part << shift) + c;
+        if (bin < n_bins) {
+          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(out) + bin, (double)v);
+          else atomicAdd(reinterpret_cast<unsigned long long*>(out) + bin, (unsigned long long)v);
+        }
+        hist[c] = (lds_t)0;
+      }
+    }
+    if (tid == 0 && !WEIGHTED) hist[bpp] = (lds_t)0;
+    __syncthreads();
+    lo = pend;
+  }
+}
+
+}  // namespace xhist
