@@ -35,16 +35,18 @@ namespace xhist {
 
 constexpr int kRouteGrp = 8;                  // records per aligned group: 8 codes = one 16-byte store
 constexpr uint32_t kChunkFillMask = 0xfffffu;  // cmeta[id] = partition << 20 | records in the chunk
-constexpr int kRouteCtl = 12 * 1024 + 64;      // control arrays of part_route (see the kernel)
-// workgroup of the routing pass and its tile: 8 samples per lane.  Two 512-thread workgroups share a CU (their
-// phases — load, digitize, sort in LDS, store — interleave; one 1024-thread workgroup runs them back to back
-// and leaves HBM idle while it sorts and stores)
-#ifndef XHIST_ROUTE_BLOCK
-#define XHIST_ROUTE_BLOCK 512
+#ifndef XHIST_ROUTE_QUADS
+#define XHIST_ROUTE_QUADS 1
 #endif
-constexpr int kRouteBlock = XHIST_ROUTE_BLOCK, kRouteTile = kRouteBlock * 8;
+// workgroup and tile of the routing pass: 4 samples per lane.  (8 per lane — the tile of part_scatter — needs more
+// registers than a 1024-thread workgroup has: what spills is reloaded inside the loop, and every reload waits for the
+// prefetch in flight, see below.)
+constexpr int kRouteBlock = 1024, kRouteTile = kRouteBlock * 4 * XHIST_ROUTE_QUADS;
 constexpr int kRouteLoads = kRouteTile / (kRouteBlock * 4);  // 4-sample vectors per lane and tile
+constexpr int kRouteListCap = 1024;            // chunks one workgroup can file in its LDS list (beyond: filed one by one, slowly)
+constexpr int kRouteCtl = 18496 + 2 * 4 * kRouteListCap;  // control arrays of part_route (see the kernel)
 constexpr int kAccBatch = 1024;                // chunks a workgroup of part_accumulate_chunks stages at a time
+__host__ __device__ constexpr int route_batch(int P) { return 2 * P; }  // chunk ids a workgroup takes from the pool at a time
 
 struct RouteArgs {
   uint32_t* pool;       // [0]: next unused chunk id
@@ -78,8 +80,24 @@ __device__ __forceinline__ V pulled_back(V q, int sh, S fill) {
   return r;
 }
 
+// `need` consecutive chunk ids from the workgroup's two LDS-resident id ranges a = {next0, end0, next1, end1};
+// 0xFFFFFFFF when both are used up (the caller then goes to the global pool itself)
+__device__ __forceinline__ uint32_t route_take_ids(uint32_t* a, uint32_t need) {
+  uint32_t s = atomicAdd(a + 0, need);
+  if (s + need <= a[1]) return s;
+  s = atomicAdd(a + 2, need);
+  if (s + need <= a[3]) return s;
+  return 0xffffffffu;
+}
+
+// Nothing between the issue of a tile's loads and their first use may wait on the vector-memory counter: it
+// counts loads, stores and returning atomics in order, so a wait for ANY of them — a register reloaded from
+// scratch, a chunk id fetched from the global pool — is a wait for the whole prefetch, and the pass degenerates
+// into load, wait, sort, store, one after the other (4.2 ms instead of 3.4 for a C5 shard).  Hence: everything
+// the partition owners keep from tile to tile (record cursors, chunk lists) lives in LDS, and chunk ids come
+// from an LDS-resident stock that one lane refills from the global pool a tile before it runs out.
 template <typename ST, typename WT, int D, int SCAN>
-__global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) part_route(const Params p, const RouteArgs ra) {
+__global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const RouteArgs ra) {
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
   constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
@@ -107,7 +125,14 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
   uint32_t* endw = first + 256;                                  // [P] end of the whole groups of the block
   uint32_t* enda = endw + 256;                                   // [P] end of the records of the block
   uint32_t* split = enda + 256;                                  // [P] LDS slot from which the block continues in the new chunk
-  uint32_t* total_p = split + 256;                               // LDS slots in use this tile
+  uint64_t* o_cur = reinterpret_cast<uint64_t*>(ctl + 12288);    // [P] next free record slot of the partition's chunk
+  uint64_t* o_cend = o_cur + 256;                                // [P] end of that chunk (0 = no chunk yet)
+  uint32_t* head = reinterpret_cast<uint32_t*>(ctl + 16384);     // [P] newest entry of the partition's chunk list
+  uint32_t* ccnt = head + 256;                                   // [P] chunks this workgroup filed for the partition
+  uint32_t* misc = ccnt + 256;                                   // [0] LDS slots in use this tile, [1] list entries, [4..7] id stock
+  uint32_t* cl_id = misc + 16;                                   // [kRouteListCap] chunk ids filed by this workgroup ...
+  uint32_t* cl_prev = cl_id + kRouteListCap;                     // ... chained per partition
+  uint32_t* stock = misc + 4;
   unsigned char* dyn = ctl + kRouteCtl;
   uint32_t* carry_key = reinterpret_cast<uint32_t*>(dyn);       // [P][GRP]
   dyn += (size_t)P * GRP * 4;
@@ -127,48 +152,65 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
 #pragma unroll
   for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
   const uint32_t code_mask = (1u << shift) - 1u;
+  const uint32_t batch = (uint32_t)route_batch(P);
   for (int i = tid; i < 256; i += blockDim.x) {
     cnt2[i] = 0u;
     cnt2[256 + i] = 0u;
     cin2[i] = 0u;
     cin2[256 + i] = 0u;
+    o_cur[i] = 0;
+    o_cend[i] = 0;
+    head[i] = 0xffffffffu;
+    ccnt[i] = 0u;
   }
-  // The lane that owns partition `tid` holds its record cursor: [cur, cend) is what is left of the
-  // current chunk; `spare` is the chunk it will continue in, taken from the pool one chunk ahead of need
-  // (the atomics that fetch it are not waited for until the next switch) and filed in the partition's
-  // list (slot spare_pos) when it becomes current.
-  uint64_t cur = 0, cend = 0;
-  uint32_t spare = 0, spare_pos = 0;
-  bool have_spare = false;
-  if (tid < P) {
-    const uint32_t id = atomicAdd(ra.pool, 2u);
-    const uint32_t pos = atomicAdd(ra.pcount + tid, 2u);
-    ra.plist[(size_t)tid * ra.list_cap + pos] = id;
-    cur = (uint64_t)id << lg;
-    cend = cur + CH;
-    spare = id + 1;
-    spare_pos = pos + 1;
-    have_spare = true;
+  if (tid == 0) {
+    const uint32_t b = atomicAdd(ra.pool, 2u * batch);
+    stock[0] = b;
+    stock[1] = b + batch;
+    stock[2] = b + batch;
+    stock[3] = b + 2u * batch;
+    misc[1] = 0u;
   }
+  bool refill_pending = false;  // lane 0: a batch of ids has been asked for, `refill_ids` arrives by the next tile
+  uint32_t refill_ids = 0;
   __syncthreads();
+
+  // a chunk becomes partition q's current one: chained into the workgroup's list (or, list full, filed directly)
+  auto file_chunk = [&](int q, uint32_t id) {
+    const uint32_t e = atomicAdd(misc + 1, 1u);
+    if (e < (uint32_t)kRouteListCap) {
+      cl_id[e] = id;
+      cl_prev[e] = head[q];
+      head[q] = e;
+      ccnt[q] += 1u;
+    } else {
+      ra.plist[(size_t)q * ra.list_cap + atomicAdd(ra.pcount + q, 1u)] = id;
+    }
+  };
 
   const int64_t n_tiles = (n + kRouteTile - 1) / kRouteTile;
   const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // the grid never exceeds the number of tiles
   auto tile_base = [&](int64_t k) { return ((int64_t)blockIdx.x + k * gridDim.x) * kRouteTile; };
   // Loads are free of control flow (see part_scatter): a quad that would cross the end of the arrays is
   // read 4 elements back from the end and moved into place when it is used.  Requires n >= 4.
-  auto load_samples = [&](int64_t base, s4 (&x)[D][U]) {
+  // Addresses: a uniform 64-bit tile pointer (scalar registers) plus ONE 32-bit byte offset per lane and load —
+  // twelve 64-bit lane addresses kept across the loop were a third of the register file.
+  auto load_tile = [&](int64_t base, s4 (&x)[D][U], w4 (&w)[U]) {
+    const int64_t origin = min(base, n - 4);  // (a last tile of fewer than 4 samples reads the 4 before the end)
+    const uint32_t last = (uint32_t)min(n - 4 - origin, (int64_t)kRouteTile);  // first element of the last whole quad, tile-relative
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = min(base + ((int64_t)u * kRouteBlock + tid) * 4, n - 4);
+      const uint32_t e = min((uint32_t)(u * kRouteBlock + tid) * 4u, last);
 #pragma unroll
-      for (int d = 0; d < D; ++d) x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(sp[d] + i));
+      for (int d = 0; d < D; ++d)
+        x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + origin) + e * (uint32_t)sizeof(ST)));
+      if (kWeighted)
+        w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(reinterpret_cast<const char*>(wp + origin) + e * (uint32_t)sizeof(wscalar)));
     }
   };
   s4 xv[D][U];
-  w4 w[U];
-  load_samples(tile_base(0), xv);
-  uint32_t my_carry = 0;  // lane q < P: records of partition q carried into the next tile
+  w4 w[U], wn[U];
+  load_tile(tile_base(0), xv, w);
   int cur_set = 0;
   for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
     const int64_t base = tile_base(k);
@@ -185,9 +227,6 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
       }
     }
     // ---- digitize the tile: flat bin index per sample (0xFFFFFFFF = dropped) ----------------------
-    // (one quad per input at a time: digitizing all 8 samples of a lane as one batch, as the streaming kernels
-    // do to keep table reads in flight, costs more registers than a 1024-thread workgroup has next to the
-    // sort's own state — the batch version spilled 80 VGPRs for two float64 inputs)
     uint32_t flat[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -196,14 +235,15 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
       for (int d = 0; d < D; ++d) xs[d][0] = xv[d][u];
       uint32_t cntle[D][1][4];
       if constexpr (SCAN == kScanArith) {
-        // table-free digitize has no loads to overlap, only ~6 float64 temporaries per sample: one sample at a time
+        // the edge constants stay in scalar registers: left alone, the compiler copies them (5 float64 per input)
+        // into vector registers ahead of the loop, and a 1024-thread workgroup has none to spare
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int d = 0; d < D; ++d) {
+          DimTable t = p.dim[d];
+          asm volatile("" : "+s"(t.e0_f), "+s"(t.eL_f), "+s"(t.step), "+s"(t.inv_step), "+s"(t.nb));
 #pragma unroll
-          for (int d = 0; d < D; ++d) {
-            cntle[d][0][v] = count_le_arith((double)xs[d][0][v], p.dim[d]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          for (int v = 0; v < 4; ++v) cntle[d][0][v] = count_le_arith((double)xs[d][0][v], t);
+        }
       } else {
         count_le_tile<CMP, SCAN, D, 1, 4>(xs, p, tab, max_steps, cntle);
       }
@@ -219,29 +259,20 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
         }
         flat[u][v] = ok ? fl : 0xffffffffu;
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t rank[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < 4; ++v) rank[u][v] = (flat[u][v] != 0xffffffffu) ? atomicAdd(cnt + (flat[u][v] >> shift), 1u) : 0u;
-    // Loads issued here land while the block layout is worked out: this tile's weights (needed when the tile
-    // is written into LDS — they are not prefetched a tile ahead: 16 more registers than a 1024-thread
-    // workgroup can spare) and the NEXT tile's samples (the tile after the last one is the last one again: one
-    // redundant load per workgroup instead of a branch around loads).  Both are waited for when the weights
-    // are used, i.e. before this tile's record stores go out.
-    if (kWeighted) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wp + min(base + ((int64_t)u * kRouteBlock + tid) * 4, n - 4)));
-    }
-    load_samples(tile_base(k + 1 < my_tiles ? k + 1 : k), xv);
+    // the next tile's loads (the tile after the last one is the last one again: one redundant load per
+    // workgroup instead of a branch around loads); waited for just before this tile's stores go out
+    load_tile(tile_base(k + 1 < my_tiles ? k + 1 : k), xv, wn);
     __syncthreads();
-    // ---- block layout (as in part_scatter) + record space of every partition's block -----------------
+    // ---- block layout (as in part_scatter) + record space of every partition's block: LDS only -------
     if (tid < ((P + 63) & ~63)) {
       const int lane = tid & 63;
-      const uint32_t c_in = my_carry;
+      const uint32_t c_in = tid < P ? cin[tid] : 0u;
       const uint32_t T = c_in + (tid < P ? cnt[tid] : 0u);
       const uint32_t block = (T + kGm) & ~kGm;
       uint32_t x = block;  // inclusive scan over the wavefront
@@ -260,36 +291,29 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
         first[tid] = B + c_in;
         endw[tid] = B + whole;
         enda[tid] = B + T;
+        uint64_t cur = o_cur[tid];
+        const uint64_t cend = o_cend[tid];
         delta[tid] = cur - B;
         const uint64_t room = cend - cur;
         if (whole <= room) {
           split[tid] = 0xffffffffu;
-          cur += whole;
-        } else {  // the current chunk fills up inside this block: the rest goes to the spare chunk
+          o_cur[tid] = cur + whole;
+        } else {  // the current chunk fills up inside this block: the rest goes to new chunk(s)
           const uint32_t n1 = (uint32_t)room, rest = whole - n1;
           const uint32_t need = (rest + CH - 1) >> lg;  // > 1 only when one tile sends more than a chunk to one partition
-          ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
-          uint32_t id0;
-          if (need == 1) {
-            id0 = spare;
-            ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
-            spare = atomicAdd(ra.pool, 1u);
-            spare_pos = atomicAdd(ra.pcount + tid, 1u);
-          } else {  // consecutive chunk ids: the rest of the block stays one contiguous run
-            id0 = atomicAdd(ra.pool, need);
-            const uint32_t pos0 = atomicAdd(ra.pcount + tid, need);
-            for (uint32_t i = 0; i < need; ++i) ra.plist[(size_t)tid * ra.list_cap + pos0 + i] = id0 + i;
-            for (uint32_t i = 0; i + 1 < need; ++i) ra.cmeta[id0 + i] = ((uint32_t)tid << 20) | CH;
-          }
+          if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
+          uint32_t id0 = route_take_ids(stock, need);
+          if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, need);  // stock used up (a burst of switches): costs a stall
+          for (uint32_t i = 0; i < need; ++i) file_chunk(tid, id0 + i);  // consecutive ids: the rest of the block is one run
+          for (uint32_t i = 0; i + 1 < need; ++i) ra.cmeta[id0 + i] = ((uint32_t)tid << 20) | CH;
           const uint64_t nb = (uint64_t)id0 << lg;
           split[tid] = B + n1;
           delta2[tid] = nb - (B + n1);
-          cur = nb + rest;
-          cend = nb + ((uint64_t)need << lg);
+          o_cur[tid] = nb + rest;
+          o_cend[tid] = nb + ((uint64_t)need << lg);
         }
-        my_carry = T - whole;
-        cin2[((cur_set ^ 1) << 8) + tid] = my_carry;
-        if (tid == P - 1) *total_p = B + block;
+        cin2[((cur_set ^ 1) << 8) + tid] = T - whole;
+        if (tid == P - 1) misc[0] = B + block;
       }
     }
     if (tid < 256) cnt2[((cur_set ^ 1) << 8) + tid] = 0u;
@@ -321,11 +345,14 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      w[u] = wn[u];
+      if (kWeighted) asm volatile("" : "+v"(w[u]));  // the wait for the prefetch sits here, ahead of the stores
 #pragma unroll
-      for (int d = 0; d < D; ++d) asm volatile("" : "+v"(xv[d][u]));  // the wait for the prefetch sits here, ahead of the stores
+      for (int d = 0; d < D; ++d) asm volatile("" : "+v"(xv[d][u]));
+    }
     __syncthreads();
-    const uint32_t total = *total_p;
+    const uint32_t total = misc[0];
     // ---- records out: one lane per group of 8 codes / per 16 bytes of weights -------------------------
     for (uint32_t g0 = (uint32_t)tid * GRP; g0 < total; g0 += kRouteBlock * GRP) {
       uint32_t kk[GRP];
@@ -362,20 +389,43 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
         }
       }
     }
+    // ---- the id stock: lane 0 moves the second range up when the first is used up, and asks the pool for a new
+    // second range; the answer is picked up one tile later (nobody waits for it) -----------------------------------
+    if (tid == 0) {
+      if (refill_pending) {
+        if (stock[2] >= stock[3]) {  // (always, unless the burst path refilled... it never does: the range is simply replaced)
+          stock[2] = refill_ids;
+          stock[3] = refill_ids + batch;
+        }
+        refill_pending = false;
+      }
+      if (stock[0] + (uint32_t)(kRouteTile >> lg) + 1u > stock[1] && stock[2] < stock[3]) {
+        stock[0] = stock[2];
+        stock[1] = stock[3];
+        stock[2] = stock[3] = 0u;
+      }
+      if (stock[2] >= stock[3]) {
+        refill_ids = atomicAdd(ra.pool, batch);
+        refill_pending = true;
+      }
+    }
     // no barrier here: the next tile's ranking touches only the other counter set, and nobody passes
     // that tile's first barrier before every lane has finished this write-out
   }
   __syncthreads();
-  // the last group of each partition (carried records padded with neutral ones), then the books are
-  // closed: fill of the chunk in use, and the spare chunk filed as empty
+  // the last group of each partition (carried records padded with neutral ones), the fill of the chunk in use,
+  // and this workgroup's chunk lists handed over to the partitions' global lists
   if (tid < P) {
+    const uint32_t my_carry = cin2[(cur_set << 8) + tid];
+    uint64_t cur = o_cur[tid], cend = o_cend[tid];
     if (my_carry != 0u) {
       if (cur == cend) {
-        ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
-        ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
-        cur = (uint64_t)spare << lg;
+        if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
+        uint32_t id0 = route_take_ids(stock, 1u);
+        if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, 1u);
+        file_chunk(tid, id0);
+        cur = (uint64_t)id0 << lg;
         cend = cur + CH;
-        have_spare = false;
       }
       for (int i = 0; i < GRP; ++i) {
         const bool real = (uint32_t)i < my_carry;
@@ -384,10 +434,15 @@ __global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_e
       }
       cur += GRP;
     }
-    ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | (uint32_t)(cur - (cend - CH));
-    if (have_spare) {
-      ra.plist[(size_t)tid * ra.list_cap + spare_pos] = spare;
-      ra.cmeta[spare] = (uint32_t)tid << 20;  // filed, empty
+    if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | (uint32_t)(cur - (cend - CH));
+    const uint32_t mine = ccnt[tid];
+    if (mine != 0u) {
+      const uint32_t pos0 = atomicAdd(ra.pcount + tid, mine);
+      uint32_t e = head[tid];
+      for (uint32_t j = 0; j < mine; ++j) {
+        ra.plist[(size_t)tid * ra.list_cap + pos0 + j] = cl_id[e];
+        e = cl_prev[e];
+      }
     }
   }
 }
