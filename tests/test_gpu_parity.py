@@ -1455,3 +1455,23 @@ def test_resident_short_cut_equals_the_general_path(xh, dtype):
     h2, _ = xh.histogram(xt, bins=e)
     np.testing.assert_array_equal(h2.cpu().numpy(), onp.histogram(x, bins=np.linspace(-2, 2, 5))[0])
     assert int(h2.sum()) > int(h1.sum())
+
+
+def test_host_inputs_of_mixed_dtypes_with_a_big_histogram_take_the_vector_kernels(xh):
+    """numpy inputs: float32 x float64 samples, int32 weights, 300 x 300 bins (beyond LDS) — converted to float64
+    on the host (exact: numpy promotes the same way) instead of 2.5e10/s memory-side atomics of the generic family"""
+    from xhistogram_amd import _native
+
+    rng = np.random.default_rng(12)
+    n = 400_000
+    x = rng.standard_normal(n).astype(np.float32)
+    y = rng.standard_normal(n)
+    w = rng.integers(-3, 9, n).astype(np.int32)
+    e = [np.linspace(-4, 4, 301), np.sort(rng.uniform(-4, 4, 301))]
+    got, _ = xh.histogram(x, y, bins=e, weights=w)
+    want, _ = onp.histogram(x, y, bins=e, weights=w)
+    assert_hist_equal(got, want, weighted=True)
+    desc = xh._get_plan(e, _native.CMP_F64, xh._host_device()).describe()
+    assert "family=fast" in desc, desc
+    got, _ = xh.histogram(x, y, bins=e)
+    np.testing.assert_array_equal(got, onp.histogram(x, y, bins=e)[0])
