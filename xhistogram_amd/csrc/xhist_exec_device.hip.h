@@ -570,6 +570,29 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     if (fast_ok && weighted) fast_ok = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
   }
 
+  // Mixtures the homogeneous vector kernels do not take — float32 next to float64, integers in a joint histogram,
+  // integer / bool / half weights — with unit column strides and the float64 compare domain: the MIXED variant of the
+  // vector kernels (four elements per load in each array's own dtype, consumed as float64).  LDS histograms only;
+  // beyond LDS the Python layer converts such inputs to float64 first (core._promote_for_big_histograms).
+  bool mixed_ok = false;
+  if (!fast_ok && !force_generic && !two && p->cmp == XHIST_CMP_F64 && D <= 3 && p->n_bins < ((int64_t)1 << 24) && !p->huge) {
+    // element-aligned, and for 1- / 2-byte elements every row dword-aligned (their four-element loads are one dword / two)
+    auto vector_loadable = [&](const xhist_array& a) {
+      const size_t es = (size_t)dtype_size(a.dtype), al = es < 4 ? 4 : es;
+      if (!(a.col_stride == 1 || n_cols == 1) || (uintptr_t)a.data % al != 0) return false;
+      if (es >= 4 || n_rows == 1) return true;
+      return (a.row_stride * es) % 4 == 0 && (a.outer_stride * es) % 4 == 0;
+    };
+    mixed_ok = true;
+    for (int d = 0; d < D && mixed_ok; ++d) mixed_ok = vector_loadable(samples[d]);
+    if (mixed_ok && weighted) mixed_ok = vector_loadable(*weights);
+    // measured (tools/mixtures.py, 2 x 10^8 samples): arrays of <= 4-byte elements gain 1.8-3.6 x over the generic family
+    // (float32 + int32 weights 1.06 -> 0.29 ms, int32 x int32 1.17 -> 0.40, uint8 x float32 1.15 -> 0.37); with an 8-byte
+    // array in a joint histogram the two are level (float32 x float64 0.91 -> 0.89), and ONE 8-byte input with odd
+    // weights is better off in the generic family (float64 + int32 weights 0.64 against 0.75)
+    if (mixed_ok && D == 1 && dtype_size(samples[0].dtype) == 8) mixed_ok = false;
+  }
+
   // Two attempts: the vector family with its tables, then (if it has no kernel for this
   // combination, or its tables do not fit LDS) the generic family with the native tables.
   bool fast = false, use_f32 = false, tables_fit = false, lds_hist = false, tables_in_lds = false;
@@ -617,13 +640,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     }
     if (hist == kHistGlobal) { cl2 = 0; hist_bytes = 0; }
   };
-  for (int attempt = fast_ok ? 0 : 1; attempt < 2 && !fn; ++attempt) {
+  bool mixed = false;
+  for (int attempt = (fast_ok || mixed_ok) ? 0 : 1; attempt < 2 && !fn; ++attempt) {
     fast = attempt == 0;
+    mixed = fast && !fast_ok;
     // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
-    use_f32 = fast && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;
+    use_f32 = fast && !mixed && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;  // (mixed dtypes are consumed as float64)
     scan = 0;
     tset = &p->ts[0][0];  // generic family: native domain, (start, cnt) tables
     if (fast) tset = &pick_tables(p, use_f32, &scan);
+    if (mixed && scan >= 3) {  // the mixed variant has no 3- / 4-edge scans: binary search on the (start, cnt) tables
+      scan = 0;
+      tset = &p->ts[0][0];
+    }
     table_bytes = (size_t)tset->words * 8;
     tables_fit = table_bytes + 1024 <= lds_cap && !(fast && p->huge);  // no bucket tables: not for the vector family
     if (tables_fit || !fast) place(table_bytes, fast);
@@ -632,7 +661,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     // uniform bins stay on the streaming kernels instead of 43 ms/10^9 samples of global atomics.
     // Also when the tables fit but only with 3-4 edges per bucket (float32, 20000 bins: 1.17 against 1.39 ms);
     // with 1-2 edges per bucket the tables win (C2: 2.28 against 2.40 ms, float32 50 bins: 0.69 against 1.12).
-    if (fast && float_samples && p->arith && arith_pref >= 0 &&
+    if (fast && (float_samples || mixed) && p->arith && arith_pref >= 0 &&
         (!tables_fit || hist == kHistGlobal || scan == 0 || scan >= 3 || arith_pref > 0)) {
       const int h0 = hist, c0 = cl2;
       const size_t b0 = hist_bytes;
@@ -648,6 +677,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       }
     }
     if (fast && !tables_fit) continue;  // the vector family keeps its tables in LDS
+    if (mixed && hist != kHistLds) continue;  // (packed / memory-side histograms: the generic family)
     lds_hist = hist == kHistLds;
     tables_in_lds = tables_fit;
     lds_bytes = (tables_in_lds ? table_bytes : 0) + hist_bytes;
@@ -659,6 +689,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       fn = fast_kernel_two_weights(sdt, wdt, D, scan, &vec);
       if (!fn) return XHIST_ERR_UNSUPPORTED;
       break;
+    }
+    if (mixed) {
+      fn = xhist_pick_mixed(weighted, D, scan);
+      vec = 4;
+      continue;  // (no kernel: the loop goes on to the generic family)
     }
     fn = fast ? (i64dom ? int64_domain_kernel(wdt, D, scan, hist, &vec) : fast_kernel(sdt, wdt, D, scan, hist, &vec))
               : generic_kernel(p->cmp, weighted, lds_hist, tables_in_lds);
@@ -768,7 +803,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       accumulate = 1;  // the output has just been zeroed
     }
   }
-  const int kUnroll = fast ? unroll_for(D, vec, scan) : 1;
+  const int kUnroll = mixed ? mixed_unroll(D) : (fast ? unroll_for(D, vec, scan) : 1);
 
   // ---- geometry -----------------------------------------------------------------------------
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
@@ -957,7 +992,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         snprintf(desc, sizeof desc,
                  "family=%s hist=%s vec=%d unroll=%d block=%d grid=%lld segs=%lld lds_bytes=%zu copies=%d table_bytes=%zu "
                  "lut_k0=%d steps0=%d scan=%d weighted=%d D=%d cmp=%s lds_cap=%zu%s slices=%d direct_store=%d",
-                 fast ? "fast" : "generic", hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
+                 mixed ? "fast mixed-dtypes" : (fast ? "fast" : "generic"), hist == kHistLds ? "lds" : (hist == kHistPacked ? "packed16" : "global"),
                  fast ? vec : 1, fast ? kUnroll : 1, block, (long long)(nr * segs), (long long)segs, lds_bytes, 1 << cl2,
                  table_bytes, dims[0].lut_k, dims[0].steps, scan, (int)weighted, D,
                  use_f32 ? "f32thr" : (p->cmp == XHIST_CMP_I64 ? "i64" : (p->cmp == XHIST_CMP_F64 ? "f64" : "per-input")), lds_cap,

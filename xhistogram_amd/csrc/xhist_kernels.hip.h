@@ -361,6 +361,64 @@ __device__ __forceinline__ const uint64_t* stage_tables(const Params& p) {
 template <typename T, int N>
 struct VecOf { typedef T type __attribute__((ext_vector_type(N), aligned(sizeof(T)))); };
 
+// Four consecutive elements of ANY supported dtype as float64 — what numpy's promotion does to float32 / integer
+// samples against float64 edges (core.py:170) and np.bincount to weights: the loads of the MIXED variant of hist_fast
+// (inputs of different dtypes, integer weights).  Two steps, so that every load of a tile is in flight before the first
+// conversion waits for one: load4_raw picks the load width from the element SIZE (one to two 16-byte loads, one 8-byte,
+// one 4-byte; 1- and 2-byte rows arrive dword-aligned, the host side sees to that), raw4_as_double converts by dtype.
+typedef double double4_t __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t raw_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t raw_u2 __attribute__((ext_vector_type(2), aligned(4)));
+struct Raw4 {
+  raw_u4 a, b;
+};
+__device__ __forceinline__ Raw4 load4_raw(const unsigned char* base, int es, int64_t i) {
+  Raw4 r;
+  const unsigned char* p = base + i * es;
+  if (es == 8) {
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const raw_u4*>(p));
+    r.b = __builtin_nontemporal_load(reinterpret_cast<const raw_u4*>(p) + 1);
+  } else if (es == 4) {
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const raw_u4*>(p));
+  } else if (es == 2) {
+    const raw_u2 q = __builtin_nontemporal_load(reinterpret_cast<const raw_u2*>(p));
+    r.a[0] = q[0];
+    r.a[1] = q[1];
+  } else {
+    r.a[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+  }
+  return r;
+}
+// one dtype switch per FOUR elements
+__device__ __forceinline__ double4_t raw4_as_double(const Raw4& r, int32_t dt) {
+  double4_t o;
+  auto w64 = [&](int v) { return v < 2 ? (((uint64_t)r.a[2 * v + 1] << 32) | r.a[2 * v]) : (((uint64_t)r.b[2 * v - 3] << 32) | r.b[2 * v - 4]); };
+  auto w16 = [&](int v) { return (r.a[v >> 1] >> ((v & 1) * 16)) & 0xffffu; };
+  auto w8 = [&](int v) { return (r.a[0] >> (v * 8)) & 0xffu; };
+#define XH_CVT4(EXPR)            \
+  _Pragma("unroll") for (int v = 0; v < 4; ++v) o[v] = (EXPR); \
+  break;
+  switch (dt) {
+    case DT_F64: XH_CVT4(__longlong_as_double((long long)w64(v)))
+    case DT_F32: XH_CVT4((double)__uint_as_float(r.a[v]))
+    case DT_F16: XH_CVT4((double)(float)__builtin_bit_cast(_Float16, (uint16_t)w16(v)))
+    case DT_I64: XH_CVT4((double)(int64_t)w64(v))
+    case DT_I32: XH_CVT4((double)(int32_t)r.a[v])
+    case DT_I16: XH_CVT4((double)(int16_t)(uint16_t)w16(v))
+    case DT_I8: XH_CVT4((double)(int8_t)(uint8_t)w8(v))
+    case DT_U64: XH_CVT4((double)w64(v))
+    case DT_U32: XH_CVT4((double)r.a[v])
+    case DT_U16: XH_CVT4((double)w16(v))
+    case DT_U8: XH_CVT4((double)w8(v))
+    default: XH_CVT4(w8(v) != 0u ? 1.0 : 0.0)  // DT_BOOL: any non-zero byte is True
+  }
+#undef XH_CVT4
+  return o;
+}
+__device__ __forceinline__ int dt_size(int32_t dt) {
+  return (dt == DT_F64 || dt == DT_I64 || dt == DT_U64) ? 8 : ((dt == DT_F32 || dt == DT_I32 || dt == DT_U32) ? 4 : ((dt == DT_F16 || dt == DT_I16 || dt == DT_U16) ? 2 : 1));
+}
+
 // #{edges <= x} for every sample of a register tile, as ONE branch-free batch: the table reads of
 // all VEC x UNROLL x D samples are independent and can be in flight together.  Shared by every
 // vector kernel (hist_fast, part_count).
@@ -423,9 +481,14 @@ constexpr int kHistGlobal = 0, kHistLds = 1, kHistPacked = 2;
 //     (the rest go to the trash slot).  S passes cost S x the streaming time; the partitioned mode
 //     moves ~3-4x the algorithmic bytes, so slices win up to S = 3-4 and work for any number of rows.
 // I64DOM: int64 / datetime64 samples compared exactly in int64 against integer edges (Dom<1>)
-template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false, bool SLICED = false, bool I64DOM = false>
+// MIXED: the inputs (and the weights) may be of ANY dtype each (p.s_dt / p.w_dt); they are loaded four elements at a
+//     time in their own type and consumed as float64 (ST = double, WT = double or NoWeight, VEC = 4) — float32 next to
+//     float64 in a joint histogram, integer samples in a joint histogram, integer weights
+template <typename ST, typename WT, int D, int VEC, int UNROLL, int HIST, int SCAN, bool W2 = false, bool SLICED = false, bool I64DOM = false,
+          bool MIXED = false>
 __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr bool LDS_HIST = HIST == kHistLds;
+  static_assert(!MIXED || (__is_same(ST, double) && VEC == 4 && !W2 && !SLICED && !I64DOM && HIST == kHistLds), "mixed dtypes: float64 domain, LDS histograms");
   static_assert(!SLICED || HIST != kHistGlobal, "slices are for LDS-resident histograms");
   static_assert(!W2 || (HIST == kHistLds && !__is_same(WT, NoWeight)), "two weights: weighted, LDS histograms");
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
@@ -478,6 +541,21 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   if (kWeighted) wp = reinterpret_cast<const wscalar*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os);
   const wscalar* wp2 = nullptr;
   if (W2) wp2 = reinterpret_cast<const wscalar*>(p.w2_ptr) + row_offset(p.row0 + row, p.w2_rs, p.w2_ir, p.w2_os);
+  // MIXED: byte pointers to the row, element sizes from the dtype tags
+  const unsigned char* mp[D];
+  const unsigned char* mw = nullptr;
+  if constexpr (MIXED) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      mp[d] = reinterpret_cast<const unsigned char*>(p.s_ptr[d]) + row_offset(p.row0 + row, p.s_rs[d], p.s_ir[d], p.s_os[d]) * dt_size(p.s_dt[d]);
+    if (kWeighted) mw = reinterpret_cast<const unsigned char*>(p.w_ptr) + row_offset(p.row0 + row, p.w_rs, p.w_ir, p.w_os) * dt_size(p.w_dt);
+  }
+  int msz[D + 1];
+  if constexpr (MIXED) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) msz[d] = dt_size(p.s_dt[d]);
+    msz[D] = kWeighted ? dt_size(p.w_dt) : 0;
+  }
   out_t* out = reinterpret_cast<out_t*>(p.out) + row * p.n_bins + (SLICED ? p.slice_lo : 0);  // bin 0 of the slice
   out_t* out2 = W2 ? reinterpret_cast<out_t*>(p.out2) + row * p.n_bins + (SLICED ? p.slice_lo : 0) : nullptr;
 
@@ -536,7 +614,44 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     wvec wv[UNROLL], wv2[UNROLL];
     uint32_t past_end = 0;  // bit (u * VEC + v): that sample lies beyond the row (ragged tile only)
     static_assert(UNROLL * VEC <= 32, "past_end is a 32-bit mask");
-    if (base + tile_elems <= p.n_cols) {
+    if constexpr (MIXED) {
+      Raw4 mraw[D + 1][UNROLL];
+      uint32_t mfull = 0;  // bit u: the u-th vector of this lane was loaded whole and waits in mraw
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + ((int64_t)u * blockDim.x + tid) * VEC;
+        if (i + VEC <= p.n_cols) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) mraw[d][u] = load4_raw(mp[d], msz[d], i);
+          if constexpr (kWeighted) mraw[D][u] = load4_raw(mw, msz[D], i);
+          mfull |= 1u << u;
+        } else {  // the ragged end of a row: element by element, NaN past it
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const bool in = i + v < p.n_cols;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xv[d][u][v] = in ? (ST)load_as<double>(mp[d], p.s_dt[d], i + v) : (ST)__builtin_nanf("");
+            if constexpr (kWeighted) wv[u][v] = in ? (wscalar)load_as<double>(mw, p.w_dt, i + v) : (wscalar)0;
+          }
+        }
+      }
+      // every load of the tile is in flight: now the conversions
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if ((mfull >> u) & 1u) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const double4_t q = raw4_as_double(mraw[d][u], p.s_dt[d]);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[d][u][v] = (ST)q[v];
+          }
+          if constexpr (kWeighted) {
+            const double4_t q = raw4_as_double(mraw[D][u], p.w_dt);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) wv[u][v] = (wscalar)q[v];
+          }
+        }
+    } else if (base + tile_elems <= p.n_cols) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         const int64_t i = base + ((int64_t)u * blockDim.x + tid) * VEC;

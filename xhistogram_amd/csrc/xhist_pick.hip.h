@@ -141,6 +141,32 @@ static kernel_fn sliced_pick_ds(int D, int scan, int hist) {
 }
 
 // ------------------------------------------------------------------------------------------
+// inputs of different dtypes / integer weights, consumed as float64 (hist_fast<..., MIXED = true>): LDS histograms,
+// binary search, <= 2 edges per bucket, or arithmetic edges
+// (raw and converted copies of a tile are both live for a moment: two vectors per lane and input, one for three inputs)
+constexpr int mixed_unroll(int D) { return D >= 3 ? 1 : 2; }
+
+template <typename WT>
+static kernel_fn mixed_pick_ds(int D, int scan) {
+#define XH_MIXED(DD, SS) (kernel_fn)hist_fast<double, WT, DD, 4, mixed_unroll(DD), kHistLds, SS, false, false, false, true>
+#define XH_MIXED_CASE(DD)                                    \
+  case DD:                                                   \
+    if (scan == 0) return XH_MIXED(DD, 0);                   \
+    if (scan == 1) return XH_MIXED(DD, 1);                   \
+    if (scan == 2) return XH_MIXED(DD, 2);                   \
+    if (scan == kScanArith) return XH_MIXED(DD, kScanArith); \
+    return nullptr;
+  switch (D) {
+    XH_MIXED_CASE(1)
+    XH_MIXED_CASE(2)
+    XH_MIXED_CASE(3)
+    default: return nullptr;
+  }
+#undef XH_MIXED_CASE
+#undef XH_MIXED
+}
+
+// ------------------------------------------------------------------------------------------
 // one-pass routing of the partitioned mode (xhist_route.hip.h): binary search, <= 2 edges per bucket, or
 // arithmetic edges; up to three inputs; any of the three weight kinds
 template <typename ST, typename WT>
@@ -176,6 +202,7 @@ kernel_fn xhist_pick_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
+kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
 // (xhist_route_f64.hip / xhist_route_f32.hip)
 kernel_fn_route xhist_pick_route_f64(int wdt, int D, int scan);
 kernel_fn_route xhist_pick_route_f32(int wdt, int D, int scan);
