@@ -1509,3 +1509,29 @@ def test_mixed_dtype_vector_kernels_against_the_oracle(xh, resident):
             got_g, desc_g = _run(xh, samples, edges, w, True, force_generic=1)
             assert "generic" in desc_g and "mixed" not in desc_g, desc_g
             assert_hist_equal(got_g, want, weighted=w is not None)
+
+
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
+def test_table_columns_with_many_bins_are_gathered_into_rows(xh, resident):
+    """(n, K) tables histogrammed over their leading axis with more bins than the row-per-lane kernels hold: the library
+    gathers the (strided) columns into dense rows and runs the vector kernels on them — whole tables, column slices of a
+    wider table, with weights, beyond-LDS histograms"""
+    rng = np.random.default_rng(41)
+    n = 30_011
+    for dtype, K in ((np.float32, 4), (np.float64, 6), (np.int16, 8)):
+        t = (rng.standard_normal((n, K)) * (1 if dtype != np.int16 else 50)).astype(dtype)
+        w = rng.uniform(0, 1, (n, K))
+        if dtype != np.int16:
+            t[7, 1] = np.nan
+        lo, hi = (-4, 4) if dtype != np.int16 else (-200, 200)
+        for nb in (3000, 150_000):
+            e = np.linspace(lo, hi, nb + 1)
+            for view, wv in ((t, None), (t[:, 1:4], None), (t, w), (t[:, :3], w[:, :3])):
+                a = _dev(view) if resident else view
+                if resident and not view.flags.c_contiguous:
+                    a = _dev(t)[:, (1 if view.shape[1] == 3 and wv is None else 0):(4 if wv is None else 3)]
+                ww = None if wv is None else (_dev(w)[:, : view.shape[1]] if resident else wv)
+                got, _ = xh.histogram(a, bins=e, axis=0, weights=ww)
+                got = got.cpu().numpy() if resident else got
+                want, _ = onp.histogram(np.ascontiguousarray(view), bins=e, axis=0, weights=None if wv is None else np.ascontiguousarray(wv))
+                assert_hist_equal(got, want, weighted=wv is not None)

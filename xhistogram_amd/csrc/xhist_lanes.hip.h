@@ -250,4 +250,63 @@ __global__ void __launch_bounds__(256) transpose_2d(const T* __restrict__ in, in
   }
 }
 
+// The other direction: a few rows whose CONTIGUOUS direction is the row index — a view [k rows, n cols] of an (n, K)
+// table (element (r, c) at in[c * K + r]: the columns of a table histogrammed over its leading axis) -> dense [k, n].
+// One table row per lane: the reads of a wavefront cover 64 consecutive table rows (16-byte loads when a row is
+// whole 16-byte units), the writes of each table column are consecutive.
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ in, int64_t K, int k, int64_t n, T* __restrict__ out) {
+  constexpr int kVec = 16 / (int)sizeof(T);
+  typedef T tvec __attribute__((ext_vector_type(kVec), aligned(16)));
+  const bool whole = K == k && (k % kVec) == 0 && ((uintptr_t)in % 16) == 0;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const T* row = in + c * K;
+    if (whole) {
+      for (int j = 0; j < k; j += 4 * kVec) {  // four 16-byte loads in flight per lane, then their stores
+        tvec q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j + u * kVec < k) q[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec*>(row + j + u * kVec));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j + u * kVec < k) {
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) __builtin_nontemporal_store(q[u][v], out + (int64_t)(j + u * kVec + v) * n + c);
+          }
+      }
+    } else {
+      for (int j = 0; j < k; ++j) out[(int64_t)j * n + c] = row[j];
+    }
+  }
+}
+
+// The same for a WHOLE table (K == k, rows of whole 16-byte units), tiled through LDS: 256 table rows are copied into
+// LDS as they lie (flat 16-byte loads: every fetched line is used once, which the lane-per-row reads above leave to
+// the 32 KiB vector cache — 2.7 TB/s for 16 float64 columns), then written out column by column, 256 consecutive
+// elements at a time.  Row pitch k + 1 elements: the column reads are conflict-free.
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_tiled(const T* __restrict__ in, int k, int64_t n, T* __restrict__ out) {
+  constexpr int kVec = 16 / (int)sizeof(T), R = 256;
+  typedef T tvec __attribute__((ext_vector_type(kVec), aligned(16)));
+  T* tile = reinterpret_cast<T*>(xhist_smem);  // [R][k + 1]
+  const int tid = threadIdx.x, pitch = k + 1;
+  const int64_t n_tiles = (n + R - 1) / R;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t r0 = t * R;
+    const int rows = (int)min<int64_t>(R, n - r0);
+    const int n_vec = rows * k / kVec;
+    const T* src = in + r0 * k;
+    for (int i = tid; i < n_vec; i += R) {
+      const tvec q = __builtin_nontemporal_load(reinterpret_cast<const tvec*>(src) + i);
+      const int e = i * kVec, row = e / k, col = e - row * k;
+#pragma unroll
+      for (int v = 0; v < kVec; ++v) tile[row * pitch + col + v] = q[v];
+    }
+    __syncthreads();
+    if (tid < rows)
+      for (int j = 0; j < k; ++j) __builtin_nontemporal_store(tile[tid * pitch + j], out + (int64_t)j * n + r0 + tid);
+    __syncthreads();
+  }
+}
+
 }  // namespace xhist
