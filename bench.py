@@ -59,6 +59,10 @@ def parse():
                     help="c4 / c5 at the FULL size of BASELINE.json on ONE GPU: (3650, 720, 1440) f32 = 15.1 GB; 4*10^9 samples x 24 B = 96 GB")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="xhist_plan_set_param override for A/B runs, e.g. --tune fused=-1 (not for the headline)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="control-flow self-test of the multi-rank harness WITHOUT kernels or GPUs: gloo on CPU, the histogram launch "
+                         "replaced by a no-op (nothing is measured; `metric` says so) — exercises rank spawn, both scaling legs, the "
+                         "gathers and the JSON line, which no 1-GPU box can")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     return ap.parse_args()
@@ -193,6 +197,8 @@ def main():
 
     from xhistogram_amd import _native, core
 
+    if args.selftest:
+        return selftest(args, torch, dist, result_fd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,18 +218,23 @@ def main():
     _native.require_device(local)
 
     wl = build_workload(args.config, args, torch, dev, rank)
+    plan = core._get_plan(wl["edges"], _native.CMP_F64, local)
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        plan.set_param(key, int(val))
+    measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd,
+                       sync=lambda: torch.cuda.synchronize(dev), stream=torch.cuda.current_stream(dev).cuda_stream)
+
+
+def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync, stream):
+    """the timed legs and the JSON line (shared with --selftest, which passes a plan double and CPU tensors)"""
     arrays, w, edges = wl["arrays"], wl["weights"], wl["edges"]
     weighted = w is not None
     n_rows = wl["rows"]
     tag = {torch.float64: _native.F64, torch.float32: _native.F32}
-    plan = core._get_plan(edges, _native.CMP_F64, local)
-    for kv in args.tune:
-        key, _, val = kv.partition("=")
-        plan.set_param(key, int(val))
     # two result buffers: the RCCL all-reduce of step k runs while step k+1's kernel streams
     out_shape = (n_rows,) + plan.bins_shape
     outs = [torch.zeros(out_shape, dtype=torch.float64 if weighted else torch.int64, device=dev) for _ in range(2)]
-    stream = torch.cuda.current_stream(dev).cuda_stream
     reduce_partials = use_dist and wl["reduce"] == "allreduce"
     density = bool(wl.get("density"))
     bytes_per_sample = sum(a.element_size() for a in arrays) + (w.element_size() if weighted else 0)
@@ -231,7 +242,7 @@ def main():
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     def run_leg(n_cols, steps, warmup):
         """`warmup` untimed + `steps` timed passes over the first n_cols samples of every row of this rank's
@@ -299,7 +310,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(steps):
                 dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize(dev)
+            sync()
             allreduce_ms = (time.perf_counter() - t0) / steps * 1e3
             fence()
         n = n_rows * n_cols
@@ -357,7 +368,7 @@ def main():
             }
 
         line = {
-            "metric": wl["metric"],
+            "metric": ("SELFTEST of the harness control flow, nothing measured: " if args.selftest else "") + wl["metric"],
             "value": m["value"],
             "unit": "samples/s",
             "n_gpus": world,
@@ -386,7 +397,7 @@ def main():
         for name, leg in legs.items():
             if name != main_leg:
                 line[name] = leg_summary(leg)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.selftest:
             nflat = arrays[0].numel()
             k = min(args.cpu_sample // max(1, len(arrays)), nflat)
             flat = [a.reshape(-1)[:k].cpu().numpy() for a in arrays]
@@ -396,6 +407,61 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def selftest(args, torch, dist, result_fd):
+    """--selftest: the multi-rank control flow of this script on CPU (gloo), with a plan double whose launch only marks
+    the output; no kernel runs and nothing is measured.  What it proves: ranks spawn and rendezvous, both scaling legs
+    run, the per-rank gathers and the all-reduce timing work, rank 0 prints ONE well-formed JSON line."""
+    from xhistogram_amd import _native, core
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py rank %d: --gpus %d does not match WORLD_SIZE %d" % (rank, args.gpus, world))
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    args.samples = min(args.samples, 20_000)
+    wl = build_workload("c2", args, torch, dev, rank)
+
+    class PlanDouble:
+        bins_shape = (args.bins,)
+
+        def __init__(self):
+            self.n = 0
+
+        def bind(self, xv, wv, n_rows, n_cols, out_ptr, weighted, mem, accumulate=False, stream=0):
+            out = next(o for o in self.outs if o.data_ptr() == out_ptr)
+
+            def run():
+                out.fill_(1.0)  # "a histogram was produced": the harness only checks that the total is positive
+                self.n += 1
+            return run
+
+        def set_param(self, key, value):
+            self.k = int(value) if key == "profile" else getattr(self, "k", 0)
+
+        def profile_read(self):
+            return [1e-3] * max(1, getattr(self, "k", 1))
+
+        def describe(self):
+            return "selftest: no kernel"
+
+    plan = PlanDouble()
+    orig_zeros = torch.zeros
+
+    def zeros_spy(*a, **k):  # the plan double needs to find the output tensors the harness allocates
+        t = orig_zeros(*a, **k)
+        plan.outs = getattr(plan, "outs", []) + [t]
+        return t
+
+    torch.zeros = zeros_spy
+    try:
+        measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync=lambda: None, stream=0)
+    finally:
+        torch.zeros = orig_zeros
 
 
 if __name__ == "__main__":

@@ -217,3 +217,26 @@ def test_bench_spawns_its_ranks_and_fails_per_rank_without_gpus():
     assert "spawning 2 ranks" in r.stderr
     assert "rank 1 of 2: needs GPU 1" in r.stderr
     assert r.stdout.strip() == ""  # stdout carries the JSON line of a successful run, nothing else
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_control_flow_selftest(scaling):
+    """`bench.py --gpus 2 --selftest`: the N > 1 branches of the harness (rank spawn, rendezvous, both scaling legs,
+    per-rank gathers, all-reduce timing, ONE JSON line from rank 0) run on CPU over gloo with a plan double — no kernel, no
+    oracle, nothing measured.  The real launch differs only in backend ("nccl"), device and plan."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest", "--steps", "3", "--warmup", "1",
+                        "--scaling", scaling], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    other = "strong" if scaling == "weak" else "weak"
+    assert d["metric"].startswith("SELFTEST") and d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3
+    assert len(d["kernel_ms_per_rank"]) == 2 and d["allreduce_ms_alone"] is not None and "cpu_baseline" not in d
+    assert d[other]["samples_total"] == (20_000 if other == "strong" else 40_000)
+    assert d["config"]["samples_total"] == (40_000 if scaling == "weak" else 20_000)
+    assert len(d[other]["kernel_ms_per_rank"]) == 2
+    for key in ("value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in d
