@@ -186,7 +186,9 @@ int xhist_buffer_add(int device, void* dst, const void* src, int64_t count, int 
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
- *       "lds_copies" (0 = auto), "profile" (0 = off, R = keep the last R kernel timings) */
+ *       "lds_copies" (0 = auto), "profile" (0 = off, R = keep the last R kernel timings),
+ *       "profile_stride" (S >= 1: time every S-th execute only — for microsecond kernels, where the two event records of
+ *       the profile mode cost as much as the launch itself) */
 int xhist_plan_set_param(xhist_plan* plan, const char* key, int64_t value);
 /* human-readable description of the last launch (kernel family, LDS bytes, copies, grid...) */
 int xhist_plan_describe(xhist_plan* plan, char* buf, size_t cap);

@@ -176,6 +176,8 @@ struct xhist_plan {
   int lanes = 0;      // 0 auto, 1 prefer the row-per-lane kernels whenever they are legal, -1 never
   int lds_copies = 0;
   int profile = 0;
+  int profile_stride = 1;  // record the event pair of every stride-th execute only (microsecond kernels: two event records cost as much as the launch)
+  int64_t n_seen = 0;
   std::mutex mu;  // guards events + desc
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;  // profile > 0: event pairs around the main kernel
   int64_t n_recorded = 0;                                // executes recorded since the last read

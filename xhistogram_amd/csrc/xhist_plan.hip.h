@@ -349,6 +349,9 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->force_global = value != 0;
   } else if (!strcmp(key, "force_generic")) {
     p->force_generic = value != 0;
+  } else if (!strcmp(key, "profile_stride")) {
+    p->profile_stride = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20));
+    p->n_seen = 0;
   } else if (!strcmp(key, "fused")) {
     p->fused_pref = value < 0 ? -1 : 0;
   } else if (!strcmp(key, "partition")) {

@@ -28,6 +28,7 @@ struct LaunchRecord {
   int begin(int profile) {
     if (!profile) return XHIST_OK;
     std::lock_guard<std::mutex> lk(p->mu);
+    if (p->profile_stride > 1 && (p->n_seen++ % p->profile_stride) != 0) return XHIST_OK;  // this execute is not sampled
     slot = (int)(p->n_recorded % profile);
     HIPC(hipEventRecord(p->ring[(size_t)slot].first, stream));
     return XHIST_OK;
