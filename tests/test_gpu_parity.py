@@ -1535,3 +1535,36 @@ def test_table_columns_with_many_bins_are_gathered_into_rows(xh, resident):
                 got = got.cpu().numpy() if resident else got
                 want, _ = onp.histogram(np.ascontiguousarray(view), bins=e, axis=0, weights=None if wv is None else np.ascontiguousarray(wv))
                 assert_hist_equal(got, want, weighted=wv is not None)
+
+
+def test_one_pass_routing_with_few_partitions_and_many_tiles(xh):
+    """3 partitions, 1024-record chunks, ~40 tiles per workgroup: every tile asks the workgroup's id stock for several
+    chunks per partition (found by tools/soak.py: the pool was once sized without the ids a stock range drops when it
+    runs out — a memory fault).  Exact against the three-pass route (an independent implementation) and the in-range count."""
+    from xhistogram_amd import _native
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    n = 120_000_000
+    a = [torch.empty(n, dtype=torch.float32, device=dev).normal_(generator=g) for _ in range(3)]
+    edges = [np.linspace(-3, 3, 48), np.linspace(-3, 3, 18) ** 3 / 9.0, np.linspace(-3, 3, 101)]
+    plan = xh._get_plan(edges, _native.CMP_F64, 0)
+    plan.set_param("partition", 1)  # (left alone, 12 B/sample and 2 bin slices would win the cost model)
+    try:
+        h, _ = xh.histogram(*a, bins=edges)
+        assert "route=fused" in plan.describe() and "parts=3" in plan.describe(), plan.describe()
+        plan.set_param("fused", -1)
+        h3, _ = xh.histogram(*a, bins=edges)
+        assert "route=fused" not in plan.describe() and "partitioned" in plan.describe(), plan.describe()
+    finally:
+        plan.set_param("fused", 0)
+        plan.set_param("partition", 0)
+    assert torch.equal(h, h3)
+    inside = torch.ones(n, dtype=torch.bool, device=dev)
+    for x, e in zip(a, edges):
+        inside &= (x >= float(e[0])) & (x <= float(e[-1]))
+    assert int(h.sum()) == int(inside.sum())
+    m = 1_000_000
+    hp, _ = xh.histogram(*[x[:m] for x in a], bins=edges)
+    np.testing.assert_array_equal(hp.cpu().numpy(), onp.histogram(*[x[:m].cpu().numpy() for x in a], bins=edges)[0])

@@ -13,6 +13,7 @@ import torch
 from oracle import oracle_np as onp
 from xhistogram_amd import core
 
+trace = open(os.environ["SOAK_TRACE"], "w") if os.environ.get("SOAK_TRACE") else None
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big_cols = int(sys.argv[3]) if len(sys.argv) > 3 else 200_000  # upper bound of the last axis in the "big" third of the cases
@@ -41,15 +42,18 @@ def one(seed):
         shape = tuple(rng.permutation(shape))
     d = int(rng.choice([1, 1, 1, 2, 2, 3]))
     dtype = rng.choice(["f64", "f32", "i32", "i64", "u8", "f16"])
-    kinds = ["int" if dtype in ("i32", "i64", "u8") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "geom"])) for _ in range(d)]
+    # a third of the joint histograms mix dtypes (the mixed-dtype vector kernels / the generic family)
+    dtypes = [str(rng.choice(["f64", "f32", "i32", "i16", "u8", "f16"])) if (d > 1 and rng.random() < 0.35) else str(dtype) for _ in range(d)]
+    kinds = ["int" if dt in ("i32", "i64", "u8", "i16") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "geom"])) for dt in dtypes]
     nbmax = {1: 70_000, 2: 400, 3: 50}[d]
     nbs = [int(rng.choice([1, 3, 17, 100, int(rng.integers(1, nbmax))])) for _ in range(d)]
     edges = [edges_for(rng, k, nb) for k, nb in zip(kinds, nbs)]
-    npdt = {"f64": np.float64, "f32": np.float32, "i32": np.int32, "i64": np.int64, "u8": np.uint8, "f16": np.float16}[dtype]
+    npdts = {"f64": np.float64, "f32": np.float32, "i32": np.int32, "i64": np.int64, "u8": np.uint8, "f16": np.float16, "i16": np.int16}
     args = []
-    for _ in range(d):
+    for dt in dtypes:
+        npdt = npdts[dt]
         a = rng.standard_normal(shape) * 2
-        if npdt in (np.int32, np.int64):
+        if npdt in (np.int32, np.int64, np.int16):
             a = np.round(a * 20)
         elif npdt == np.uint8:
             a = np.abs(np.round(a * 20)) % 256
@@ -62,7 +66,10 @@ def one(seed):
     wkind = rng.choice(["none", "none", "full", "bcast", "scalar"])
     w = None
     if wkind == "full":
-        w = rng.uniform(-1, 2, shape).astype(rng.choice([np.float64, np.float32]))
+        wdt = rng.choice(["f64", "f64", "f32", "i32", "bool", "f16"])
+        w = rng.uniform(-1, 2, shape)
+        w = {"f64": lambda v: v, "f32": lambda v: v.astype(np.float32), "i32": lambda v: np.round(v * 4).astype(np.int32),
+             "bool": lambda v: v > 0.5, "f16": lambda v: v.astype(np.float16)}[str(wdt)](w)
     elif wkind == "bcast":
         wshape = tuple(n if rng.random() < 0.5 else 1 for n in shape)
         w = rng.uniform(0, 2, wshape)
@@ -73,9 +80,9 @@ def one(seed):
         return None  # keep outputs (and the oracle's temporaries) small
     density = bool(rng.random() < 0.25)
     resident = bool(rng.random() < 0.6) and not any(a.dtype == np.float16 and False for a in args)
-    two = w is not None and rng.random() < 0.25 and not density
+    two = w is not None and w.dtype.kind == "f" and w.dtype.itemsize >= 4 and rng.random() < 0.25 and not density
     bins = edges if d > 1 else edges[0]
-    desc = dict(seed=seed, shape=shape, d=d, dtype=dtype, kinds=kinds, nbs=nbs, axis=axis, wkind=wkind, density=density, resident=resident, two=two)
+    desc = dict(seed=seed, shape=shape, d=d, dtype=dtypes, wdtype=None if w is None else str(w.dtype), kinds=kinds, nbs=nbs, axis=axis, wkind=wkind, density=density, resident=resident, two=two)
     try:
         want = onp.histogram(*args, bins=bins, weights=w, axis=axis, density=density)[0]
     except (NotImplementedError, TypeError, ValueError):
@@ -85,7 +92,7 @@ def one(seed):
     plan, override = None, None
     if rng.random() < 0.5:
         override = [("partition", 1), ("slices", 1), ("arith", 1), ("lanes", 1), ("lanes", -1), ("force_generic", 1), ("force_global", 1),
-                    ("lds_copies", 1), ("slices", -1), ("arith", -1)][int(rng.integers(0, 10))]
+                    ("lds_copies", 1), ("slices", -1), ("arith", -1), ("fused", -1), ("partition", 1)][int(rng.integers(0, 12))]
         try:
             dom, cedges, _ = core._compare_domain([a.dtype for a in args], edges)
             plan = core._get_plan(cedges, dom, 0)
@@ -93,6 +100,9 @@ def one(seed):
         except (NotImplementedError, TypeError):
             plan = None
     desc["override"] = override
+    if trace:
+        trace.write("  %r\n" % (desc,))
+        trace.flush()
     try:
         return _compare(args, bins, w, axis, density, resident, two, conv, want, desc, rng)
     finally:
@@ -128,7 +138,12 @@ t0 = time.time()
 n = 0
 seed = seed0
 while time.time() - t0 < budget:
+    if trace:  # a GPU memory fault kills the process: the last seed written is the culprit (or the one before it)
+        trace.write("%d\n" % seed)
+        trace.flush()
     bad = one(seed)
+    if trace:
+        torch.cuda.synchronize()
     if bad is not None:
         print("MISMATCH", bad, flush=True)
         sys.exit(1)

@@ -206,9 +206,12 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   int lg = 10;
   while (lg < 14 && ((n_cols / G) >> lg) + 2 * n_parts > kRouteListCap / 2) ++lg;
   const int64_t GP = (int64_t)G * n_parts;
-  // every chunk but the one in use by its (workgroup, partition) owner is full; at most 7 padding records are added
-  // per owner; a workgroup may leave two batches of chunk ids (and a few ids at batch ends) unused
-  const int64_t pool_chunks = ((n_cols + 7 * GP) >> lg) + GP + (int64_t)G * (2 * route_batch(n_parts) + 16) + 2;
+  // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
+  // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
+  // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
+  // and ends with at most two ranges in hand.
+  const int64_t used = ((n_cols + 7 * GP) >> lg) + GP;
+  const int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg) + 2 * route_max_need(lg)) + 64;
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;

@@ -46,7 +46,14 @@ constexpr int kRouteLoads = kRouteTile / (kRouteBlock * 4);  // 4-sample vectors
 constexpr int kRouteListCap = 1024;            // chunks one workgroup can file in its LDS list (beyond: filed one by one, slowly)
 constexpr int kRouteCtl = 18496 + 2 * 4 * kRouteListCap;  // control arrays of part_route (see the kernel)
 constexpr int kAccBatch = 1024;                // chunks a workgroup of part_accumulate_chunks stages at a time
-__host__ __device__ constexpr int route_batch(int P) { return 2 * P; }  // chunk ids a workgroup takes from the pool at a time
+// most chunks one partition can need for ONE tile (every record of the tile, plus padding, minus what its chunk still holds)
+__host__ __device__ constexpr int route_max_need(int chunk_log2) { return ((kRouteTile + 2 * kRouteGrp) >> chunk_log2) + 1; }
+// chunk ids a workgroup takes from the pool at a time: enough for every partition to switch in one tile, and at least
+// eight times the largest single request, so that the ids a range cannot serve any more (fewer than the largest request,
+// dropped when the next range takes over) stay below an eighth of what it handed out
+__host__ __device__ constexpr int route_batch(int P, int chunk_log2) {
+  return 2 * P > 8 * route_max_need(chunk_log2) ? 2 * P : 8 * route_max_need(chunk_log2);
+}
 
 struct RouteArgs {
   uint32_t* pool;       // [0]: next unused chunk id
@@ -55,7 +62,7 @@ struct RouteArgs {
   uint32_t* cmeta;      // [pool_chunks]: partition << 20 | fill, written once when a chunk is closed
   uint16_t* codes;      // [pool_chunks << chunk_log2]: bin index inside the partition
   void* wrec;           // [pool_chunks << chunk_log2]: weight (float64, or float32 for float32 weights)
-  uint32_t list_cap;
+  uint32_t list_cap;    // = chunks in the pool
   int32_t chunk_log2;
 };
 
@@ -152,7 +159,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
 #pragma unroll
   for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
   const uint32_t code_mask = (1u << shift) - 1u;
-  const uint32_t batch = (uint32_t)route_batch(P);
+  const uint32_t batch = (uint32_t)route_batch(P, lg), max_need = (uint32_t)route_max_need(lg);
   for (int i = tid; i < 256; i += blockDim.x) {
     cnt2[i] = 0u;
     cnt2[256 + i] = 0u;
@@ -304,6 +311,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
           if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
           uint32_t id0 = route_take_ids(stock, need);
           if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, need);  // stock used up (a burst of switches): costs a stall
+          if (id0 + need > ra.list_cap) __builtin_trap();          // cannot happen (the pool is sized for the worst case): fail loudly, never write past it
           for (uint32_t i = 0; i < need; ++i) file_chunk(tid, id0 + i);  // consecutive ids: the rest of the block is one run
           for (uint32_t i = 0; i + 1 < need; ++i) ra.cmeta[id0 + i] = ((uint32_t)tid << 20) | CH;
           const uint64_t nb = (uint64_t)id0 << lg;
@@ -399,7 +407,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
         }
         refill_pending = false;
       }
-      if (stock[0] + (uint32_t)(kRouteTile >> lg) + 1u > stock[1] && stock[2] < stock[3]) {
+      if (stock[0] + max_need > stock[1] && stock[2] < stock[3]) {  // the first range can no longer serve the largest request
         stock[0] = stock[2];
         stock[1] = stock[3];
         stock[2] = stock[3] = 0u;
@@ -423,6 +431,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
         if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
         uint32_t id0 = route_take_ids(stock, 1u);
         if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, 1u);
+        if (id0 + 1u > ra.list_cap) __builtin_trap();
         file_chunk(tid, id0);
         cur = (uint64_t)id0 << lg;
         cend = cur + CH;
