@@ -214,3 +214,67 @@ def test_more_than_2_31_elements(xh):
     hw, _ = xh.histogram(x, bins=e, weights=w)
     hwp = sum(xh.histogram(x[a:b], bins=e, weights=w[a:b])[0] for a, b in zip(cuts, cuts[1:]))
     assert float((hw - hwp).abs().max() / hw.abs().max()) < 1e-12
+
+
+@st.composite
+def mixed_cases(draw):
+    """joint histograms whose inputs have DIFFERENT dtypes, weights of any dtype, histograms from a few bins to beyond LDS
+    (the mixed-dtype vector kernels, the generic family, packed / sliced / partitioned modes with their overrides)"""
+    d = draw(st.integers(1, 3))
+    rows = draw(st.integers(1, 4))
+    cols = draw(st.sampled_from([1, 3, 4, 5, 63, 64, 257, 1000, 4096, 20_011]))
+    dtypes = [draw(st.sampled_from([np.float64, np.float32, np.float16, np.int32, np.int16, np.uint8, np.int64])) for _ in range(d)]
+    big = d == 2 and draw(st.booleans())
+    nbs = [draw(st.integers(150, 420)) if big else draw(st.integers(1, 40)) for _ in range(d)]
+    kinds = [draw(st.sampled_from(["uniform", "random"])) for _ in range(d)]
+    wdtype = draw(st.sampled_from([None, None, np.float64, np.float32, np.float16, np.int32, np.bool_, np.uint8]))
+    axis = draw(st.sampled_from([None, 1, 0]))
+    seed = draw(st.integers(0, 2**31 - 1))
+    resident = draw(st.booleans())
+    override = draw(st.sampled_from([None, None, ("force_generic", 1), ("partition", 1), ("fused", -1), ("slices", 1), ("slices", -1), ("arith", 1), ("lanes", -1)]))
+    return d, rows, cols, dtypes, nbs, kinds, wdtype, axis, seed, resident, override
+
+
+@settings(max_examples=250, deadline=None, suppress_health_check=list(HealthCheck))
+@given(mixed_cases())
+def test_mixed_dtypes_and_big_histograms_match_oracle(xh, case):
+    d, rows, cols, dtypes, nbs, kinds, wdtype, axis, seed, resident, override = case
+    rng = np.random.default_rng(seed)
+    args, edges = [], []
+    for dt, nb, kind in zip(dtypes, nbs, kinds):
+        if np.dtype(dt).kind == "f":
+            a = (rng.standard_normal((rows, cols)) * 2).astype(dt)
+            a.reshape(-1)[rng.integers(0, a.size, max(1, a.size // 23))] = rng.choice([np.nan, np.inf, -np.inf, 3.0, -3.0])
+            lo, hi = -3.0, 3.0
+        elif dt == np.uint8:
+            a = rng.integers(0, 256, (rows, cols)).astype(dt)
+            lo, hi = 10.0, 250.0
+        else:
+            a = rng.integers(-60, 61, (rows, cols)).astype(dt)
+            lo, hi = -50.0, 50.0
+        args.append(a)
+        e = np.linspace(lo, hi, nb + 1) if kind == "uniform" else np.sort(np.concatenate([[lo, hi], rng.uniform(lo, hi, nb - 1)]))
+        edges.append(e)
+    w = None
+    if wdtype is not None:
+        w = rng.uniform(0, 3, (rows, cols))
+        w = (w > 1.5) if wdtype == np.bool_ else (np.round(w * 3).astype(wdtype) if np.dtype(wdtype).kind in "iu" else w.astype(wdtype))
+    kw = dict(bins=edges if d > 1 else edges[0], axis=axis)
+    want, _ = onp.histogram(*args, weights=w, **kw)
+    if resident:
+        targs = [torch.as_tensor(a).cuda() for a in args]
+        tw = None if w is None else torch.as_tensor(w).cuda()
+    else:
+        targs, tw = args, w
+    plan = None
+    if override:
+        dom, conv, _ = xh._compare_domain([np.dtype(np.float64)] * d if False else [xh._np_dtype_of(a) for a in targs], edges)
+        plan = xh._get_plan(conv, dom, 0)
+        plan.set_param(*override)
+    try:
+        got, _ = xh.histogram(*targs, weights=tw, **kw)
+    finally:
+        if plan is not None:
+            plan.set_param(override[0], 0)
+    got = got.cpu().numpy() if resident else got
+    assert_hist_equal(got, want, weighted=w is not None)
