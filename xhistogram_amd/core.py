@@ -109,6 +109,7 @@ def _np_dtype_of(a):
 _plans = OrderedDict()
 _areas = OrderedDict()  # device-resident bin areas of the density epilogue, per set of edges
 _plans_lock = threading.Lock()
+_plan_create_lock = threading.Lock()
 _PLAN_CACHE = 32
 
 
@@ -119,11 +120,17 @@ def _get_plan(edges, cmp_domain, device):
         if plan is not None:
             _plans.move_to_end(key)
             return plan
-    plan = _native.Plan(edges, cmp_domain, device)
-    with _plans_lock:
-        _plans[key] = plan
-        while len(_plans) > _PLAN_CACHE:
-            _plans.popitem(last=False)
+    # one creation at a time (and no duplicates): building the tables costs a launch and a device synchronisation, and
+    # dask's threaded scheduler sends every block of a fresh graph here at once
+    with _plan_create_lock:
+        with _plans_lock:
+            plan = _plans.get(key)
+        if plan is None:
+            plan = _native.Plan(edges, cmp_domain, device)
+            with _plans_lock:
+                _plans[key] = plan
+                while len(_plans) > _PLAN_CACHE:
+                    _plans.popitem(last=False)
     return plan
 
 

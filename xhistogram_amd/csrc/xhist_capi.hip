@@ -33,8 +33,8 @@ struct Staged {
   size_t cap = 0;
 };
 
-static void stage_free(Staged& st, hipStream_t stream) {
-  if (st.dptr) (void)hipFreeAsync(st.dptr, stream);
+static void stage_free(Staged& st, hipStream_t stream, bool synced = false) {
+  if (st.dptr) (void)scratch_free(st.dptr, stream, synced);
   st.dptr = nullptr;
   st.cap = 0;
 }
@@ -49,7 +49,7 @@ static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0,
     const size_t need = (size_t)nr * nc * es;
     if (need > st.cap) {
       stage_free(st, stream);
-      HIPC(hipMallocAsync(&st.dptr, need, stream));
+      HIPC(scratch_malloc(&st.dptr, need, stream));
       st.cap = need;
     }
     const char* src = static_cast<const char*>(a.data) + (r0 + c0 * a.col_stride) * es;
@@ -76,7 +76,7 @@ static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0,
   const size_t need = (size_t)rows * cols * es;
   if (need > st.cap) {
     stage_free(st, stream);
-    HIPC(hipMallocAsync(&st.dptr, need, stream));
+    HIPC(scratch_malloc(&st.dptr, need, stream));
     st.cap = need;
   }
   const char* src = static_cast<const char*>(a.data) + ((a.row_stride ? r0 * a.row_stride : 0) + (a.col_stride ? c0 : 0)) * es;
@@ -108,12 +108,13 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
   void* d_out = nullptr;
   Staged st[kMaxDims + 1];
   int rc = XHIST_OK;
+  bool synced = false;  // the stream has been waited for since the scratch was last used: no event needed to recycle it
   auto done = [&](int code) {
-    for (auto& s : st) stage_free(s, stream);
-    if (d_out) (void)hipFreeAsync(d_out, stream);
+    for (auto& s : st) stage_free(s, stream, synced);
+    if (d_out) (void)scratch_free(d_out, stream, synced);
     return code;
   };
-  if (hipMallocAsync(&d_out, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
+  if (scratch_malloc(&d_out, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
   if (int zrc = zero_output(d_out, out_elems, stream)) return done(zrc);
 
   // views with grouped rows (reduced axes between kept axes) are staged whole, strides intact:
@@ -134,7 +135,7 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
       const int64_t extent = roff + (n_cols - 1) * a.col_stride + 1;
       if (extent > ((int64_t)1 << 32)) { rc = fail(XHIST_ERR_UNSUPPORTED, "grouped host view spans more than 2^32 elements"); break; }
       Staged& s = st[d < D ? d : kMaxDims];
-      if (hipMallocAsync(&s.dptr, (size_t)extent * es, stream) != hipSuccess) { rc = fail(XHIST_ERR_NOMEM, "allocation of a staging buffer failed"); break; }
+      if (scratch_malloc(&s.dptr, (size_t)extent * es, stream) != hipSuccess) { rc = fail(XHIST_ERR_NOMEM, "allocation of a staging buffer failed"); break; }
       s.cap = (size_t)extent * es;
       if (hipMemcpyAsync(s.dptr, a.data, (size_t)extent * es, hipMemcpyHostToDevice, stream) != hipSuccess) {
         rc = fail(XHIST_ERR_HIP, "host to device copy failed");
@@ -163,16 +164,18 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
       // the staging buffers are reused by the next chunk: same-stream ordering makes that safe
     }
   }
-  if (rc != XHIST_OK) { (void)hipStreamSynchronize(stream); return done(rc); }
+  if (rc != XHIST_OK) { synced = hipStreamSynchronize(stream) == hipSuccess; return done(rc); }
   if (!accumulate) {
     if (hipMemcpyAsync(out, d_out, (size_t)out_elems * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
       return done(fail(XHIST_ERR_HIP, "copy of the result to the host failed: %s", hipGetErrorString(hipGetLastError())));
+    synced = true;
   } else {
     std::vector<uint64_t> tmp((size_t)out_elems);
     if (hipMemcpyAsync(tmp.data(), d_out, (size_t)out_elems * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
       return done(fail(XHIST_ERR_HIP, "copy of the result to the host failed: %s", hipGetErrorString(hipGetLastError())));
+    synced = true;
     if (weights) {
       double* o = static_cast<double*>(out);
       const double* t = reinterpret_cast<const double*>(tmp.data());
@@ -201,7 +204,8 @@ extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, con
   // threaded scheduler runs many blocks at once — then overlap one block's staging copy with another
   // block's kernel instead of queueing behind each other.
   Range r("xhist_plan_execute[host: stage + bin]");
-  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s ? s : hipStreamPerThread);
+  static const bool null_stream = [] { const char* e = getenv("XHIST_AMD_HOST_STREAM"); return e && !strcmp(e, "null"); }();
+  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s ? s : (null_stream ? nullptr : hipStreamPerThread));
 }
 
 extern "C" int xhist_plan_execute_two_weights(xhist_plan* p, const xhist_array* samples, const xhist_array* weights_a,
@@ -270,7 +274,7 @@ extern "C" int xhist_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_cache.clear();
   }
-  trim_pools();  // scratch kept in the stream-ordered pools goes back to the driver
+  trim_pools();  // cached scratch goes back to the driver
   return XHIST_OK;
 }
 
@@ -343,7 +347,6 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
   if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available; this library has no CPU path", device);
   DeviceGuard g;
   if (int rc = g.set(device)) return rc;
-  keep_pool_warm(device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   Staged st;
   xhist_array view = *a;
@@ -354,11 +357,11 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
   const int grid = 1024;
   double* d_part = nullptr;
   auto done = [&](int code) {
-    if (d_part) (void)hipFreeAsync(d_part, s);
+    if (d_part) (void)scratch_free(d_part, s);
     stage_free(st, s);
     return code;
   };
-  if (hipMallocAsync((void**)&d_part, sizeof(double) * 3 * grid, s) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "device allocation failed"));
+  if (scratch_malloc((void**)&d_part, sizeof(double) * 3 * grid, s) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "device allocation failed"));
   // contiguous float data (the usual `bins=int` on a whole array): the vectorised kernel
   const bool flat = (view.dtype == XHIST_F64 || view.dtype == XHIST_F32) && view.inner_rows == 0 && (n_cols == 1 || view.col_stride == 1) &&
                     (n_rows == 1 || view.row_stride == n_cols) && ((uintptr_t)view.data % (size_t)dtype_size(view.dtype)) == 0;

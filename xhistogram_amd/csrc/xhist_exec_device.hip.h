@@ -88,12 +88,12 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
   void* d_w = nullptr;  // record weights: float64, or float32 when the caller's weights are
   uint32_t* d_flat = nullptr;
   auto release = [&](int rc) {
-    if (d_flat) (void)hipFreeAsync(d_flat, stream);
-    if (d_counts) (void)hipFreeAsync(d_counts, stream);
-    if (d_base) (void)hipFreeAsync(d_base, stream);
-    if (d_offsets) (void)hipFreeAsync(d_offsets, stream);
-    if (d_codes) (void)hipFreeAsync(d_codes, stream);
-    if (d_w) (void)hipFreeAsync(d_w, stream);
+    if (d_flat) (void)scratch_free(d_flat, stream);
+    if (d_counts) (void)scratch_free(d_counts, stream);
+    if (d_base) (void)scratch_free(d_base, stream);
+    if (d_offsets) (void)scratch_free(d_offsets, stream);
+    if (d_codes) (void)scratch_free(d_codes, stream);
+    if (d_w) (void)scratch_free(d_w, stream);
     return rc;
   };
 #define HIPR(expr)                                                                                     \
@@ -101,14 +101,14 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
     hipError_t e_ = (expr);                                                                            \
     if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
   } while (0)
-  HIPR(hipMallocAsync((void**)&d_counts, (size_t)G * n_parts * 4, stream));
-  HIPR(hipMallocAsync((void**)&d_base, (size_t)G * n_parts * 8, stream));
-  HIPR(hipMallocAsync((void**)&d_offsets, (size_t)(n_parts + 1) * 8, stream));
-  HIPR(hipMallocAsync((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
+  HIPR(scratch_malloc((void**)&d_counts, (size_t)G * n_parts * 4, stream));
+  HIPR(scratch_malloc((void**)&d_base, (size_t)G * n_parts * 8, stream));
+  HIPR(scratch_malloc((void**)&d_offsets, (size_t)(n_parts + 1) * 8, stream));
+  HIPR(scratch_malloc((void**)&d_flat, (size_t)n_tiles * kPartTile * 4, stream));
   const size_t n_rec = (size_t)n_cols + (size_t)G * n_parts * grp;  // every slice rounded up to whole groups
-  HIPR(hipMallocAsync((void**)&d_codes, n_rec * 2 + 16, stream));
+  HIPR(scratch_malloc((void**)&d_codes, n_rec * 2 + 16, stream));
   const bool rec_f32 = wdt == XHIST_F32;
-  if (weighted) HIPR(hipMallocAsync(&d_w, n_rec * (rec_f32 ? 4 : 8) + 16, stream));
+  if (weighted) HIPR(scratch_malloc(&d_w, n_rec * (rec_f32 ? 4 : 8) + 16, stream));
 
   Params kp;
   memset(&kp, 0, sizeof kp);
@@ -218,11 +218,11 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   uint16_t* d_codes = nullptr;
   void* d_w = nullptr;
   auto release = [&](int rc) {
-    if (d_ctr) (void)hipFreeAsync(d_ctr, stream);
-    if (d_plist) (void)hipFreeAsync(d_plist, stream);
-    if (d_cmeta) (void)hipFreeAsync(d_cmeta, stream);
-    if (d_codes) (void)hipFreeAsync(d_codes, stream);
-    if (d_w) (void)hipFreeAsync(d_w, stream);
+    if (d_ctr) (void)scratch_free(d_ctr, stream);
+    if (d_plist) (void)scratch_free(d_plist, stream);
+    if (d_cmeta) (void)scratch_free(d_cmeta, stream);
+    if (d_codes) (void)scratch_free(d_codes, stream);
+    if (d_w) (void)scratch_free(d_w, stream);
     return rc;
   };
 #define HIPR(expr)                                                                                     \
@@ -231,11 +231,11 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
   } while (0)
   const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [2 .. 2 + P) chunks filed per partition
-  HIPR(hipMallocAsync((void**)&d_ctr, (size_t)ctr_words * 8, stream));
-  HIPR(hipMallocAsync((void**)&d_plist, (size_t)n_parts * pool_chunks * 4, stream));
-  HIPR(hipMallocAsync((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
-  HIPR(hipMallocAsync((void**)&d_codes, ((size_t)pool_chunks << lg) * 2, stream));
-  if (weighted) HIPR(hipMallocAsync(&d_w, ((size_t)pool_chunks << lg) * (rec_f32 ? 4 : 8), stream));
+  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8, stream));
+  HIPR(scratch_malloc((void**)&d_plist, (size_t)n_parts * pool_chunks * 4, stream));
+  HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
+  HIPR(scratch_malloc((void**)&d_codes, ((size_t)pool_chunks << lg) * 2, stream));
+  if (weighted) HIPR(scratch_malloc(&d_w, ((size_t)pool_chunks << lg) * (rec_f32 ? 4 : 8), stream));
 
   Params kp;
   memset(&kp, 0, sizeof kp);
@@ -405,7 +405,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   void* scratch[kMaxDims + 1] = {nullptr};
   auto release = [&](int rc) {
     for (auto s : scratch)
-      if (s) (void)hipFreeAsync(s, stream);
+      if (s) (void)scratch_free(s, stream);
     return rc;
   };
 #define HIPL(expr)                                                                                     \
@@ -427,7 +427,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     if (transpose && rs != 0 && cs != 0) {
       ir = os = 0;
       const int es = dtype_size(a.dtype);
-      HIPL(hipMallocAsync(&scratch[d], (size_t)n_rows * n_cols * es, stream));
+      HIPL(scratch_malloc(&scratch[d], (size_t)n_rows * n_cols * es, stream));
       const dim3 grid((unsigned)((n_rows + 63) / 64), (unsigned)((n_cols + 63) / 64));
       if (es == 8)
         hipLaunchKernelGGL(transpose_2d<double>, grid, dim3(256), 0, stream, (const double*)a.data, rs, n_rows, n_cols, (double*)scratch[d]);
@@ -575,7 +575,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         if (d == D && !weighted) break;
         const xhist_array& a = d < D ? samples[d] : *weights;
         const int es = dtype_size(a.dtype);
-        if (hipMallocAsync(&scratch[d], (size_t)n_rows * n_cols * es, stream) != hipSuccess) {
+        if (scratch_malloc(&scratch[d], (size_t)n_rows * n_cols * es, stream) != hipSuccess) {
           (void)hipGetLastError();
           rc = fail(XHIST_ERR_NOMEM, "allocation of %lld bytes of gather scratch failed", (long long)n_rows * n_cols * es);
           break;
@@ -603,7 +603,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       }
       if (rc == XHIST_OK) rc = execute_device(p, dense, weighted ? &dense_w : nullptr, n_rows, n_cols, out, accumulate, stream);
       for (auto* sc : scratch)
-        if (sc) (void)hipFreeAsync(sc, stream);
+        if (sc) (void)scratch_free(sc, stream);
       return rc;
     }
   }

@@ -86,44 +86,177 @@ static int n_devices() {
   return n;
 }
 
-// Scratch (staging of host inputs, the partitioned mode's record streams, transposes) comes from the device's
-// stream-ordered pool, so concurrent callers never share it.  By default that pool gives everything back to
-// the driver at the next synchronisation and the following call pays for fresh allocations: 100 us of a
-// 465 us numpy call of 10^6 samples — and 1.1 to 1.6 SECONDS per call for the 56 GB of record streams of
-// C5 at 4*10^9 samples, against 40 ms of kernels (profiles/r02_c_alloc_probe.jsonl).  So the pool keeps what
-// it was given, up to half of the device's memory ($XHIST_AMD_POOL_KEEP_GB overrides; xhist_shutdown trims).
-static std::mutex g_pool_mu;
-static bool g_pool_done[64] = {false};
+// ------------------------------------------------------------------------------------------
+// Scratch memory (staging of host inputs, the partitioned mode's record streams, transposes, gathers): a caching
+// allocator of the library's own on top of hipMalloc, with stream-ordered reuse.
+//
+// Why not hipMallocAsync: (1) the device's stream-ordered pool returns everything to the driver at the next
+// synchronisation unless its release threshold is raised — 100 us of a 465 us numpy call of 10^6 samples, and 1.1-1.6 s
+// per call for the 56 GB of record streams of C5 at 4*10^9 samples against 40 ms of kernels
+// (profiles/r02_c_alloc_probe.jsonl); (2) with ROCm 7.0 it is not safe next to plain hipMalloc / hipFree calls of OTHER
+// threads: host-route calls (hipMallocAsync'ed staging) running while another thread creates a plan, or merely
+// allocates and frees device memory, came back with a sample in the wrong bin about once in 10^4 calls
+// (tools/race_probe.py, profiles/r02_n_race_probe.txt; 0 in 7*10^4 without the other thread, 0 in 7*10^4 for
+// device-resident calls, which allocate nothing) — found as a flaky dask test: the threaded scheduler creates the plan
+// of a fresh graph while other blocks are already running.
+//
+// A block freed on a stream is reusable on that stream at once, on other streams once an event recorded at the free
+// has completed.  Freed blocks are kept (up to half of the device's memory, $XHIST_AMD_POOL_KEEP_GB overrides) and
+// handed back to the driver beyond that, or by xhist_shutdown.
+// ------------------------------------------------------------------------------------------
+struct ScratchBlock {
+  void* ptr = nullptr;
+  size_t size = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;  // last used on
+  uint64_t owner = 0;            // (hipStreamPerThread names a different stream in every thread)
+  hipEvent_t ev = nullptr;
+  bool pending = false;          // `ev` marks the point on `stream` after which the block is free
+};
+static std::mutex g_sc_mu;
+static std::vector<ScratchBlock> g_sc_free;
+static std::map<void*, ScratchBlock> g_sc_live;
+static uint64_t g_sc_cached[64] = {0}, g_sc_limit[64] = {0};
 
-static void keep_pool_warm(int device) {
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  if (device < 0 || device >= 64 || g_pool_done[device]) return;
-  g_pool_done[device] = true;
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess) return;
-  size_t free_b = 0, total_b = 0;
-  uint64_t want = (uint64_t)2 << 30;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) want = std::max<uint64_t>(want, (uint64_t)total_b / 2);
-  if (const char* env = getenv("XHIST_AMD_POOL_KEEP_GB")) {
-    const double gb = atof(env);
-    if (gb >= 0) want = (uint64_t)(gb * 1073741824.0);
-  }
-  uint64_t cur = 0;
-  if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur >= want) return;
-  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want);
+static uint64_t scratch_owner(hipStream_t s) {
+  static thread_local char key;
+  return s == hipStreamPerThread ? (uint64_t)(uintptr_t)&key : 0;
 }
 
-static void trim_pools() {
-  std::lock_guard<std::mutex> lk(g_pool_mu);
+static size_t scratch_round(size_t b) {  // size classes 1/8 apart: a cached block serves requests close to its size
+  if (b < 4096) return 4096;
+  size_t step = (size_t)1 << 9;
+  while ((step << 4) <= b) step <<= 1;
+  return (b + step - 1) / step * step;
+}
+
+static uint64_t scratch_limit(int device) {  // call with g_sc_mu held and `device` current
+  if (device < 0 || device >= 64) return (uint64_t)2 << 30;
+  if (!g_sc_limit[device]) {
+    size_t free_b = 0, total_b = 0;
+    uint64_t want = (uint64_t)2 << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) want = std::max<uint64_t>(want, (uint64_t)total_b / 2);
+    if (const char* env = getenv("XHIST_AMD_POOL_KEEP_GB")) {
+      const double gb = atof(env);
+      if (gb >= 0) want = (uint64_t)(gb * 1073741824.0) + 1;
+    }
+    g_sc_limit[device] = want;
+  }
+  return g_sc_limit[device];
+}
+
+// give cached blocks of `device` back to the driver until at most `keep` bytes stay (blocks still in flight are skipped
+// unless `sync`, which waits for the device first); g_sc_mu held, `device` current
+static void scratch_evict(int device, uint64_t keep, bool sync) {
+  if (sync) (void)hipDeviceSynchronize();
+  while (device >= 0 && device < 64 && g_sc_cached[device] > keep) {
+    int best = -1;
+    for (int i = 0; i < (int)g_sc_free.size(); ++i) {
+      ScratchBlock& b = g_sc_free[(size_t)i];
+      if (b.device != device) continue;
+      if (b.pending && !sync && hipEventQuery(b.ev) != hipSuccess) continue;
+      if (best < 0 || b.size > g_sc_free[(size_t)best].size) best = i;
+    }
+    if (best < 0) break;
+    ScratchBlock b = g_sc_free[(size_t)best];
+    g_sc_free.erase(g_sc_free.begin() + best);
+    g_sc_cached[device] -= b.size;
+    if (b.ev) (void)hipEventDestroy(b.ev);
+    (void)hipFree(b.ptr);
+  }
+}
+
+// same shape as hipMallocAsync / hipFreeAsync; the device the caller made current is the block's device
+static bool scratch_use_hip_pool() {  // A/B switch for measurements only (the HIP pool is the unsafe one, see above)
+  static const bool on = [] { const char* e = getenv("XHIST_AMD_SCRATCH"); return e && !strcmp(e, "hip-pool"); }();
+  return on;
+}
+
+static hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t stream) {
+  if (scratch_use_hip_pool()) return hipMallocAsync(out, bytes, stream);
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
+  const size_t want = scratch_round(bytes);
+  const uint64_t owner = scratch_owner(stream);
+  {
+    std::lock_guard<std::mutex> lk(g_sc_mu);
+    const size_t slack = std::max<size_t>(want / 4, (size_t)1 << 20);
+    int best = -1;
+    for (int i = 0; i < (int)g_sc_free.size(); ++i) {
+      ScratchBlock& b = g_sc_free[(size_t)i];
+      if (b.device != device || b.size < want || b.size > want + slack) continue;
+      bool ok = !b.pending || (b.stream == stream && b.owner == owner);
+      if (!ok && hipEventQuery(b.ev) == hipSuccess) {
+        b.pending = false;
+        ok = true;
+      }
+      if (ok && (best < 0 || b.size < g_sc_free[(size_t)best].size)) best = i;
+    }
+    if (best >= 0) {
+      ScratchBlock b = g_sc_free[(size_t)best];
+      g_sc_free.erase(g_sc_free.begin() + best);
+      if (device < 64) g_sc_cached[device] -= b.size;
+      g_sc_live[b.ptr] = b;
+      *out = b.ptr;
+      return hipSuccess;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {  // out of memory: everything cached goes back first
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(g_sc_mu);
+      scratch_evict(device, 0, true);
+    }
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+  }
+  ScratchBlock b;
+  b.ptr = p;
+  b.size = want;
+  b.device = device;
+  std::lock_guard<std::mutex> lk(g_sc_mu);
+  g_sc_live[p] = b;
+  *out = p;
+  return hipSuccess;
+}
+
+// synced: the caller has synchronised `stream` since the block's last use (no event needed)
+static hipError_t scratch_free(void* p, hipStream_t stream, bool synced = false) {
+  if (!p) return hipSuccess;
+  if (scratch_use_hip_pool()) return hipFreeAsync(p, stream);
+  std::lock_guard<std::mutex> lk(g_sc_mu);
+  auto it = g_sc_live.find(p);
+  if (it == g_sc_live.end()) return hipErrorInvalidValue;
+  ScratchBlock b = it->second;
+  g_sc_live.erase(it);
+  b.stream = stream;
+  b.owner = scratch_owner(stream);
+  b.pending = false;
+  if (!synced) {
+    if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) b.ev = nullptr;
+    if (b.ev && hipEventRecord(b.ev, stream) == hipSuccess) {
+      b.pending = true;
+    } else {  // no event to wait on: wait now
+      (void)hipStreamSynchronize(stream);
+    }
+  }
+  g_sc_free.push_back(b);
+  if (b.device >= 0 && b.device < 64) {
+    g_sc_cached[b.device] += b.size;
+    if (g_sc_cached[b.device] > scratch_limit(b.device)) scratch_evict(b.device, scratch_limit(b.device), false);
+  }
+  return hipSuccess;
+}
+
+static void trim_pools() {  // xhist_shutdown: every cached block of every device goes back to the driver
+  std::lock_guard<std::mutex> lk(g_sc_mu);
   int prev = -1;
   if (hipGetDevice(&prev) != hipSuccess) return;
   for (int d = 0; d < 64; ++d) {
-    if (!g_pool_done[d]) continue;
-    hipMemPool_t pool;
-    if (hipSetDevice(d) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess) {
-      (void)hipDeviceSynchronize();
-      (void)hipMemPoolTrimTo(pool, 0);
-    }
+    if (!g_sc_cached[d]) continue;
+    if (hipSetDevice(d) == hipSuccess) scratch_evict(d, 0, true);
   }
   (void)hipSetDevice(prev);
 }

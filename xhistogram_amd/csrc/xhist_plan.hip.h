@@ -197,7 +197,6 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
                 n_devices());
   DeviceGuard g;
   if (int rc = g.set(device)) return rc;
-  keep_pool_warm(device);
 
   xhist_plan* p = new (std::nothrow) xhist_plan();
   if (!p) return fail(XHIST_ERR_NOMEM, "out of host memory");
