@@ -135,5 +135,51 @@ def spread():
     print("SPREAD-OK")
 
 
+def soak():
+    """randomised dask cases on the GPU under the threaded scheduler (the reference's test_chunking_hypotheses.py idea:
+    random shapes, chunkings — aligned or not between the arguments —, axes, weights, density) against numpy.  Fresh
+    edges in every case, so the plan of each graph is created while its first blocks are already running."""
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    for case in range(n_cases):
+        ndim = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(1, 9)) for _ in range(ndim - 1)) + (int(rng.integers(1, 400)),)
+        d = int(rng.integers(1, 3))
+        args = [rng.standard_normal(shape) for _ in range(d)]
+        if args[0].size > 5:
+            args[0].reshape(-1)[rng.integers(0, args[0].size, 2)] = [np.nan, 7.0]
+        edges = [np.sort(rng.uniform(-3, 3, int(rng.integers(2, 30)))) if rng.random() < 0.5 else np.linspace(-3, 3 + 1e-3 * case, int(rng.integers(2, 30)))
+                 for _ in range(d)]
+        chunk = lambda: tuple(int(rng.integers(1, n + 1)) for n in shape)
+        dargs = [dsa.from_array(a, chunks=chunk()) for a in args]
+        w = rng.uniform(0, 2, shape) if rng.random() < 0.5 else None
+        dw = None if w is None else dsa.from_array(w, chunks=chunk())
+        axes = [None] + [tuple(c) for r in range(1, ndim + 1) for c in combinations(range(ndim), r)]
+        axis = axes[int(rng.integers(0, len(axes)))]
+        density = bool(rng.random() < 0.3)
+        bins = edges if d > 1 else edges[0]
+        h, _ = histogram(*dargs, bins=bins, axis=axis, weights=dw, density=density)
+        got = h.compute(scheduler="threads")
+        ax = tuple(range(ndim)) if axis is None else axis
+        moved = [np.moveaxis(a, ax, tuple(range(-len(ax), 0))).reshape(-1, int(np.prod([shape[i] for i in ax]))) for a in args]
+        wm = None if w is None else np.moveaxis(w, ax, tuple(range(-len(ax), 0))).reshape(moved[0].shape)
+        rows = []
+        for r in range(moved[0].shape[0]):
+            hh = np.histogramdd([m[r] for m in moved], bins=edges, weights=None if wm is None else wm[r], density=False)[0]
+            if density:
+                areas = np.ones(())
+                for e in edges:
+                    areas = np.multiply.outer(areas, np.diff(e))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    hh = hh / areas / hh.sum()
+            rows.append(hh)
+        want = np.stack(rows).reshape(got.shape)
+        if w is None and not density:
+            np.testing.assert_array_equal(got, want, err_msg="case %d" % case)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True, err_msg="case %d" % case)
+    print("SOAK-OK %d" % n_cases)
+
+
 if __name__ == "__main__":
-    {"lazy": lazy, "compute": compute, "spread": spread}[sys.argv[1]]()
+    {"lazy": lazy, "compute": compute, "spread": spread, "soak": soak}[sys.argv[1]]()

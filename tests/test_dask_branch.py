@@ -19,13 +19,13 @@ def _have_dask_python():
 needs = pytest.mark.skipif(not _have_dask_python(), reason="no interpreter with dask in this image")
 
 
-def _run(mode):
+def _run(mode, *extra):
     env = dict(os.environ)
     # conda's python ships an older libstdc++ than libamdhip64 needs: let the system one win
     sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
     if os.path.exists(sys_cxx):
         env["LD_PRELOAD"] = (sys_cxx + ":" + env["LD_PRELOAD"]) if env.get("LD_PRELOAD") else sys_cxx
-    r = subprocess.run([PY39, "-W", "ignore", SCRIPT, mode], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([PY39, "-W", "ignore", SCRIPT, mode] + [str(e) for e in extra], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
 
@@ -44,3 +44,10 @@ def test_dask_blocks_are_spread_over_the_gpus_of_the_node():
 @pytest.mark.gpu
 def test_dask_blocks_compute_on_gpu():
     assert "COMPUTE-OK" in _run("compute")
+
+
+@needs
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_dask_graphs_on_gpu_match_numpy(seed):
+    assert "SOAK-OK" in _run("soak", seed, 40)
