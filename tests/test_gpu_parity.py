@@ -1502,9 +1502,7 @@ def test_mixed_dtype_vector_kernels_against_the_oracle(xh, resident):
             got, desc = _run(xh, samples, edges, w, resident)
             want = onp.bincount_rows(samples, edges, w)
             assert_hist_equal(got, want, weighted=w is not None)
-            if n == 4096 and not (len(samples) == 1 and samples[0].dtype.itemsize == 8):
-                # (rows of 1- / 2-byte elements must be dword-aligned for the vector loads: 70001 is not; one 8-byte
-                #  input with odd weights stays in the generic family, which is faster there)
+            if n == 4096:  # (rows of 1- / 2-byte elements must be dword-aligned for the vector loads: 70001 is not)
                 assert "mixed-dtypes" in desc, desc
             got_g, desc_g = _run(xh, samples, edges, w, True, force_generic=1)
             assert "generic" in desc_g and "mixed" not in desc_g, desc_g

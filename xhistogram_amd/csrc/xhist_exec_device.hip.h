@@ -630,6 +630,10 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     if (fast_ok && weighted) fast_ok = weights->col_stride == 1 && ((uintptr_t)weights->data % (size_t)dtype_size(wdt) == 0);
   }
 
+  if (fast_ok && !i64dom) {  // development switch: send homogeneous float inputs through the mixed-dtype kernels (A/B of the load path)
+    static const bool force_mixed = [] { const char* e = getenv("XHIST_AMD_FORCE_MIXED"); return e && e[0] == '1'; }();
+    if (force_mixed) fast_ok = false;
+  }
   // Mixtures the homogeneous vector kernels do not take — float32 next to float64, integers in a joint histogram,
   // integer / bool / half weights — with unit column strides and the float64 compare domain: the MIXED variant of the
   // vector kernels (four elements per load in each array's own dtype, consumed as float64).  LDS histograms only;
@@ -646,11 +650,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     mixed_ok = true;
     for (int d = 0; d < D && mixed_ok; ++d) mixed_ok = vector_loadable(samples[d]);
     if (mixed_ok && weighted) mixed_ok = vector_loadable(*weights);
-    // measured (tools/mixtures.py, 2 x 10^8 samples): arrays of <= 4-byte elements gain 1.8-3.6 x over the generic family
-    // (float32 + int32 weights 1.06 -> 0.29 ms, int32 x int32 1.17 -> 0.40, uint8 x float32 1.15 -> 0.37); with an 8-byte
-    // array in a joint histogram the two are level (float32 x float64 0.91 -> 0.89), and ONE 8-byte input with odd
-    // weights is better off in the generic family (float64 + int32 weights 0.64 against 0.75)
-    if (mixed_ok && D == 1 && dtype_size(samples[0].dtype) == 8) mixed_ok = false;
+    // measured (tools/mixtures.py, 2 x 10^8 samples, against the generic family): float32 + int32 weights 1.06 -> 0.30 ms,
+    // int32 x int32 1.17 -> 0.40, uint8 x float32 1.15 -> 0.37, float32 x float64 0.91 -> 0.46
   }
 
   // Two attempts: the vector family with its tables, then (if it has no kernel for this
@@ -931,8 +932,11 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     for (int d = 0; d < D; ++d) ssz = std::max<int64_t>(ssz, dtype_size(samples[d].dtype));
     int64_t threads_per_cu = (int64_t)bpc * 256;  // (block is 64..256 here, bpc was sized for 256)
     block = 256;
-    if (!(lane_bytes >= 128 && ssz >= 8 && total_samples * (double)sample_bytes > (double)((int64_t)256 << 20))) {
-      const int64_t per_cu = (ssz >= 8 && scan == 1 && float_samples ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
+    if (mixed || !(lane_bytes >= 128 && ssz >= 8 && total_samples * (double)sample_bytes > (double)((int64_t)256 << 20))) {
+      int64_t per_cu = (ssz >= 8 && scan == 1 && float_samples ? 32 : 64) * 1024 / std::max<int64_t>(lane_bytes, 1);
+      // the mixed-dtype kernels convert after loading and want the whole CU: float32 x float64, 2 x 10^8 samples:
+      // 256 threads per CU 0.88 ms, 512 0.52, 1024 0.44 (tools/mixtures.py)
+      if (mixed) per_cu = 1024;
       threads_per_cu = std::min<int64_t>(1024, std::max<int64_t>(256, per_cu / 256 * 256));
       block = (int)threads_per_cu;
       while (block > 256 && n_rows * (n_cols / ((int64_t)block * vec * kUnroll)) < p->cus / 2) block -= 256;
