@@ -240,3 +240,29 @@ def test_bench_multi_rank_control_flow_selftest(scaling):
     assert len(d[other]["kernel_ms_per_rank"]) == 2
     for key in ("value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert key in d
+
+
+def test_blocks_in_flight_per_gpu_are_bounded():
+    """dask's threaded scheduler runs os.cpu_count() blocks at once; each holds device memory of its own size"""
+    import time
+
+    multigpu.set_devices([0, 1])
+    try:
+        lock, live, worst = threading.Lock(), {}, {}
+
+        def block():
+            with multigpu.block_device() as d:
+                with lock:
+                    live[d] = live.get(d, 0) + 1
+                    worst[d] = max(worst.get(d, 0), live[d])
+                time.sleep(0.01)
+                with lock:
+                    live[d] -= 1
+
+        ts = [threading.Thread(target=block) for _ in range(40)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert sorted(worst) == [0, 1] and max(worst.values()) <= multigpu.MAX_BLOCKS_IN_FLIGHT
+        assert all(v == 0 for v in multigpu._inflight.values())
+    finally:
+        multigpu.set_devices(None)

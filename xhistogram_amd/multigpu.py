@@ -103,16 +103,34 @@ def on_device(device):
         core._tls.device = prev
 
 
+# blocks one GPU stages and bins at a time.  A block holds device memory of its own size while it is in flight and the PCIe link
+# is the bottleneck long before four of them overlap, so more concurrency buys nothing — but dask's threaded scheduler runs
+# os.cpu_count() blocks at once (256 on the test box: 256 x a 1.9 GB C4 chunk would not fit one 288 GB GPU)
+MAX_BLOCKS_IN_FLIGHT = max(1, int(os.environ.get("XHIST_AMD_BLOCKS_IN_FLIGHT", "4")))
+_slot_free = threading.Condition(_lock)
+
+
 def _pick_block_device(devices):
-    """least blocks in flight; ties go round so that a serial scheduler still visits every GPU"""
-    with _lock:
-        n = len(devices)
-        start = _rr[0] % n
-        order = devices[start:] + devices[:start]
-        best = min(order, key=lambda d: _inflight.get(d, 0))
+    """least blocks in flight; ties go round so that a serial scheduler still visits every GPU; waits while every GPU
+    has MAX_BLOCKS_IN_FLIGHT blocks"""
+    with _slot_free:
+        while True:
+            n = len(devices)
+            start = _rr[0] % n
+            order = devices[start:] + devices[:start]
+            best = min(order, key=lambda d: _inflight.get(d, 0))
+            if _inflight.get(best, 0) < MAX_BLOCKS_IN_FLIGHT:
+                break
+            _slot_free.wait()
         _inflight[best] = _inflight.get(best, 0) + 1
         _rr[0] = devices.index(best) + 1
         return best
+
+
+def _release_block_device(dev):
+    with _slot_free:
+        _inflight[dev] -= 1
+        _slot_free.notify()
 
 
 @contextlib.contextmanager
@@ -123,18 +141,12 @@ def block_device():
     if getattr(core._tls, "device", None) is not None:
         yield core._tls.device
         return
-    devices = get_devices()
-    if len(devices) == 1:
-        with on_device(devices[0]) as d:
-            yield d
-        return
-    dev = _pick_block_device(devices)
+    dev = _pick_block_device(get_devices())
     try:
         with on_device(dev) as d:
             yield d
     finally:
-        with _lock:
-            _inflight[dev] -= 1
+        _release_block_device(dev)
 
 
 # ---------------------------------------------------------------------------------------------
