@@ -104,9 +104,9 @@ def on_device(device):
 
 
 # blocks one GPU stages and bins at a time.  A block holds device memory of its own size while it is in flight and the PCIe link
-# is the bottleneck long before four of them overlap, so more concurrency buys nothing — but dask's threaded scheduler runs
+# is the bottleneck before two of them overlap (tools/dask_c4.py: 26-35 GB/s with 1 to 8 in flight, 45 GB/s one at a time), so more concurrency buys nothing — but dask's threaded scheduler runs
 # os.cpu_count() blocks at once (256 on the test box: 256 x a 1.9 GB C4 chunk would not fit one 288 GB GPU)
-MAX_BLOCKS_IN_FLIGHT = max(1, int(os.environ.get("XHIST_AMD_BLOCKS_IN_FLIGHT", "4")))
+MAX_BLOCKS_IN_FLIGHT = max(1, int(os.environ.get("XHIST_AMD_BLOCKS_IN_FLIGHT", "2")))
 _slot_free = threading.Condition(_lock)
 
 
