@@ -322,3 +322,41 @@ def test_host_route_calls_survive_allocation_churn_in_another_thread(xh):
     c.join()
     assert not errors, errors
     assert bad[0] == 0, "%d of 4800 calls put their sample in the wrong bin" % bad[0]
+
+
+def test_one_shot_entry_point_evicts_its_plan_cache_safely(xh):
+    """xhist_bincount_rows keeps at most 64 plans and drops them all when full: threads that are still executing a
+    dropped plan hold their own reference (the cache used to destroy plans in use)"""
+    import ctypes as C
+
+    from xhistogram_amd import _native
+
+    lib = _native.load()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(20_000)
+    errors, bad = [], [0]
+
+    def worker(k):
+        try:
+            for it in range(60):
+                e = np.linspace(-4, 4 + 1e-3 * (k * 60 + it), 33)  # 480 distinct edge sets over 8 threads: many evictions
+                out = np.empty(32, dtype=np.int64)
+                view = (_native.XhistArray * 1)(_native.make_view(x.ctypes.data, _native.F64, x.size, 1))
+                eptr = (C.c_void_p * 1)(e.ctypes.data)
+                elen = (C.c_int64 * 1)(e.size)
+                rc = lib.xhist_bincount_rows(0, 1, view, None, 1, x.size, eptr, elen, _native.CMP_F64, C.c_void_p(out.ctypes.data),
+                                             _native.I64, _native.MEM_HOST, 0, None)
+                if rc != 0:
+                    errors.append((rc, lib.xhist_last_error()))
+                    return
+                if not np.array_equal(out, np.histogram(x, bins=e)[0]):
+                    bad[0] += 1
+        except Exception as exc:  # pragma: no cover
+            errors.append(repr(exc))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:2]
+    assert bad[0] == 0
+    assert lib.xhist_shutdown() == 0
