@@ -64,7 +64,10 @@ typedef enum { XHIST_CMP_F64 = 0, XHIST_CMP_I64 = 1 } xhist_cmp_domain;
  * edge arrays hold uint64 values and their samples (uint8..uint64, bool) compare as unsigned
  * (numpy: uint64 data against uint64 edges). */
 #define XHIST_CMP_UNSIGNED 0x200
-typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1 } xhist_mem_kind;
+/* XHIST_MEM_HOST_TO_DEVICE: samples / weights are HOST pointers (staged by the library), `out` is a DEVICE buffer on the plan's GPU:
+ * the partial histogram of a host-resident block stays on the GPU that computed it, for the sum over blocks and GPUs
+ * (xhist_buffer_add, xhist_comm_allreduce) that replaces dask's `.sum(drop_axes)` (core.py:439) */
+typedef enum { XHIST_MEM_HOST = 0, XHIST_MEM_DEVICE = 1, XHIST_MEM_HOST_TO_DEVICE = 2 } xhist_mem_kind;
 
 /* A logical [M, C] array addressed as data[row_offset(r) + c * col_stride] (strides in ELEMENTS):
  *   row_offset(r) = r * row_stride                                                  if inner_rows == 0
@@ -104,7 +107,7 @@ int xhist_plan_destroy(xhist_plan* plan);
 
 /* The fused hot path — replaces core.py:137-194 (_bincount_2d_vectorized: searchsorted 170-173,
  * ravel_multi_index 178-181, _dispatch_bincount/_bincount_2d 73-134, trim 189-192) in ONE kernel.
- *   samples[n_inputs], weights (NULL = unweighted): xhist_array views, all HOST or all DEVICE.
+ *   samples[n_inputs], weights (NULL = unweighted): xhist_array views, all HOST or all DEVICE (mem_kind).
  *   out: contiguous [n_rows, prod(nb_d)];  out_dtype XHIST_I64 (unweighted) or XHIST_F64 (weighted).
  *   accumulate != 0: add into `out` instead of overwriting it — this is the reference's
  *     "sum over blocks" (dask `.sum(drop_axes)`, core.py:439) fused into the kernel's flush.

@@ -78,6 +78,16 @@ def compute():
     t = rng.standard_normal((8, 36, 72)).astype(np.float32)  # C4 miniature: chunks on time
     h, _ = histogram(dsa.from_array(t, chunks=(2, 36, 72)), bins=np.linspace(-4, 4, 51), axis=[1, 2])
     np.testing.assert_array_equal(h.compute(scheduler="threads"), np.stack([np.histogram(t[i], bins=np.linspace(-4, 4, 51))[0] for i in range(8)]))
+    # the same through the device-resident reduction (partials stay on the GPU, one copy back per output chunk)
+    from xhistogram_amd import multigpu
+    multigpu.set_dask_exchange("rccl")
+    da, db, dw = dsa.from_array(a, chunks=(3, 5)), dsa.from_array(b, chunks=(4, 6)), dsa.from_array(w, chunks=(2, 12))
+    h, _ = histogram(da, db, bins=[bins_a, bins_b], weights=dw)
+    assert any(k.startswith("reduce_partials") for k in h.dask.layers)
+    np.testing.assert_allclose(h.compute(), np.histogram2d(a.ravel(), b.ravel(), bins=[bins_a, bins_b], weights=w.ravel())[0], rtol=1e-6)
+    h, _ = histogram(dsa.from_array(t, chunks=(2, 18, 72)), bins=np.linspace(-4, 4, 51), axis=[1, 2])
+    np.testing.assert_array_equal(h.compute(scheduler="threads"), np.stack([np.histogram(t[i], bins=np.linspace(-4, 4, 51))[0] for i in range(8)]))
+    multigpu.set_dask_exchange(None)
     print("COMPUTE-OK")
 
 
@@ -106,6 +116,7 @@ def spread():
 
     core._bincount = oracle_bincount
     multigpu.set_devices([0, 1, 2, 3, 4, 5, 6, 7])
+    multigpu.set_dask_exchange("host")  # first the reference's own graph; the device-resident reduction below
     rng = np.random.default_rng(1)
     # C2-shaped: one long sample axis in 16 chunks, full reduction, weights chunked differently (unaligned)
     x, w = rng.standard_normal(40_000), rng.uniform(0, 1, 40_000)
@@ -132,6 +143,24 @@ def spread():
     h, _ = histogram(dsa.from_array(a, chunks=(7, 40)), dsa.from_array(b, chunks=(11, 13)), bins=[ea, eb], density=True)
     np.testing.assert_allclose(h.compute(), np.histogram2d(a.ravel(), b.ravel(), bins=[ea, eb], density=True)[0], rtol=1e-10)
     assert all(v == 0 for v in multigpu._inflight.values())
+    multigpu.set_dask_exchange(None)
+    # the device-resident reduction (default with more than one GPU): same results through the two-stage graph — here the
+    # block adapter double returns host arrays, which reduce_partials adds like the empty blocks of a real run
+    assert multigpu.dask_exchange() == "rccl"  # 8 GPUs in use
+    seen.clear()
+    h, _ = histogram(dsa.from_array(x, chunks=2500), bins=e, weights=dsa.from_array(w, chunks=3000))
+    assert not seen and any(k.startswith("reduce_partials") for k in h.dask.layers), list(h.dask.layers)
+    np.testing.assert_allclose(h.compute(), np.histogram(x, bins=e, weights=w)[0], rtol=1e-10)
+    h, _ = histogram(dsa.from_array(t, chunks=(5, 9, 36)), bins=e4, axis=[1, 2])
+    got = h.compute(scheduler="threads")
+    np.testing.assert_array_equal(got, want)
+    assert got.dtype == np.int64 and got.shape == (24, 50)
+    h, _ = histogram(dsa.from_array(a, chunks=(7, 40)), dsa.from_array(b, chunks=(11, 13)), bins=[ea, eb], density=True)
+    np.testing.assert_allclose(h.compute(), np.histogram2d(a.ravel(), b.ravel(), bins=[ea, eb], density=True)[0], rtol=1e-10)
+    multigpu.set_dask_exchange("host")
+    h, _ = histogram(dsa.from_array(x, chunks=2500), bins=e)
+    assert any(k.startswith("sum") for k in h.dask.layers) and not any(k.startswith("reduce_partials") for k in h.dask.layers)
+    multigpu.set_dask_exchange(None)
     print("SPREAD-OK")
 
 

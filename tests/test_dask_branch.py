@@ -19,8 +19,10 @@ def _have_dask_python():
 needs = pytest.mark.skipif(not _have_dask_python(), reason="no interpreter with dask in this image")
 
 
-def _run(mode, *extra):
+def _run(mode, *extra, exchange=None):
     env = dict(os.environ)
+    if exchange:
+        env["XHIST_AMD_DASK_EXCHANGE"] = exchange
     # conda's python ships an older libstdc++ than libamdhip64 needs: let the system one win
     sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
     if os.path.exists(sys_cxx):
@@ -51,3 +53,11 @@ def test_dask_blocks_compute_on_gpu():
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_dask_graphs_on_gpu_match_numpy(seed):
     assert "SOAK-OK" in _run("soak", seed, 40)
+
+
+@needs
+@pytest.mark.gpu
+def test_random_dask_graphs_with_partials_kept_on_the_gpu():
+    """the device-resident reduction (default with more than one GPU, forced here): block results stay on the GPU as
+    DevicePartial, are added there and come back once per output chunk"""
+    assert "SOAK-OK" in _run("soak", 7, 60, exchange="rccl")

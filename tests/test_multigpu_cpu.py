@@ -266,3 +266,69 @@ def test_blocks_in_flight_per_gpu_are_bounded():
         assert all(v == 0 for v in multigpu._inflight.values())
     finally:
         multigpu.set_devices(None)
+
+
+def test_reduce_partials_adds_per_gpu_then_across_gpus():
+    """second stage of the dask graph under the device-resident reduction: partials grouped by GPU, added there, the GPUs'
+    sums all-reduced (test seam instead of RCCL), one copy back; empty blocks arrive as host arrays"""
+    from xhistogram_amd import _native
+
+    log = []
+
+    class FakeBuf:
+        def __init__(self, arr, device):
+            self.arr, self.device, self.ptr, self.closed = arr.astype(np.float64).ravel().copy(), device, id(self), False
+
+        def add(self, other, count, tag):
+            assert other.device == self.device and not other.closed
+            log.append(("add", self.device))
+            self.arr[:count] += other.arr[:count]
+
+        def download(self, out):
+            log.append(("download", self.device))
+            out[...] = self.arr.reshape(out.shape)
+
+        def close(self):
+            self.closed = True
+
+    rng = np.random.default_rng(3)
+    shape = (4, 1, 1, 7)  # a kept-axis chunk of 4 rows, two reduced axes as single-element dims, 7 bins
+    blocks = [rng.integers(0, 9, shape).astype(np.float64) for _ in range(7)]
+    devs = [2, 0, 2, 1, 0, 2, 1]
+    parts = [_native.DevicePartial(FakeBuf(b, d), shape, np.float64) for b, d in zip(blocks, devs)]
+    empty = np.zeros(shape)
+    nested = [[parts[0], parts[1], [parts[2]]], [parts[3], empty, parts[4]], [parts[5], parts[6]]]
+
+    def allreduce(sums, count, tag):
+        log.append(("allreduce", tuple(s.device for s in sums)))
+        tot = sum(s.buf.arr[:count] for s in sums)
+        for s in sums:
+            s.buf.arr[:count] = tot
+
+    got = multigpu.reduce_partials(nested, drop_axes=(1, 2), out_dtype="<f8", _allreduce=allreduce)
+    np.testing.assert_allclose(got, sum(blocks).squeeze((1, 2)))
+    assert got.shape == (4, 7)
+    assert [e for e in log if e[0] == "allreduce"] == [("allreduce", (0, 1, 2))]       # ONE exchange, GPUs in order
+    assert sorted(e[1] for e in log if e[0] == "add") == [0, 1, 2, 2]                     # 7 partials on 3 GPUs: 4 local adds
+    assert [e for e in log if e[0] == "download"] == [("download", 0)]                   # one copy back
+    assert all(p.buf.closed for p in parts)
+    # integer counts; a single GPU needs no exchange
+    ip = [_native.DevicePartial(FakeBuf(np.full((2, 1, 3), k), 5), (2, 1, 3), np.int64) for k in (1, 2, 3)]
+    got = multigpu.reduce_partials([ip], drop_axes=(1,), out_dtype="<i8", _allreduce=lambda *a: (_ for _ in ()).throw(AssertionError("no exchange for one GPU")))
+    np.testing.assert_array_equal(got, np.full((2, 3), 6))
+    assert got.dtype == np.int64
+
+
+def test_dask_exchange_policy(monkeypatch):
+    multigpu.set_devices([0])
+    try:
+        assert multigpu.dask_exchange() == "host"
+        multigpu.set_devices([0, 1])
+        assert multigpu.dask_exchange() == "rccl"
+        monkeypatch.setenv("XHIST_AMD_DASK_EXCHANGE", "host")
+        assert multigpu.dask_exchange() == "host"
+        multigpu.set_dask_exchange("rccl")
+        assert multigpu.dask_exchange() == "rccl"
+    finally:
+        multigpu.set_dask_exchange(None)
+        multigpu.set_devices(None)

@@ -29,7 +29,7 @@ F64, F32, F16, I64, I32, I16, I8, U64, U32, U16, U8, BOOL = range(12)
 CMP_F64, CMP_I64 = 0, 1
 CMP_PER_DIM = 0x100  # | mask: bit d set <=> input d compares in int64 (XHIST_CMP_PER_DIM)
 CMP_UNSIGNED = 0x200  # | onto CMP_I64 / CMP_PER_DIM: the int64-domain inputs are unsigned 64-bit (edges passed as uint64)
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_TO_DEVICE = 0, 1, 2
 COMM_ID_BYTES = 128
 REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
 
@@ -368,6 +368,38 @@ class DeviceBuffer:
             self.close()
         except Exception:
             pass
+
+
+class DevicePartial:
+    """A partial histogram that stays on the GPU that computed it (numpy inputs, XHIST_MEM_HOST_TO_DEVICE): what a dask block
+    task hands to the reduction over blocks and GPUs instead of a host array.  Shape bookkeeping only; the data is a
+    DeviceBuffer of int64 counts or float64 sums."""
+
+    def __init__(self, buf, shape, dtype):
+        self.buf, self.shape, self.dtype = buf, tuple(int(n) for n in shape), np.dtype(dtype)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)) else shape
+        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        self.shape = tuple(int(n) for n in shape)
+        return self
+
+    def to_numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        self.buf.download(out)
+        return out
 
 
 def shutdown():

@@ -255,7 +255,16 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
     # the library zero-initialises (overwrites) the output itself: no fill here, which for torch
     # would be one more kernel launch per call
     out_shape = ((2,) if wview2 is not None else ()) + (nrows,) + plan.bins_shape
-    if backend == "numpy":
+    if backend == "numpy" and getattr(_tls, "device_out", False) and wview2 is None and int(np.prod(out_shape, dtype=np.int64)) > 0:
+        # a dask block under the device-resident reduction (multigpu.reduce_partials): only the inputs cross PCIe, the
+        # partial histogram stays on its GPU
+        out_dtype = np.float64 if weighted else np.int64
+        buf = _native.DeviceBuffer(device, int(np.prod(out_shape, dtype=np.int64)) * 8)
+        out = _native.DevicePartial(buf, out_shape, out_dtype)
+        out_ptr = buf.ptr
+        mem = _native.MEM_HOST_TO_DEVICE
+        empty = False
+    elif backend == "numpy":
         out = np.empty(out_shape, dtype=np.float64 if weighted else np.int64)
         out_ptr = out.ctypes.data
         empty = out.size == 0
@@ -516,6 +525,20 @@ def _bincount_spread(*all_arrays, **kwargs):
 
     with multigpu.block_device():
         return _bincount(*all_arrays, **kwargs)
+
+
+def _bincount_partial(*all_arrays, **kwargs):
+    """One dask block under the device-resident reduction: as _bincount_spread, but the result is a
+    _native.DevicePartial on the block's GPU (only the inputs cross PCIe)."""
+    from . import multigpu
+
+    with multigpu.block_device():
+        prev = getattr(_tls, "device_out", False)
+        _tls.device_out = True
+        try:
+            return _bincount(*all_arrays, **kwargs)
+        finally:
+            _tls.device_out = prev
 
 
 def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
@@ -918,16 +941,35 @@ def _dask_graph(all_arrays, has_weights, drop_axes, bins, bincount_kwargs):
     data_index = tuple(_range(ndim))
     bin_index = tuple(_range(ndim, ndim + len(bins)))
     operands = [item for arr in all_arrays for item in (arr, data_index)]
+    from . import multigpu
+
+    on_gpus = multigpu.dask_exchange() == "rccl"
+    out_dtype = np.dtype("i8" if not has_weights else all_arrays[-1].dtype)
     partials = dsa.blockwise(
-        _bincount_spread,
+        _bincount_partial if on_gpus else _bincount_spread,
         data_index + bin_index,
         *operands,
         new_axes={ax: len(b) - 1 for ax, b in zip(bin_index, bins)},
         adjust_chunks={ax: (lambda extent: 1) for ax in drop_axes},
-        meta=np.array((), "i8" if not has_weights else all_arrays[-1].dtype),
+        meta=np.array((), out_dtype),
         **bincount_kwargs,
     )
-    return partials.sum(drop_axes)
+    if not on_gpus:
+        return partials.sum(drop_axes)
+    # the partial histograms stay on the GPUs that computed them; one task per output chunk adds up the partials of each
+    # GPU there and the GPUs' sums with ONE RCCL all-reduce (multigpu.reduce_partials), instead of dask's tree of host sums
+    kept_index = tuple(i for i in data_index if i not in drop_axes)
+    return dsa.blockwise(
+        multigpu.reduce_partials,
+        kept_index + bin_index,
+        partials,
+        data_index + bin_index,
+        concatenate=False,
+        meta=np.array((), out_dtype),
+        dtype=out_dtype,
+        drop_axes=tuple(int(a) for a in drop_axes),
+        out_dtype=out_dtype.str,
+    )
 
 
 def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", _second_weights=None):

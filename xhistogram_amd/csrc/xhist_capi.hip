@@ -96,13 +96,20 @@ static int stage_chunk(const xhist_array& a, int64_t r0, int64_t nr, int64_t c0,
   return XHIST_OK;
 }
 
+// device_out: `out` is a DEVICE buffer of the plan's GPU (XHIST_MEM_HOST_TO_DEVICE): the partial histogram stays where it
+// was computed — for the sum over blocks / GPUs that follows (xhist_buffer_add, xhist_comm_allreduce) — and only the
+// inputs cross PCIe
 static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows, int64_t n_cols,
-                        void* out, int accumulate, hipStream_t stream) {
+                        void* out, int accumulate, hipStream_t stream, bool device_out = false) {
   const int D = p->n_dims;
   const int64_t out_elems = n_rows * p->n_bins;
   if (out_elems == 0) return XHIST_OK;
   if (n_cols == 0) {
-    if (!accumulate) memset(out, 0, (size_t)out_elems * 8);
+    if (!accumulate) {
+      if (!device_out) memset(out, 0, (size_t)out_elems * 8);
+      else if (int zrc = zero_output(out, out_elems, stream)) return zrc;
+    }
+    if (device_out) HIPC(hipStreamSynchronize(stream));
     return XHIST_OK;
   }
   void* d_out = nullptr;
@@ -114,8 +121,15 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
     if (d_out) (void)scratch_free(d_out, stream, synced);
     return code;
   };
-  if (scratch_malloc(&d_out, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
-  if (int zrc = zero_output(d_out, out_elems, stream)) return done(zrc);
+  void* const user_out = out;
+  if (device_out) {  // accumulate straight into the caller's device buffer
+    if (!accumulate)
+      if (int zrc = zero_output(out, out_elems, stream)) return done(zrc);
+  } else {
+    if (scratch_malloc(&d_out, (size_t)out_elems * 8, stream) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "hipMalloc of %lld output bytes failed", (long long)out_elems * 8));
+    if (int zrc = zero_output(d_out, out_elems, stream)) return done(zrc);
+  }
+  void* const acc = device_out ? user_out : d_out;
 
   // views with grouped rows (reduced axes between kept axes) are staged whole, strides intact:
   // the bytes between the first and the last element are copied as they lie
@@ -145,7 +159,7 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
       v.data = s.dptr;
       if (d < D) views[d] = v; else wview = v;
     }
-    if (rc == XHIST_OK) rc = execute_device(p, views, weights ? &wview : nullptr, n_rows, n_cols, d_out, 1, stream);
+    if (rc == XHIST_OK) rc = execute_device(p, views, weights ? &wview : nullptr, n_rows, n_cols, acc, 1, stream);
   }
   // chunks of <= 2^27 elements per array: whole rows when a row fits, else column spans of one row
   const int64_t kChunk = (int64_t)1 << 27;
@@ -160,11 +174,16 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
       for (int d = 0; d < D && rc == XHIST_OK; ++d) rc = stage_chunk(samples[d], r0, nr, c0, nc, st[d], &views[d], stream);
       if (rc == XHIST_OK && weights) rc = stage_chunk(*weights, r0, nr, c0, nc, st[kMaxDims], &wview, stream);
       if (rc == XHIST_OK)
-        rc = execute_device(p, views, weights ? &wview : nullptr, nr, nc, static_cast<char*>(d_out) + (size_t)r0 * p->n_bins * 8, 1, stream);
+        rc = execute_device(p, views, weights ? &wview : nullptr, nr, nc, static_cast<char*>(acc) + (size_t)r0 * p->n_bins * 8, 1, stream);
       // the staging buffers are reused by the next chunk: same-stream ordering makes that safe
     }
   }
   if (rc != XHIST_OK) { synced = hipStreamSynchronize(stream) == hipSuccess; return done(rc); }
+  if (device_out) {  // the result stays on the GPU; the staging copies of the caller's (pageable) inputs must be done
+    if (hipStreamSynchronize(stream) != hipSuccess) return done(fail(XHIST_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
+    synced = true;
+    return done(XHIST_OK);
+  }
   if (!accumulate) {
     if (hipMemcpyAsync(out, d_out, (size_t)out_elems * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
@@ -191,7 +210,8 @@ static int execute_host(xhist_plan* p, const xhist_array* samples, const xhist_a
 extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_rows,
                                   int64_t n_cols, void* out, int out_dtype, int mem_kind, int accumulate, void* stream) {
   if (int rc = validate_arrays(p, samples, weights, n_rows, n_cols, out, out_dtype)) return rc;
-  if (mem_kind != XHIST_MEM_HOST && mem_kind != XHIST_MEM_DEVICE) return fail(XHIST_ERR_INVALID, "unknown mem_kind %d", mem_kind);
+  if (mem_kind != XHIST_MEM_HOST && mem_kind != XHIST_MEM_DEVICE && mem_kind != XHIST_MEM_HOST_TO_DEVICE)
+    return fail(XHIST_ERR_INVALID, "unknown mem_kind %d", mem_kind);
   DeviceGuard g;
   if (int rc = g.set(p->device)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -205,7 +225,8 @@ extern "C" int xhist_plan_execute(xhist_plan* p, const xhist_array* samples, con
   // block's kernel instead of queueing behind each other.
   Range r("xhist_plan_execute[host: stage + bin]");
   static const bool null_stream = [] { const char* e = getenv("XHIST_AMD_HOST_STREAM"); return e && !strcmp(e, "null"); }();
-  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s ? s : (null_stream ? nullptr : hipStreamPerThread));
+  return execute_host(p, samples, weights, n_rows, n_cols, out, accumulate, s ? s : (null_stream ? nullptr : hipStreamPerThread),
+                      mem_kind == XHIST_MEM_HOST_TO_DEVICE);
 }
 
 extern "C" int xhist_plan_execute_two_weights(xhist_plan* p, const xhist_array* samples, const xhist_array* weights_a,

@@ -43,7 +43,7 @@ from . import _native, core
 
 __all__ = [
     "set_devices", "get_devices", "visible_devices", "block_device", "on_device", "DeviceGroup", "plan_shards",
-    "host_sharded_counts", "Sharded", "scatter", "histogram",
+    "host_sharded_counts", "Sharded", "scatter", "histogram", "dask_exchange", "set_dask_exchange", "reduce_partials",
 ]
 
 _range = range
@@ -52,6 +52,8 @@ _configured = None  # explicit set_devices(); None = policy below
 _inflight = {}  # device -> blocks currently running there (block_device)
 _rr = [0]
 _groups = {}  # tuple(devices) -> DeviceGroup
+
+_dask_exchange = None  # explicit set_dask_exchange(); None = policy in dask_exchange()
 
 # host inputs are sharded over GPUs only when every shard still moves this many bytes over PCIe: below it a
 # call is dominated by per-device fixed costs (plan creation, staging allocation, one more thread hop)
@@ -90,6 +92,25 @@ def get_devices():
     if spec is None or spec == "all":
         return visible_devices() or [core.default_device()]
     return list(spec)
+
+
+def set_dask_exchange(mode):
+    """how the partial histograms of dask blocks are added up: "host" (the reference's graph: each block returns a host
+    array, dask's ``sum`` layer adds them), "rccl" (the partials stay on the GPUs that computed them; one task per
+    output chunk adds each GPU's partials there and the GPUs' sums with ONE RCCL all-reduce over xGMI), or None = default"""
+    global _dask_exchange
+    if mode not in (None, "host", "rccl"):
+        raise ValueError("dask exchange must be 'host', 'rccl' or None, got %r" % (mode,))
+    _dask_exchange = mode
+
+
+def dask_exchange():
+    """"rccl" when the blocks are spread over more than one GPU (or $XHIST_AMD_DASK_EXCHANGE / set_dask_exchange says so),
+    else "host": with one GPU the partials of an output chunk meet on the host anyway and the reference's own graph is kept"""
+    mode = _dask_exchange or os.environ.get("XHIST_AMD_DASK_EXCHANGE", "").strip().lower() or None
+    if mode in ("host", "rccl"):
+        return mode
+    return "rccl" if len(get_devices()) > 1 else "host"
 
 
 @contextlib.contextmanager
@@ -165,6 +186,9 @@ class DeviceGroup:
         self._pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix="xhist-gpu%d" % d) for d in self.devices]
         self._comms = None
         self._closed = False
+        # collectives must be issued in the same order on every GPU: two callers (two dask reduction tasks, two user
+        # threads) that interleaved their per-GPU submissions would deadlock the communicators
+        self.collective = threading.RLock()
 
     def __len__(self):
         return len(self.devices)
@@ -191,11 +215,12 @@ class DeviceGroup:
 
     def comms(self):
         """one ``_native.Comm`` per GPU (rank k = k-th device); collective creation from the GPU threads"""
-        if self._comms is None:
-            world = len(self.devices)
-            uid = _native.comm_unique_id()
-            self._comms = self.run(lambda rank, device, _: _native.Comm(device, rank, world, uid), [None] * world)
-        return self._comms
+        with self.collective:
+            if self._comms is None:
+                world = len(self.devices)
+                uid = _native.comm_unique_id()
+                self._comms = self.run(lambda rank, device, _: _native.Comm(device, rank, world, uid), [None] * world)
+            return self._comms
 
     def close(self):
         if self._closed:
@@ -346,10 +371,15 @@ def _allreduce_host_partials(group, parts):
     """partials (numpy, one per GPU of the group) -> their sum, by ONE RCCL all-reduce: each GPU's thread
     uploads its partial into a device buffer of the library, joins the all-reduce, and the first GPU's
     thread brings the result back"""
-    comms = group.comms()
     tag = _native.F64 if parts[0].dtype == np.float64 else _native.I64
     shape, dtype = parts[0].shape, parts[0].dtype
     count = int(parts[0].size)
+    with group.collective:
+        return _allreduce_host_partials_locked(group, parts, tag, shape, dtype, count)
+
+
+def _allreduce_host_partials_locked(group, parts, tag, shape, dtype, count):
+    comms = group.comms()
 
     def one(rank, device, part):
         buf = _native.DeviceBuffer(device, count * 8)
@@ -366,6 +396,66 @@ def _allreduce_host_partials(group, parts):
             buf.close()
 
     return group.run(one, list(parts))[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# dask: partial histograms that stay on their GPUs
+# ---------------------------------------------------------------------------------------------
+def _flatten(nested):
+    if isinstance(nested, (list, tuple)):
+        for item in nested:
+            yield from _flatten(item)
+    else:
+        yield nested
+
+
+def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None):
+    """Second stage of the dask graph under ``dask_exchange() == "rccl"`` — replaces ``bin_counts.sum(drop_axes)``
+    (core.py:439) for ONE output chunk.  ``nested`` holds the partial histograms of every block that contributes to the
+    chunk (``_native.DevicePartial`` on the GPU that computed each; host arrays for empty blocks), all of one shape with
+    the reduced axes as single-element dims.  The partials of each GPU are added up on that GPU (``xhist_buffer_add``), the
+    GPUs' sums by ONE in-place RCCL all-reduce issued from the GPUs' host threads, and the first GPU's copy comes back to
+    the host: one device-to-host copy per output chunk instead of one per block.  ``_allreduce`` is a test seam."""
+    parts = list(_flatten(nested))
+    dtype = np.dtype(out_dtype)
+    host = [np.asarray(p) for p in parts if not isinstance(p, _native.DevicePartial)]
+    on_gpu = [p for p in parts if isinstance(p, _native.DevicePartial)]
+    total = None
+    if on_gpu:
+        shape, pdtype, count = on_gpu[0].shape, on_gpu[0].dtype, on_gpu[0].size
+        tag = _native.F64 if pdtype == np.float64 else _native.I64
+        by_dev = {}
+        for p in on_gpu:
+            assert p.shape == shape and p.dtype == pdtype, (p.shape, shape)
+            by_dev.setdefault(p.device, []).append(p)
+        devices = sorted(by_dev)
+        sums = []
+        for d in devices:  # this GPU's partials -> its first partial (same GPU, NULL stream: ordered)
+            acc = by_dev[d][0]
+            for other in by_dev[d][1:]:
+                acc.buf.add(other.buf, count, tag)
+            sums.append(acc)
+        if len(devices) > 1:
+            if _allreduce is not None:
+                _allreduce(sums, count, tag)
+            else:
+                group = group_for(devices)
+                with group.collective:
+                    comms = group.comms()
+
+                    def one(rank, device, acc):
+                        comms[rank].allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
+                        acc.buf.synchronize()
+
+                    group.run(one, sums)
+        total = sums[0].to_numpy()  # (download waits for the NULL stream of that GPU)
+        for p in on_gpu:
+            p.buf.close()
+    for h in host:
+        total = h.astype(dtype, copy=True) if total is None else total + h
+    if total is None:
+        raise ValueError("no partial histograms to reduce")
+    return total.squeeze(tuple(drop_axes)).astype(dtype, copy=False)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -513,19 +603,20 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         for p in parts[1:]:
             counts += p.to(home)
     elif exchange == "rccl":
-        comms = group.comms()
+        with group.collective:
+            comms = group.comms()
 
-        def allreduce(rank, device, t):
-            torch = core._torch()
-            torch.cuda.set_device(device)
-            t = t.contiguous()
-            tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
-            stream = torch.cuda.current_stream(device).cuda_stream
-            comms[rank].allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
-            torch.cuda.current_stream(device).synchronize()
-            return t
+            def allreduce(rank, device, t):
+                torch = core._torch()
+                torch.cuda.set_device(device)
+                t = t.contiguous()
+                tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
+                stream = torch.cuda.current_stream(device).cuda_stream
+                comms[rank].allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
+                torch.cuda.current_stream(device).synchronize()
+                return t
 
-        counts = group.run(allreduce, parts)[0]
+            counts = group.run(allreduce, parts)[0]
     else:
         raise ValueError("exchange must be 'rccl' or 'p2p', got %r" % (exchange,))
 
