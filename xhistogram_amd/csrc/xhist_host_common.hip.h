@@ -173,7 +173,18 @@ static bool scratch_use_hip_pool() {  // A/B switch for measurements only (the H
 }
 
 static hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t stream) {
-  if (scratch_use_hip_pool()) return hipMallocAsync(out, bytes, stream);
+  if (scratch_use_hip_pool()) {
+    static thread_local int warmed = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (warmed != dev) {  // (the A/B needs the pool to keep its memory, as the round-2 code before the switch did)
+      hipMemPool_t pool;
+      uint64_t keep = ~(uint64_t)0;
+      if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      warmed = dev;
+    }
+    return hipMallocAsync(out, bytes, stream);
+  }
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
   const size_t want = scratch_round(bytes);
