@@ -193,25 +193,26 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
-  const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted);
+  const int tile = route_tile(dtype_size(sdt));
+  const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile);
   const bool rec_f32 = wdt == XHIST_F32;
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
   if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
-  const int64_t n_tiles = (n_cols + kRouteTile - 1) / kRouteTile;
+  const int64_t n_tiles = (n_cols + tile - 1) / tile;
   const int per_cu = std::max<int>(1, std::min<int>(4, (int)((size_t)160 * 1024 / lds_route)));
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
   const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_cols + 65535) / 65536));
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
-  while (lg < 14 && ((n_cols / G) >> lg) + 2 * n_parts > kRouteListCap / 2) ++lg;
+  while (lg < 14 && (((n_cols / G) + tile) >> lg) + n_parts + 16 > kRouteListCap) ++lg;
   const int64_t GP = (int64_t)G * n_parts;
   // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
   // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
   // and ends with at most two ranges in hand.
   const int64_t used = ((n_cols + 7 * GP) >> lg) + GP;
-  const int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg) + 2 * route_max_need(lg)) + 64;
+  const int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
@@ -292,7 +293,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
              "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
-             n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, kRouteTile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
+             n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
@@ -830,7 +831,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       int r_scan = scan;
       const TableSet* r_tset = tset;
       bool r_f32 = use_f32;
-      const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted), lds_notab = part_route_lds(0, (int)n_parts, weighted);
+      const int r_tile = route_tile(dtype_size(sdt));
+      const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, r_tile), lds_notab = part_route_lds(0, (int)n_parts, weighted, r_tile);
       if (p->arith && arith_pref >= 0 && scan != kScanArith && n_parts <= 128 &&
           (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab)) {
         r_scan = kScanArith;

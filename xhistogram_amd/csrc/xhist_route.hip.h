@@ -35,24 +35,22 @@ namespace xhist {
 
 constexpr int kRouteGrp = 8;                  // records per aligned group: 8 codes = one 16-byte store
 constexpr uint32_t kChunkFillMask = 0xfffffu;  // cmeta[id] = partition << 20 | records in the chunk
-#ifndef XHIST_ROUTE_QUADS
-#define XHIST_ROUTE_QUADS 1
-#endif
-// workgroup and tile of the routing pass: 4 samples per lane.  (8 per lane — the tile of part_scatter — needs more
-// registers than a 1024-thread workgroup has: what spills is reloaded inside the loop, and every reload waits for the
-// prefetch in flight, see below.)
-constexpr int kRouteBlock = 1024, kRouteTile = kRouteBlock * 4 * XHIST_ROUTE_QUADS;
-constexpr int kRouteLoads = kRouteTile / (kRouteBlock * 4);  // 4-sample vectors per lane and tile
+// workgroup and tile of the routing pass: 4 samples per lane.  8 per lane — the tile of part_scatter — needs more
+// registers than a 1024-thread workgroup has next to the sort's state for float64 samples (what spills is reloaded inside
+// the loop, and every reload waits for the prefetch in flight, see below), and is no faster for float32 ones, where it
+// fits (5 x 10^8 float32 pairs + weights, 1024 x 1024 bins: 3.39 ms against 3.00)
+constexpr int kRouteBlock = 1024;
+__host__ __device__ constexpr int route_tile(int /*sample_bytes*/) { return 4096; }
 constexpr int kRouteListCap = 1024;            // chunks one workgroup can file in its LDS list (beyond: filed one by one, slowly)
 constexpr int kRouteCtl = 18496 + 2 * 4 * kRouteListCap;  // control arrays of part_route (see the kernel)
 constexpr int kAccBatch = 1024;                // chunks a workgroup of part_accumulate_chunks stages at a time
 // most chunks one partition can need for ONE tile (every record of the tile, plus padding, minus what its chunk still holds)
-__host__ __device__ constexpr int route_max_need(int chunk_log2) { return ((kRouteTile + 2 * kRouteGrp) >> chunk_log2) + 1; }
+__host__ __device__ constexpr int route_max_need(int chunk_log2, int tile) { return ((tile + 2 * kRouteGrp) >> chunk_log2) + 1; }
 // chunk ids a workgroup takes from the pool at a time: enough for every partition to switch in one tile, and at least
 // eight times the largest single request, so that the ids a range cannot serve any more (fewer than the largest request,
 // dropped when the next range takes over) stay below an eighth of what it handed out
-__host__ __device__ constexpr int route_batch(int P, int chunk_log2) {
-  return 2 * P > 8 * route_max_need(chunk_log2) ? 2 * P : 8 * route_max_need(chunk_log2);
+__host__ __device__ constexpr int route_batch(int P, int chunk_log2, int tile) {
+  return 2 * P > 8 * route_max_need(chunk_log2, tile) ? 2 * P : 8 * route_max_need(chunk_log2, tile);
 }
 
 struct RouteArgs {
@@ -66,10 +64,10 @@ struct RouteArgs {
   int32_t chunk_log2;
 };
 
-__host__ __device__ constexpr int part_route_slots(int P) { return kRouteTile + 2 * (kRouteGrp - 1) * P + kRouteGrp; }
-__host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted) {
+__host__ __device__ constexpr int part_route_slots(int P, int tile) { return tile + 2 * (kRouteGrp - 1) * P + kRouteGrp; }
+__host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted, int tile) {
   return ((table_bytes + 15) & ~(size_t)15) + (size_t)kRouteCtl + (size_t)P * kRouteGrp * (weighted ? 12 : 4) +
-         (size_t)part_route_slots(P) * (weighted ? 12 : 4) + 64;
+         (size_t)part_route_slots(P, tile) * (weighted ? 12 : 4) + 64;
 }
 
 // a 4-vector read `sh` elements before where it belongs (loads near the end of the array are pulled
@@ -112,7 +110,8 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
   using RT = typename std::conditional<__is_same(WT, float), float, double>::type;  // record weights keep the caller's precision
   constexpr int RV = 16 / (int)sizeof(RT);
   typedef RT rvec __attribute__((ext_vector_type(RV)));
-  constexpr int GRP = kRouteGrp, U = kRouteLoads;
+  constexpr int kRouteTile = route_tile((int)sizeof(ST));
+  constexpr int GRP = kRouteGrp, U = kRouteTile / (kRouteBlock * 4);  // 4-sample vectors per lane and tile
   constexpr uint32_t kGm = GRP - 1;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   typedef ST s4 __attribute__((ext_vector_type(4), aligned(sizeof(ST))));
@@ -145,7 +144,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
   dyn += (size_t)P * GRP * 4;
   RT* carry_w = reinterpret_cast<RT*>(dyn);                      // [P][GRP]
   if (kWeighted) dyn += (size_t)P * GRP * 8;
-  const int S = part_route_slots(P);
+  const int S = part_route_slots(P, kRouteTile);
   RT* sw = reinterpret_cast<RT*>(dyn);                           // [S] weights of the sorted tile
   if (kWeighted) dyn += (size_t)S * 8;
   uint32_t* skey = reinterpret_cast<uint32_t*>(dyn);             // [S] keys: part << 16 | code
@@ -159,7 +158,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
 #pragma unroll
   for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
   const uint32_t code_mask = (1u << shift) - 1u;
-  const uint32_t batch = (uint32_t)route_batch(P, lg), max_need = (uint32_t)route_max_need(lg);
+  const uint32_t batch = (uint32_t)route_batch(P, lg, kRouteTile), max_need = (uint32_t)route_max_need(lg, kRouteTile);
   for (int i = tid; i < 256; i += blockDim.x) {
     cnt2[i] = 0u;
     cnt2[256 + i] = 0u;
