@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 5
+#define XHIST_ABI_VERSION 6
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -181,6 +181,17 @@ int xhist_buffer_alloc(int device, size_t bytes, void** dptr);
 int xhist_buffer_free(int device, void* dptr);
 int xhist_buffer_copy(int device, void* dst, const void* src, size_t bytes, int direction, void* stream);
 int xhist_buffer_add(int device, void* dst, const void* src, int64_t count, int dtype, void* stream);
+
+/* Strided N-D copy between device buffers of `device`, asynchronous on `stream`: element (i_0 … i_{ndim-1}) of the source
+ * (byte strides `src_strides`, 0 and negative allowed) goes to the same index of the destination (`dst_strides`).
+ * ndim <= 8.  dst_dtype == src_dtype copies raw elements; dst_dtype == XHIST_F64 converts every supported dtype to float64
+ * (numpy's promotion inside searchsorted, core.py:170).  This is what blocks of a device-resident dask array need around
+ * the path: the moveaxis + reshape copy of core.py:218-226 for layouts no three strides describe, slices, and the
+ * concatenation of unaligned chunks (test_chunking.py:104-146) — without a host round trip and without torch. */
+int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, const void* src, int src_dtype, const int64_t* src_strides,
+                         void* dst, int dst_dtype, const int64_t* dst_strides, void* stream);
+/* GPU a device pointer belongs to (for arrays that arrive through __cuda_array_interface__, which does not say) */
+int xhist_pointer_device(const void* ptr, int* device);
 
 /* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
 /* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),

@@ -183,6 +183,12 @@ def soak():
         dargs = [dsa.from_array(a, chunks=chunk()) for a in args]
         w = rng.uniform(0, 2, shape) if rng.random() < 0.5 else None
         dw = None if w is None else dsa.from_array(w, chunks=chunk())
+        if os.environ.get("XHIST_SOAK_RESIDENT"):
+            # chunks that already live on the GPU (DeviceArray), some of them next to host chunks; unaligned chunkings make
+            # dask slice and concatenate them on the device
+            from xhistogram_amd.devicearray import to_device_chunks
+            dargs = [to_device_chunks(a) if rng.random() < 0.75 else a for a in dargs]
+            dw = to_device_chunks(dw) if dw is not None and rng.random() < 0.75 else dw
         axes = [None] + [tuple(c) for r in range(1, ndim + 1) for c in combinations(range(ndim), r)]
         axis = axes[int(rng.integers(0, len(axes)))]
         density = bool(rng.random() < 0.3)
@@ -210,5 +216,41 @@ def soak():
     print("SOAK-OK %d" % n_cases)
 
 
+def resident():
+    """dask arrays whose chunks already live on the GPU (DeviceArray chunks, no torch under dask): every block is binned where
+    it lies — nothing but the partial histograms crosses PCIe — for aligned and unaligned chunkings, both exchange forms."""
+    from xhistogram_amd import multigpu
+    from xhistogram_amd.devicearray import DeviceArray, to_device_chunks
+
+    rng = np.random.default_rng(0)
+    bins_a, bins_b = np.linspace(-4, 4, 9), np.linspace(-4, 4, 10)
+    a, b, w = rng.standard_normal((10, 12)), rng.standard_normal((10, 12)).astype(np.float32), rng.uniform(0, 1, (10, 12))
+    t = rng.standard_normal((8, 36, 72)).astype(np.float32)
+    e50 = np.linspace(-4, 4, 51)
+    for exchange in ("host", "rccl"):
+        multigpu.set_dask_exchange(exchange)
+        da = to_device_chunks(dsa.from_array(a, chunks=(3, 5))).persist()
+        assert isinstance(da.blocks[1, 1].compute(), DeviceArray)
+        h, _ = histogram(da, bins=bins_a)
+        np.testing.assert_array_equal(h.compute(), np.histogram(a, bins=bins_a)[0])
+        h, _ = histogram(da, bins=bins_a, axis=0)  # (the persisted chunks are used again)
+        np.testing.assert_array_equal(h.compute(), np.stack([np.histogram(a[:, j], bins=bins_a)[0] for j in range(12)]))
+        db = to_device_chunks(dsa.from_array(b, chunks=(4, 6)))  # unaligned with da: dask rechunks DeviceArray chunks
+        dw = dsa.from_array(w, chunks=(2, 12))  # host chunks next to resident ones
+        h, _ = histogram(da, db, bins=[bins_a, bins_b], weights=dw)
+        np.testing.assert_allclose(h.compute(scheduler="threads"),
+                                   np.histogram2d(a.ravel(), b.astype(np.float64).ravel(), bins=[bins_a, bins_b], weights=w.ravel())[0], rtol=1e-6)
+        h, _ = histogram(da, bins=bins_a, weights=to_device_chunks(dw), density=True, axis=1)
+        want = np.stack([np.histogram(a[i], bins=bins_a, weights=w[i], density=True)[0] for i in range(10)])
+        np.testing.assert_allclose(h.compute(), want, rtol=1e-6)
+        dt = to_device_chunks(dsa.from_array(t, chunks=(2, 36, 72))).persist()  # C4 miniature: chunks on time, resident
+        h, _ = histogram(dt, bins=e50, axis=[1, 2])
+        np.testing.assert_array_equal(h.compute(scheduler="threads"), np.stack([np.histogram(t[i], bins=e50)[0] for i in range(8)]))
+        h, _ = histogram(dt, bins=e50, axis=[0, 2])  # reduced axes on both sides of a kept one
+        np.testing.assert_array_equal(h.compute(scheduler="threads"), np.stack([np.histogram(t[:, j], bins=e50)[0] for j in range(36)]))
+    multigpu.set_dask_exchange(None)
+    print("RESIDENT-OK")
+
+
 if __name__ == "__main__":
-    {"lazy": lazy, "compute": compute, "spread": spread, "soak": soak}[sys.argv[1]]()
+    {"lazy": lazy, "compute": compute, "spread": spread, "soak": soak, "resident": resident}[sys.argv[1]]()

@@ -19,10 +19,12 @@ def _have_dask_python():
 needs = pytest.mark.skipif(not _have_dask_python(), reason="no interpreter with dask in this image")
 
 
-def _run(mode, *extra, exchange=None):
+def _run(mode, *extra, exchange=None, resident=False):
     env = dict(os.environ)
     if exchange:
         env["XHIST_AMD_DASK_EXCHANGE"] = exchange
+    if resident:
+        env["XHIST_SOAK_RESIDENT"] = "1"
     # conda's python ships an older libstdc++ than libamdhip64 needs: let the system one win
     sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
     if os.path.exists(sys_cxx):
@@ -61,3 +63,18 @@ def test_random_dask_graphs_with_partials_kept_on_the_gpu():
     """the device-resident reduction (default with more than one GPU, forced here): block results stay on the GPU as
     DevicePartial, are added there and come back once per output chunk"""
     assert "SOAK-OK" in _run("soak", 7, 60, exchange="rccl")
+
+
+@needs
+@pytest.mark.gpu
+def test_dask_arrays_with_chunks_resident_on_the_gpu():
+    """the per-block contract (core.py:429-437) on chunks that already live on the GPU (DeviceArray): persisted chunks are
+    binned where they lie, unaligned chunkings are sliced / concatenated on the device"""
+    assert "RESIDENT-OK" in _run("resident")
+
+
+@needs
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["host", "rccl"])
+def test_random_dask_graphs_over_resident_chunks(exchange):
+    assert "SOAK-OK" in _run("soak", 11, 40, exchange=exchange, resident=True)

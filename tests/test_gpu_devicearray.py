@@ -1,0 +1,263 @@
+"""Device-resident arrays without torch (xhistogram_amd.devicearray): the strided-copy kernel against numpy, and the HIP path
+on DeviceArray inputs against the golden vectors (outputs of the reference itself) and the CPU oracle.  Run with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+
+from conftest import MANIFEST, assert_hist_equal
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xh():
+    from xhistogram_amd import _native, core
+
+    _native.load()
+    assert _native.device_count() >= 1, "no MI355X visible: GPU tests must not pass on a fallback"
+    return core
+
+
+@pytest.fixture(scope="module")
+def DA(xh):
+    from xhistogram_amd.devicearray import DeviceArray
+
+    return DeviceArray
+
+
+DTYPES = [np.float64, np.float32, np.float16, np.int64, np.int32, np.int16, np.int8, np.uint64, np.uint32, np.uint16, np.uint8, np.bool_]
+
+
+def _values(rng, shape, dtype):
+    dtype = np.dtype(dtype)
+    if dtype.kind == "f":
+        return rng.normal(size=shape).astype(dtype)
+    if dtype.kind == "b":
+        return rng.random(shape) < 0.5
+    info = np.iinfo(dtype)
+    return rng.integers(max(info.min, -1000), min(info.max, 1000), size=shape).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# the array type itself
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES + ["datetime64[s]"])
+def test_round_trip(DA, dtype):
+    rng = np.random.default_rng(0)
+    a = _values(rng, (7, 5, 3), np.int64 if np.dtype(dtype).kind == "M" else dtype)
+    if np.dtype(dtype).kind == "M":
+        a = a.astype(dtype)
+    d = DA.from_numpy(a)
+    assert d.shape == a.shape and d.dtype == a.dtype and d.is_contiguous()
+    np.testing.assert_array_equal(d.to_numpy(), a)
+    np.testing.assert_array_equal(np.asarray(d), a)
+    assert DA.from_numpy(np.zeros((0, 4))).to_numpy().shape == (0, 4)
+    np.testing.assert_array_equal(DA.from_numpy(np.float64(3.5)).to_numpy(), np.float64(3.5))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_strided_copies_match_numpy(DA, seed):
+    """views of every kind (slices with steps and negative steps, transposes, broadcasts, new axes) copied by the library's
+    strided-copy kernel == numpy's copy of the same view"""
+    rng = np.random.default_rng(seed)
+    nd = int(rng.integers(1, 6))
+    shape = tuple(int(n) for n in rng.integers(1, 9 if nd > 2 else 300, size=nd))
+    dtype = DTYPES[seed % len(DTYPES)]
+    a = _values(rng, shape, dtype)
+    d = DA.from_numpy(a)
+    for _ in range(8):
+        key = []
+        for n in shape:
+            kind = rng.integers(0, 5)
+            if kind == 0:
+                key.append(slice(None))
+            elif kind == 1:
+                key.append(slice(int(rng.integers(0, n)), None, int(rng.integers(1, 4))))
+            elif kind == 2:
+                key.append(slice(None, None, -int(rng.integers(1, 3))))
+            elif kind == 3:
+                key.append(int(rng.integers(0, n)))
+            else:
+                key.append(slice(0, int(rng.integers(0, n + 1))))
+        key = tuple(key)
+        np.testing.assert_array_equal(d[key].copy().to_numpy(), a[key])
+        np.testing.assert_array_equal(d[key].to_numpy(), a[key])
+    perm = tuple(rng.permutation(nd))
+    np.testing.assert_array_equal(d.transpose(*perm).copy().to_numpy(), a.transpose(perm))
+    np.testing.assert_array_equal(d[None].broadcast_to((3,) + shape).copy().to_numpy(), np.broadcast_to(a, (3,) + shape))
+    np.testing.assert_array_equal(d.T.reshape(-1).to_numpy(), a.T.reshape(-1))  # a reshape that has to copy
+
+
+def test_big_transposes_and_few_column_tables(DA):
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(3000, 1100)).astype(np.float32)
+    np.testing.assert_array_equal(DA.from_numpy(a).T.copy().to_numpy(), a.T)
+    t = rng.normal(size=(200_000, 3))
+    np.testing.assert_array_equal(DA.from_numpy(t)[:, 1].copy().to_numpy(), t[:, 1])
+    big = np.arange(5_000_000, dtype=np.int64)
+    np.testing.assert_array_equal(DA.from_numpy(big)[::-1].copy().to_numpy(), big[::-1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conversion_to_float64(DA, dtype):
+    rng = np.random.default_rng(2)
+    a = _values(rng, (37, 11), dtype)
+    got = DA.from_numpy(a).T.astype(np.float64)
+    assert got.dtype == np.float64 and (got.is_contiguous() or np.dtype(dtype) == np.float64)  # (float64 -> float64: the view itself)
+    np.testing.assert_array_equal(got.to_numpy(), a.T.astype(np.float64))
+    with pytest.raises(TypeError):
+        DA.from_numpy(a).astype(np.int8 if np.dtype(dtype) != np.int8 else np.int16)
+
+
+def test_concatenate_on_the_device(DA):
+    rng = np.random.default_rng(3)
+    parts = [rng.normal(size=(4, n, 5)) for n in (3, 1, 7)]
+    got = np.concatenate([DA.from_numpy(p) for p in parts], axis=1)
+    assert isinstance(got, DA)
+    np.testing.assert_array_equal(got.to_numpy(), np.concatenate(parts, axis=1))
+    mixed = np.concatenate([DA.from_numpy(parts[0]).transpose(2, 1, 0), parts[0].transpose(2, 1, 0)], axis=-1)  # a host piece rides along
+    np.testing.assert_array_equal(mixed.to_numpy(), np.concatenate([parts[0].transpose(2, 1, 0)] * 2, axis=-1))
+
+
+def test_foreign_device_memory_through_cuda_array_interface(xh, DA):
+    torch = pytest.importorskip("torch")
+    t = torch.arange(24, dtype=torch.float32, device="cuda").reshape(4, 6)
+    d = DA.from_cuda_array_interface(t[:, ::2])
+    assert d.device == t.device.index and d.shape == (4, 3) and d.strides == (24, 8)
+    np.testing.assert_array_equal(d.to_numpy(), t[:, ::2].cpu().numpy())
+    edges = np.linspace(0, 24, 7)
+    got, _ = xh.histogram(d, bins=edges)
+    want, _ = onp.histogram(t[:, ::2].cpu().numpy(), bins=edges)
+    np.testing.assert_array_equal(got, want)
+    back = torch.as_tensor(DA.from_numpy(np.arange(5.0)), device="cuda")  # and the other way round
+    np.testing.assert_array_equal(back.cpu().numpy(), np.arange(5.0))
+
+
+# ---------------------------------------------------------------------------------------------
+# the hot path on DeviceArray inputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(MANIFEST["hotpath"]))
+def test_hotpath_golden_devicearray(xh, DA, golden, name):
+    samples, edges, w, want = golden.hotpath_case(name)
+    got = xh._bincount_2d_vectorized(*[DA.from_numpy(s) for s in samples], bins=edges, weights=None if w is None else DA.from_numpy(w))
+    assert isinstance(got, np.ndarray) and got.dtype == want.dtype
+    assert_hist_equal(got, want, weighted=w is not None)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["core"]))
+def test_public_api_golden_devicearray(xh, DA, golden, name):
+    args, kw, want, meta = golden.core_case(name)
+    dkw = dict(kw)
+    if "weights" in kw:
+        dkw["weights"] = DA.from_numpy(kw["weights"])
+    got, edges = xh.histogram(*[DA.from_numpy(a) for a in args], **dkw)
+    assert isinstance(got, np.ndarray) and got.shape == tuple(meta["h_shape"]) and str(got.dtype) == meta["h_dtype"]
+    assert_hist_equal(got, want, weighted=("weights" in kw) or kw.get("density", False))
+    for i, e in enumerate(edges):
+        np.testing.assert_array_equal(e, golden.core["%s/edges%d" % (name, i)])
+
+
+@pytest.mark.parametrize("axis", [None, (0,), (1,), (2,), (0, 1), (1, 2), (0, 2), (0, 1, 2), (-1,)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_every_axis_form_against_the_oracle(xh, DA, axis, weighted):
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(24, 130, 70)).astype(np.float32)
+    y = rng.normal(size=(24, 130, 70))
+    w = rng.uniform(size=(130, 70)) if weighted else None  # broadcast against the data, and a host array next to resident ones
+    edges = [np.linspace(-3, 3, 21), np.sort(rng.uniform(-3, 3, 9))]
+    kw = dict(bins=edges, axis=axis)
+    want, _ = onp.histogram(x, y, weights=w, **kw)
+    got, _ = xh.histogram(DA.from_numpy(x), DA.from_numpy(y), weights=w, **kw)
+    assert_hist_equal(got, want, weighted=weighted)
+    # strided views of resident arrays: sliced, transposed
+    xs, ys = DA.from_numpy(x)[::2, :, 1:], DA.from_numpy(y)[::2, :, 1:]
+    want, _ = onp.histogram(x[::2, :, 1:], y[::2, :, 1:], weights=None if w is None else w[:, 1:], **kw)
+    got, _ = xh.histogram(xs, ys, weights=None if w is None else DA.from_numpy(w)[:, 1:], **kw)
+    assert_hist_equal(got, want, weighted=weighted)
+
+
+def test_integer_bins_use_the_device_min_max(xh, DA):
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=1_000_003)
+    for bins, rng_ in ((64, None), (10, (-1.0, 2.0)), ("sturges", None)):
+        got, e = xh.histogram(DA.from_numpy(x), bins=bins, range=rng_)
+        want, ew = np.histogram(x, bins=bins, range=rng_)
+        np.testing.assert_array_equal(e[0], ew)
+        np.testing.assert_array_equal(got, want)
+    got, _ = xh.histogram(DA.from_numpy(x), bins=20, density=True)
+    np.testing.assert_allclose(got, np.histogram(x, bins=20, density=True)[0], rtol=1e-12)
+
+
+def test_big_histograms_promote_on_the_device(xh, DA):
+    """float32 x float64 joint histogram beyond LDS: converted to float64 by the copy kernel, then the vector kernels"""
+    rng = np.random.default_rng(7)
+    n = 3_000_000
+    x = rng.normal(size=n).astype(np.float32)
+    y = rng.normal(size=n)
+    w = rng.integers(0, 5, size=n).astype(np.int32)
+    edges = [np.linspace(-4, 4, 301), np.linspace(-4, 4, 301)]
+    got, _ = xh.histogram(DA.from_numpy(x), DA.from_numpy(y), bins=edges, weights=DA.from_numpy(w))
+    want, _ = onp.histogram(x, y, bins=edges, weights=w)
+    assert_hist_equal(got, want, weighted=True)
+    cmp_domain, conv, _ = xh._compare_domain([np.dtype("f8")] * 2, edges)
+    plan_desc = xh._get_plan(conv, cmp_domain, 0).describe()
+    assert "family=generic" not in plan_desc, plan_desc
+
+
+def test_datetime_and_two_weights(xh, DA):
+    rng = np.random.default_rng(8)
+    t = (np.datetime64("2000-01-01", "s") + rng.integers(0, 86400 * 365, size=50_000).astype("timedelta64[s]"))
+    edges = np.arange(np.datetime64("2000-01-01", "s"), np.datetime64("2001-01-02", "s"), np.timedelta64(30 * 86400, "s"))
+    got, _ = xh.histogram(DA.from_numpy(t), bins=edges)
+    want, _ = onp.histogram(t, bins=edges)
+    np.testing.assert_array_equal(got, want)
+    x = rng.normal(size=(40, 5000))
+    wa, wb = rng.uniform(size=x.shape), rng.uniform(size=x.shape)
+    e = np.linspace(-3, 3, 33)
+    ha, hb, _ = xh.histogram_two_weights(DA.from_numpy(x), bins=e, axis=1, weights=(DA.from_numpy(wa), DA.from_numpy(wb)))
+    assert_hist_equal(ha, onp.histogram(x, bins=e, axis=1, weights=wa)[0], weighted=True)
+    assert_hist_equal(hb, onp.histogram(x, bins=e, axis=1, weights=wb)[0], weighted=True)
+
+
+def test_block_task_contract_with_resident_chunks(xh, DA):
+    """what the dask branch calls per block (core.py:429-437) with chunks that live on the GPU: the block runs on the chunks'
+    GPU, the partial keeps every input axis, and under the device-resident reduction it never leaves the GPU"""
+    from xhistogram_amd import _native, multigpu
+
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(6, 40, 50)).astype(np.float32)
+    w = rng.uniform(size=x.shape).astype(np.float32)
+    edges = [np.linspace(-3, 3, 13)]
+    want = onp.block_adapter([x], edges, weights=w, axis=[1, 2])
+    got = xh._bincount_spread(DA.from_numpy(x), w, weights=True, axis=[1, 2], bins=edges, density=False, block_size="auto")
+    assert got.shape == (6, 1, 1, 12)
+    assert_hist_equal(got.reshape(want.shape), want, weighted=True)
+    part = xh._bincount_partial(DA.from_numpy(x), DA.from_numpy(w), weights=True, axis=[1, 2], bins=edges, density=False, block_size="auto")
+    assert isinstance(part, _native.DevicePartial) and part.shape == (6, 1, 1, 12) and part.device == 0
+    total = multigpu.reduce_partials([[[part]]], drop_axes=(1, 2), out_dtype="<f8")
+    assert_hist_equal(np.asarray(total).reshape(want.shape), want, weighted=True)
+
+
+def test_library_first_then_torch_in_one_process():
+    """torch wheels bundle their own HIP runtime: loading this library BEFORE torch used to leave torch without a GPU"""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from xhistogram_amd import core\n"
+        "h = core.histogram(np.arange(10.0), bins=np.linspace(0, 10, 3))[0]\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'torch lost the GPU'\n"
+        "s = torch.cuda.Stream()\n"
+        "with torch.cuda.stream(s):\n"
+        "    t = torch.arange(1e6, device='cuda', dtype=torch.float64)\n"
+        "    g = core.histogram(t, bins=np.linspace(0, 1e6, 3))[0]\n"
+        "assert h.tolist() == [5, 5] and g.tolist() == [500000, 500000]\n"
+        "print('ORDER-OK')\n"
+    )
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert "ORDER-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -71,8 +71,34 @@ EXPORTS = (
     "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
     "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
-    "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_shutdown",
+    "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
+    "xhist_pointer_device", "xhist_shutdown",
 )
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so).  A process that loads this
+    library first and imports torch afterwards ends up with two runtimes, and the second one finds no GPU
+    (`torch.cuda.is_available()` turns False; measured on the MI355X box).  With torch's copy loaded first — the order every
+    torch-first program has anyway — both see the GPU and share streams.  So: when torch is installed but not imported yet, its
+    runtime is loaded before ours.  No torch (the dask interpreter): nothing to do."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -88,6 +114,7 @@ def load():
                 "libxhist_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or xhistogram_amd/csrc/build.sh. There is no CPU fallback." % LIB_PATH
             )
+        _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         lib.xhist_abi_version.restype = C.c_int
         lib.xhist_last_error.restype = C.c_char_p
@@ -121,6 +148,9 @@ def load():
         lib.xhist_buffer_free.argtypes = [C.c_int, C.c_void_p]
         lib.xhist_buffer_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.xhist_buffer_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        lib.xhist_buffer_copy_nd.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_int, C.POINTER(C.c_int64),
+                                             C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p]
+        lib.xhist_pointer_device.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         for name in EXPORTS:
             getattr(lib, name)  # AttributeError here = header and library disagree
         if lib.xhist_abi_version() != ABI_VERSION:
@@ -400,6 +430,22 @@ class DevicePartial:
         out = np.empty(self.shape, self.dtype)
         self.buf.download(out)
         return out
+
+
+def copy_nd(device, shape, src_ptr, src_tag, src_strides, dst_ptr, dst_tag, dst_strides, stream=0):
+    """strided N-D copy between device buffers (byte strides), optionally converting to float64 (xhist_buffer_copy_nd)"""
+    nd = len(shape)
+    arr = C.c_int64 * max(nd, 1)
+    check(load().xhist_buffer_copy_nd(int(device), nd, arr(*[int(n) for n in shape]), C.c_void_p(src_ptr), int(src_tag),
+                                      arr(*[int(n) for n in src_strides]), C.c_void_p(dst_ptr), int(dst_tag),
+                                      arr(*[int(n) for n in dst_strides]), C.c_void_p(stream or 0)))
+
+
+def pointer_device(ptr):
+    """GPU a device pointer lives on"""
+    d = C.c_int(-1)
+    check(load().xhist_pointer_device(C.c_void_p(ptr), C.byref(d)))
+    return d.value
 
 
 def shutdown():

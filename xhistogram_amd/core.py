@@ -24,6 +24,7 @@ from collections.abc import Iterable
 import numpy as np
 
 from . import _native
+from .devicearray import DeviceArray
 
 # range is a keyword of histogram(), like in the reference
 _range = range
@@ -36,6 +37,17 @@ __all__ = ["histogram", "histogram_two_weights"]
 # ---------------------------------------------------------------------------------------------
 def _is_torch(a):
     return type(a).__module__.split(".")[0] == "torch" and hasattr(a, "data_ptr")
+
+
+def _is_devarr(a):
+    return type(a) is DeviceArray
+
+
+def _backend_of(arrays):
+    """"torch" (GPU tensors), "device" (DeviceArray: GPU memory without torch) or "numpy" (host memory)"""
+    if any(_is_torch(a) for a in arrays):
+        return "torch"
+    return "device" if any(_is_devarr(a) for a in arrays) else "numpy"
 
 
 def _is_dask(a):
@@ -217,6 +229,15 @@ def _strided_view(a2d, backend):
         if a2d.shape[0] <= 1:
             rs = 0 if a2d.shape[0] == 0 else rs
         return a2d.data_ptr(), _torch_tag(a2d.dtype), rs, cs, 0, 0, a2d
+    if backend == "device":
+        item = a2d.itemsize
+        if any(st < 0 or st % item for st in a2d.strides) or (
+                a2d.strides[0] > item and a2d.strides[1] > item and a2d.shape[1] > 1 and a2d.size >= (1 << 16)):
+            a2d = a2d.copy()  # (the same two cases as for torch tensors above)
+        rs, cs = (st // item for st in a2d.strides)
+        if a2d.shape[0] <= 1:
+            rs = 0 if a2d.shape[0] == 0 else rs
+        return a2d.ptr, _native.dtype_tag(np.dtype(np.int64) if a2d.dtype.kind in "mM" else a2d.dtype), rs, cs, 0, 0, a2d
     if a2d.dtype.kind in "mM":
         a2d = a2d.view(np.int64)
     item = a2d.dtype.itemsize
@@ -242,6 +263,10 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
         device = _host_device()
         stream = 0
         mem = _native.MEM_HOST
+    elif backend == "device":
+        device = like.device
+        stream = 0
+        mem = _native.MEM_DEVICE
     else:
         torch = _torch()
         if like.device.type != "cuda":
@@ -255,16 +280,19 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
     # the library zero-initialises (overwrites) the output itself: no fill here, which for torch
     # would be one more kernel launch per call
     out_shape = ((2,) if wview2 is not None else ()) + (nrows,) + plan.bins_shape
-    if backend == "numpy" and getattr(_tls, "device_out", False) and wview2 is None and int(np.prod(out_shape, dtype=np.int64)) > 0:
-        # a dask block under the device-resident reduction (multigpu.reduce_partials): only the inputs cross PCIe, the
-        # partial histogram stays on its GPU
+    n_out = int(np.prod(out_shape, dtype=np.int64))
+    device_partial = backend != "torch" and getattr(_tls, "device_out", False) and wview2 is None
+    if n_out > 0 and (device_partial or backend == "device"):
+        # a dask block under the device-resident reduction (multigpu.reduce_partials): only host inputs cross PCIe, the
+        # partial histogram stays on its GPU.  (A DeviceArray block outside that reduction: downloaded below.)
         out_dtype = np.float64 if weighted else np.int64
-        buf = _native.DeviceBuffer(device, int(np.prod(out_shape, dtype=np.int64)) * 8)
+        buf = _native.DeviceBuffer(device, n_out * 8)
         out = _native.DevicePartial(buf, out_shape, out_dtype)
         out_ptr = buf.ptr
-        mem = _native.MEM_HOST_TO_DEVICE
+        if backend == "numpy":
+            mem = _native.MEM_HOST_TO_DEVICE
         empty = False
-    elif backend == "numpy":
+    elif backend != "torch":
         out = np.empty(out_shape, dtype=np.float64 if weighted else np.int64)
         out_ptr = out.ctypes.data
         empty = out.size == 0
@@ -308,6 +336,8 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
             accumulate=False,
             stream=stream,
         )
+    if backend == "device" and not device_partial:
+        return out.to_numpy()  # DeviceArray in, numpy histogram out (the result is small; the data never moved)
     return out
 
 
@@ -323,7 +353,7 @@ def _bincount_2d_vectorized(*args, bins=None, weights=None, density=False, right
     temporaries that do not exist here, and never changes the result.
     """
     a0 = args[0]
-    backend = "torch" if _is_torch(a0) else "numpy"
+    backend = _backend_of(args)
     for a, b in zip(args, bins):  # core.py:146-151
         assert a.ndim == 2
         assert np.ndim(b) == 1
@@ -344,8 +374,10 @@ def _prepare_dtypes(args, weights, dtypes, bins, backend):
     """dtype-level preparation shared by every entry: datetime64 inputs are brought to the unit
     they share with their edges (and later viewed as int64), complex weights are rejected like
     numpy's bincount does"""
-    if backend == "numpy":
+    if backend in ("numpy", "device"):
         _, _, common = _compare_domain(dtypes, bins)
+        if backend == "device" and any(c is not None and a.dtype != c for a, c in zip(args, common)):
+            raise TypeError("datetime64 DeviceArrays must already have the unit they share with their bin edges")
         args = [a.astype(c) if c is not None and a.dtype != c else a for a, c in zip(args, common)]
         if weights is not None and weights.dtype.kind == "c":
             raise TypeError("Cannot cast array data from complex to float64 (weights)")  # numpy bincount
@@ -370,6 +402,12 @@ def _rows_cols(a, axis, do_full_array):
         for k in keep:
             m *= int(k)
         return moved.reshape(m, -1)
+    if _is_devarr(a):
+        if do_full_array:
+            return a.reshape(1, -1)
+        moved = a.moveaxis(tuple(axis), tuple(_range(-len(axis), 0)))
+        m = int(np.prod(moved.shape[: moved.ndim - len(axis)], dtype=np.int64))
+        return moved.reshape(m, (a.size // m) if m else 0)  # a view where the strides allow it, else one device copy
     if do_full_array:
         moved, m = a, 1
     else:
@@ -456,6 +494,10 @@ def _view_of(a, desc, backend, both_strided_limit=1 << 16):
         if rs > 1 and cs > 1 and m * c >= both_strided_limit:
             return None  # strided both ways: every lane would touch its own cache line
         return a.data_ptr(), _torch_tag(a.dtype), rs, cs, ir, os_, a
+    if backend == "device":
+        if rs > 1 and cs > 1 and m * c >= both_strided_limit:
+            return None
+        return a.ptr, _native.dtype_tag(np.dtype(np.int64) if a.dtype.kind in "mM" else a.dtype), rs, cs, ir, os_, a
     if not a.dtype.isnative:
         return None
     if a.dtype.kind in "mM":
@@ -501,8 +543,9 @@ def _promote_for_big_histograms(arrays, w_array, dtypes, bins, backend="torch"):
         return arrays, w_array, dtypes  # let the regular path raise what it raises
     if cmp_domain != _native.CMP_F64 or d > 3:
         return arrays, w_array, dtypes  # exact int64 / datetime comparisons stay exact
-    if backend == "numpy":
-        # host inputs: the conversion is a host pass (numpy), still far cheaper than ~2.5 x 10^10 atomics per second
+    if backend in ("numpy", "device"):
+        # host inputs: the conversion is a host pass (numpy), still far cheaper than ~2.5 x 10^10 atomics per second;
+        # DeviceArrays: one strided-copy kernel with the conversion in it (DeviceArray.astype)
         if not vector_ok:
             arrays = [a if a.dtype == np.float64 else a.astype(np.float64) for a in arrays]
             dtypes = [np.dtype(np.float64)] * d
@@ -517,13 +560,19 @@ def _promote_for_big_histograms(arrays, w_array, dtypes, bins, backend="torch"):
     return arrays, w_array, dtypes
 
 
+def _block_placement(all_arrays, multigpu):
+    """where one dask block runs: on the GPU its chunks already live on (DeviceArray chunks), else on the least busy one"""
+    resident = next((a for a in all_arrays if _is_devarr(a)), None)
+    return multigpu.block_device() if resident is None else multigpu.on_device(resident.device)
+
+
 def _bincount_spread(*all_arrays, **kwargs):
     """One dask block (core.py:429-437): the block adapter on whichever of the node's GPUs has the fewest
     blocks in flight — dask's threaded scheduler runs many blocks at once, and each one is staged over
     its own GPU's PCIe link and binned there (multigpu.block_device)."""
     from . import multigpu
 
-    with multigpu.block_device():
+    with _block_placement(all_arrays, multigpu):
         return _bincount(*all_arrays, **kwargs)
 
 
@@ -532,7 +581,7 @@ def _bincount_partial(*all_arrays, **kwargs):
     _native.DevicePartial on the block's GPU (only the inputs cross PCIe)."""
     from . import multigpu
 
-    with multigpu.block_device():
+    with _block_placement(all_arrays, multigpu):
         prev = getattr(_tls, "device_out", False)
         _tls.device_out = True
         try:
@@ -550,9 +599,14 @@ def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, bl
     trailing axes), the block is DESCRIBED to the native library as a strided [rows, cols] view —
     broadcast inputs, leading-axis and middle-axis reductions included — and only layouts no
     three strides can express fall back to that copy."""
+    backend = _backend_of(all_arrays)
+    if backend == "device":
+        # a dask block: chunks that live on a GPU next to host chunks (weights from a numpy-backed dask array) — the
+        # host ones follow the resident ones to their GPU
+        dev = next(a.device for a in all_arrays if _is_devarr(a))
+        all_arrays = [a.to(dev) if _is_devarr(a) else DeviceArray.from_numpy(a, dev) for a in all_arrays]
     a0 = all_arrays[0]
     ndim = a0.ndim
-    backend = "torch" if _is_torch(a0) else "numpy"
     do_full_array = (axis is None) or (set(axis) == set(_range(ndim)))
     if do_full_array:
         kept_axes_shape = (1,) * ndim
@@ -574,7 +628,7 @@ def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, bl
     counts = None
     order = _reduced_order(arrays[0], list(_range(ndim)) if do_full_array else axis)
     descs = [_collapse(a, axis, do_full_array, order) for a in arrays + w_list]
-    if backend == "torch" and _beyond_lds(bins, weights) and any(d is not None and d[1] > 1 and d[3] != 1 for d in descs):
+    if backend != "numpy" and _beyond_lds(bins, weights) and any(d is not None and d[1] > 1 and d[3] != 1 for d in descs):
         # columns that are not unit-stride (strided or broadcast views, leading-axis reductions) go to kernels that
         # keep their histogram in LDS or, beyond it, in memory-side atomics: for a big histogram the reference's
         # copy into [rows, cols] blocks (core.py:211-229), made on the device, is far cheaper than those atomics
@@ -641,20 +695,23 @@ def _device_bin_edges(a, b, r, has_weights):
     (reduced on the GPU, NaN-propagating like numpy) and its dtype; string estimators need the
     data itself and take the slow path through host memory."""
     proto_dtype = _np_dtype_of(a)
+    resident = _is_devarr(a)
     if isinstance(b, str):
         if has_weights:
             raise TypeError("Automated estimation of the number of bins is not supported for weighted data")
-        return np.histogram_bin_edges(a.detach().cpu().numpy(), bins=b, range=r)
+        return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
-        if a.numel() == 0:
+        if (a.size if resident else a.numel()) == 0:
             return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=None)
         flat = a.reshape(1, -1)
-        ptr, tag, rs, cs, _ir, _os, keep = _strided_view(flat, "torch")
-        torch = _torch()
-        dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
-        lo, hi = _native.minmax(
-            _native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev, torch.cuda.current_stream(dev).cuda_stream
-        )
+        ptr, tag, rs, cs, _ir, _os, keep = _strided_view(flat, "device" if resident else "torch")
+        if resident:
+            dev, stream = a.device, 0
+        else:
+            torch = _torch()
+            dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        lo, hi = _native.minmax(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev, stream)
         return np.histogram_bin_edges(np.array([lo, hi]).astype(proto_dtype), bins=b, range=None)
     return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=r)
 
@@ -1029,6 +1086,13 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         all_arrays = [a.to(dev) if _is_torch(a) else torch.as_tensor(np.asarray(a)).to(dev) for a in all_arrays]
         w_raw = all_arrays[n_inputs] if has_weights else None  # as given, before broadcasting
         all_arrays = list(torch.broadcast_tensors(*all_arrays))
+    elif any(_is_devarr(a) for a in all_arrays):
+        backend = "device"
+        dev = next(a.device for a in all_arrays if _is_devarr(a))
+        all_arrays = [a.to(dev) if _is_devarr(a) else DeviceArray.from_numpy(np.asarray(a), dev) for a in all_arrays]
+        w_raw = all_arrays[n_inputs] if has_weights else None
+        shape = np.broadcast_shapes(*[a.shape for a in all_arrays])
+        all_arrays = [a.broadcast_to(shape) for a in all_arrays]
     else:
         backend = "numpy"
         all_arrays = [np.asarray(a) for a in all_arrays]
@@ -1042,7 +1106,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     if backend == "dask":
         if not all(isinstance(b, np.ndarray) for b in bins):
             raise TypeError("When using dask arrays, bins must be provided as numpy array(s) of edges")
-    elif backend == "torch":
+    elif backend in ("torch", "device"):
         bins = [_device_bin_edges(a, b, r, has_weights) for a, b, r in zip(all_arrays, bins, range)]
     else:
         w_for_edges = all_arrays[n_inputs] if has_weights else None

@@ -358,6 +358,120 @@ extern "C" int xhist_buffer_add(int device, void* dst, const void* src, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// strided N-D copies between device buffers (blocks of a device-resident dask array: slices, concatenations of
+// unaligned chunks, the reference's moveaxis + reshape copy of core.py:218-226 where no three strides describe the
+// block), optionally converting to float64 on the way (numpy's promotion inside searchsorted, core.py:170)
+// ------------------------------------------------------------------------------------------
+struct NdCopy {
+  int32_t ndim;        // >= 1 after normalisation
+  int64_t shape[8];
+  int64_t ss[8];       // source strides, bytes (0 and negative allowed)
+  int64_t ds[8];       // destination strides, bytes
+};
+
+template <int ITEM>  // bytes per element of a raw copy; 0: convert src_dt -> float64
+__global__ void __launch_bounds__(256) copy_nd_kernel(const char* __restrict__ src, char* __restrict__ dst, NdCopy nd, int wlog2,
+                                                      int64_t rows, int64_t col_tiles, int32_t src_dt) {
+  // a workgroup covers (256 >> wlog2) rows x (16 << wlog2) elements of the innermost dimension per step
+  const int last = nd.ndim - 1;
+  const int64_t inner = nd.shape[last], ss_in = nd.ss[last], ds_in = nd.ds[last];
+  const int rows_per_wg = 256 >> wlog2;
+  const int64_t row_groups = (rows + rows_per_wg - 1) / rows_per_wg;
+  for (int64_t t = blockIdx.x; t < row_groups * col_tiles; t += gridDim.x) {
+    const int64_t rg = t / col_tiles, ct = t - rg * col_tiles;
+    const int64_t row = rg * rows_per_wg + (threadIdx.x >> wlog2);
+    if (row >= rows) continue;
+    int64_t rem = row, so = 0, dof = 0;
+    for (int k = last - 1; k >= 0; --k) {
+      const int64_t q = rem / nd.shape[k], idx = rem - q * nd.shape[k];
+      rem = q;
+      so += idx * nd.ss[k];
+      dof += idx * nd.ds[k];
+    }
+    const int64_t c0 = (ct << (wlog2 + 4)) + (threadIdx.x & ((1 << wlog2) - 1));
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int64_t c = c0 + ((int64_t)j << wlog2);
+      if (c >= inner) break;
+      const char* s = src + so + c * ss_in;
+      char* d = dst + dof + c * ds_in;
+      if constexpr (ITEM == 0) *reinterpret_cast<double*>(d) = load_as<double>(s, src_dt, 0);
+      else if constexpr (ITEM == 8) *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s);
+      else if constexpr (ITEM == 4) *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s);
+      else if constexpr (ITEM == 2) *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s);
+      else *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s);
+    }
+  }
+}
+
+extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, const void* src, int src_dtype,
+                                    const int64_t* src_strides, void* dst, int dst_dtype, const int64_t* dst_strides, void* stream) {
+  if (ndim < 0 || ndim > 8) return fail(XHIST_ERR_INVALID, "copy_nd takes 0..8 dimensions, got %d", ndim);
+  if (ndim && (!shape || !src_strides || !dst_strides)) return fail(XHIST_ERR_INVALID, "shape / strides is NULL");
+  const int item = dtype_size(src_dtype);
+  if (!item || !dtype_size(dst_dtype)) return fail(XHIST_ERR_INVALID, "unknown dtype tag %d / %d", src_dtype, dst_dtype);
+  const bool convert = dst_dtype != src_dtype;
+  if (convert && dst_dtype != XHIST_F64) return fail(XHIST_ERR_UNSUPPORTED, "copy_nd converts to float64 only");
+  int64_t n = 1;
+  for (int k = 0; k < ndim; ++k) {
+    if (shape[k] < 0) return fail(XHIST_ERR_INVALID, "negative extent");
+    n *= shape[k];
+  }
+  if (n == 0) return XHIST_OK;
+  if (!src || !dst) return fail(XHIST_ERR_INVALID, "src / dst is NULL");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available", device);
+  // drop extent-1 dimensions, merge neighbours that walk both sides like one dimension
+  NdCopy nd{};
+  for (int k = 0; k < ndim; ++k) {
+    if (shape[k] == 1) continue;
+    const int m = nd.ndim;
+    if (m && nd.ss[m - 1] == src_strides[k] * shape[k] && nd.ds[m - 1] == dst_strides[k] * shape[k]) {
+      nd.shape[m - 1] *= shape[k];
+      nd.ss[m - 1] = src_strides[k];
+      nd.ds[m - 1] = dst_strides[k];
+    } else {
+      nd.shape[m] = shape[k];
+      nd.ss[m] = src_strides[k];
+      nd.ds[m] = dst_strides[k];
+      nd.ndim = m + 1;
+    }
+  }
+  if (nd.ndim == 0) { nd.ndim = 1; nd.shape[0] = 1; nd.ss[0] = 0; nd.ds[0] = 0; }
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  const int64_t inner = nd.shape[nd.ndim - 1], rows = n / inner;
+  int wlog2 = 0;
+  while (wlog2 < 8 && ((int64_t)1 << wlog2) < inner) ++wlog2;
+  const int64_t col_tiles = (inner + ((int64_t)16 << wlog2) - 1) / ((int64_t)16 << wlog2);
+  const int rows_per_wg = 256 >> wlog2;
+  const int64_t tiles = ((rows + rows_per_wg - 1) / rows_per_wg) * col_tiles;
+  const int grid = (int)std::min<int64_t>(tiles, 256 * 32);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* sp = static_cast<const char*>(src);
+  char* dp = static_cast<char*>(dst);
+#define XHIST_COPY_ND(ITEM) hipLaunchKernelGGL((copy_nd_kernel<ITEM>), dim3(grid), dim3(256), 0, s, sp, dp, nd, wlog2, rows, col_tiles, (int32_t)src_dtype)
+  if (convert) XHIST_COPY_ND(0);
+  else if (item == 8) XHIST_COPY_ND(8);
+  else if (item == 4) XHIST_COPY_ND(4);
+  else if (item == 2) XHIST_COPY_ND(2);
+  else XHIST_COPY_ND(1);
+#undef XHIST_COPY_ND
+  HIPC(hipGetLastError());
+  return XHIST_OK;
+}
+
+extern "C" int xhist_pointer_device(const void* ptr, int* device) {
+  if (!ptr || !device) return fail(XHIST_ERR_INVALID, "ptr / device is NULL");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return fail(XHIST_ERR_INVALID, "%p is not device memory of this process", ptr);
+  }
+  *device = attr.device;
+  return XHIST_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // min / max
 // ------------------------------------------------------------------------------------------
 extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result, int mem_kind,
