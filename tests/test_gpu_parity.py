@@ -615,6 +615,87 @@ def test_partitioned_mode_tiny_and_ragged_inputs(xh):
             assert_hist_equal(got, onp.bincount_rows([x, y], edges, ww), ww is not None)
 
 
+def test_partitioned_mode_packed_records_one_sign(xh):
+    """float64 weights of one sign travel as 8-byte records (36 mantissa bits + the bin code): within 2^-37 per weight of the
+    full-float64 records, and both inside the 1e-6 contract against the oracle"""
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    rng = np.random.default_rng(60)
+    n = 3_000_001
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    for w in (rng.uniform(0, 1, (1, n)), -rng.uniform(0, 1e300, (1, n)), rng.uniform(0, 1, (1, n)) * 1e-300,
+              np.abs(rng.standard_normal((1, n))).astype(np.float64) + 0.0):
+        want = onp.bincount_rows([x, y], edges, w)
+        packed, desc = _run(xh, [x, y], edges, w, True, partition=1)
+        assert "records=packed48" in desc, desc
+        exact, desc = _run(xh, [x, y], edges, w, True, partition=1, records48=-1)
+        assert "records=u16+f64" in desc, desc
+        assert_hist_equal(packed, want, True)
+        assert_hist_equal(exact, want, True)
+        np.testing.assert_allclose(packed, exact, rtol=2.0 ** -36, atol=0)
+
+
+def test_partitioned_mode_packed_records_fall_back_on_mixed_signs(xh):
+    """weights of both signs: the packed attempt is discarded ON THE GPU and the exact pass of the same call produces the result
+    (weights that cancel would turn 2^-37 per weight into anything per bin); the plan remembers and later calls go straight
+    to exact records"""
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    rng = np.random.default_rng(61)
+    n = 2_500_003
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    w = rng.standard_normal((1, n)) * 1e6
+    w[0, 1::2] = -w[0, ::2][: w[0, 1::2].size] * (1 + 1e-9)  # pairs that nearly cancel wherever they share a bin
+    want = onp.bincount_rows([x, y], edges, w)
+    exact, _ = _run(xh, [x, y], edges, w, True, partition=1, records48=-1)
+    first, desc = _run(xh, [x, y], edges, w, True, partition=1, records48=0)  # (setting the knob forgets earlier calls)
+    assert "records=packed48(+exact" in desc, desc
+    np.testing.assert_allclose(first, exact, rtol=1e-9, atol=1e-3)  # same records, another order of the atomics
+    scale = np.abs(w).max()
+    np.testing.assert_allclose(first, want, rtol=1e-6, atol=1e-9 * scale)
+    # one negative weight among positive ones is enough
+    w2 = rng.uniform(0, 1, (1, n))
+    w2[0, 12345] = -0.25
+    got, _ = _run(xh, [x, y], edges, w2, True, partition=1, records48=0)
+    ex2, _ = _run(xh, [x, y], edges, w2, True, partition=1, records48=-1)
+    np.testing.assert_allclose(got, ex2, rtol=1e-12, atol=0)
+    # the plan remembers: without touching the knob, the next call does not try packed records
+    plan = _plan_for(xh, [_dev(x), _dev(y)], edges)
+    plan.set_param("partition", 1)
+    try:
+        xh._bincount_2d_vectorized(_dev(x), _dev(y), bins=edges, weights=_dev(w2))
+        torch.cuda.synchronize()
+        again = xh._bincount_2d_vectorized(_dev(x), _dev(y), bins=edges, weights=_dev(w2)).cpu().numpy()
+        assert "records=u16+f64" in plan.describe(), plan.describe()
+    finally:
+        plan.set_param("partition", 0)
+        plan.set_param("records48", 0)
+    np.testing.assert_allclose(again, ex2, rtol=1e-12, atol=0)
+
+
+def test_partitioned_mode_packed_records_special_weights(xh):
+    """NaN poisons its own bin only (whatever its payload), infinities stay infinities, the largest finite weight does not round
+    up to infinity, -0.0 and denormals are harmless, a NaN weight on a dropped sample is dropped with it"""
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    rng = np.random.default_rng(62)
+    n = 1_000_003
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    w = rng.uniform(0, 1, (1, n))
+    w[0, 10] = np.nan
+    w[0, 11] = np.frombuffer(np.uint64(0x7FF0000000000001).tobytes(), np.float64)[0]  # NaN whose payload sits in the low 16 bits
+    w[0, 12] = np.inf
+    w[0, 13] = np.finfo(np.float64).max
+    w[0, 14] = 5e-324
+    w[0, 15] = 0.0
+    x[0, 16], w[0, 16] = 9.0, np.nan  # out of range: dropped, weight and all
+    x[0, 17], w[0, 17] = np.nan, -1.0  # dropped: its sign does not count
+    want = onp.bincount_rows([x, y], edges, w)
+    got, desc = _run(xh, [x, y], edges, w, True, partition=1, records48=0)
+    assert "records=packed48" in desc, desc
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    assert np.isnan(got).sum() == len({(np.searchsorted(edges[0], x[0, i], "right"), np.searchsorted(edges[1], y[0, i], "right")) for i in (10, 11)})
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
 def test_per_input_compare_domains_datetime_and_int64_next_to_floats(xh, resident):
     """a time axis (datetime64 / int64, compared exactly) against a float axis, as numpy does per argument"""

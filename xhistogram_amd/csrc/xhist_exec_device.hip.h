@@ -178,12 +178,28 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
 // part_accumulate_chunks, all on `stream`.  Returns XHIST_ERR_UNSUPPORTED (nothing launched) for what only
 // the multi-pass form takes: more than 128 partitions, tables that do not fit LDS next to the sort buffers,
 // in-bucket scans of 3 or 4 edges, integer samples.
+static bool exact_records_env() {
+  static const bool v = [] { const char* e = getenv("XHIST_AMD_EXACT_RECORDS"); return e && *e && *e != '0'; }();
+  return v;
+}
+
 static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan) {
   if (sdt == XHIST_F64) return xhist_pick_route_f64(wdt, D, scan);
   if (sdt == XHIST_F32) return xhist_pick_route_f32(wdt, D, scan);
   return nullptr;
 }
 
+//
+// Packed records (float64 weights).  A record is normally a 16-bit bin code plus the float64 weight: 10 bytes in two streams.
+// Rounding the weight to 36 mantissa bits makes room for the code in its low 16 bits: ONE 8-byte record, 40 instead of 44
+// bytes of traffic per C5 sample.  The rounding is 2^-37 = 7.3e-12 relative per weight, so a bin's sum is off by at most
+// 7.3e-12 x sum|w| — five orders inside the 1e-6 contract as long as sum|w| is comparable to |sum w|, i.e. as long as the
+// weights of a bin do not cancel.  That is guaranteed when all weights have one sign, which the routing pass learns for free
+// while it reads them.  So: route with packed records and note the signs seen (on the GPU); the packed adding-up pass runs only
+// if one sign was seen; if both were, an exact routing + adding-up pass — queued behind, and returning at once otherwise —
+// redoes the work with full float64 records.  Every decision is taken on the GPU (no host synchronisation: the call stays
+// asynchronous); the plan remembers mixed signs through a pinned host word the exact pass sets, and later calls skip the
+// packed attempt.  "records48" = -1 or XHIST_AMD_EXACT_RECORDS=1 turn packing off.
 static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
                                      hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
                                      int n_parts, int profile, LaunchRecord& rec, bool first, bool last) {
@@ -192,6 +208,18 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   if (n_cols >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
   kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
+  bool pack = weighted && wdt == XHIST_F64 && p->records48_pref >= 0 && !exact_records_env();
+  if (pack && !p->mixed_hint) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->mixed_hint) {
+      uint32_t* h = nullptr;
+      if (hipHostMalloc((void**)&h, 64, hipHostMallocDefault) == hipSuccess) { *h = 0u; p->mixed_hint = h; }
+      else (void)hipGetLastError();
+    }
+  }
+  if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
+  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan) : nullptr;
+  if (pack && !k_route48) pack = false;
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
   const int tile = route_tile(dtype_size(sdt));
   const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile);
@@ -231,8 +259,8 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     hipError_t e_ = (expr);                                                                            \
     if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
   } while (0)
-  const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [2 .. 2 + P) chunks filed per partition
-  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8, stream));
+  const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [1] signs seen, [2 .. 2 + P) chunks filed per partition; two sets
+  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8 * 2, stream));
   HIPR(scratch_malloc((void**)&d_plist, (size_t)n_parts * pool_chunks * 4, stream));
   HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
   HIPR(scratch_malloc((void**)&d_codes, ((size_t)pool_chunks << lg) * 2, stream));
@@ -274,6 +302,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   ra.wrec = d_w;
   ra.list_cap = (uint32_t)pool_chunks;
   ra.chunk_log2 = lg;
+  ra.flags = d_ctr + 1;
+  ra.gate = nullptr;
+  ra.hint = nullptr;
+  ra.gate_mode = 0;
 
   if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
   kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
@@ -283,18 +315,38 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
 
   if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
     if (int rrc = rec.begin(profile)) return release(rrc);
-  if (int zrc = zero_output(d_ctr, ctr_words, stream)) return release(zrc);
+  if (int zrc = zero_output(d_ctr, ctr_words * 2, stream)) return release(zrc);
+  if (pack) {
+    kernel_fn_acc_chunks k_acc48 = (kernel_fn_acc_chunks)part_accumulate_chunks<true, double, true>;
+    if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
+    if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+    hipLaunchKernelGGL(k_route48, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);  // packed records, notes the signs
+    HIPR(hipGetLastError());
+    RouteArgs ra48 = ra;
+    ra48.gate = d_ctr + 1;
+    ra48.gate_mode = 1;  // one sign: add the packed records up
+    hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, stream, ra48, out, p->n_bins, shift, n_parts);
+    HIPR(hipGetLastError());
+    // both signs: the exact pass below runs (its own counters: the second set), otherwise its kernels return at once
+    ra.pool = d_ctr + 2 * ctr_words;
+    ra.pcount = ra.pool + 2;
+    ra.flags = ra.pool + 1;
+    ra.gate = d_ctr + 1;
+    ra.gate_mode = 2;
+    ra.hint = p->mixed_hint;
+  }
   hipLaunchKernelGGL(k_route, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts);
   HIPR(hipGetLastError());
   {
-    char desc[384];
+    char desc[512];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
              n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
-             (int)weighted, D, use_f32 ? "f32thr" : "f64");
+             (int)weighted, D, use_f32 ? "f32thr" : "f64",
+             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }

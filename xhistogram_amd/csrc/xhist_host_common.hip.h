@@ -315,6 +315,8 @@ struct xhist_plan {
   int force_generic = 0;
   int partition = 0;  // 0 auto, 1 prefer the partitioned mode whenever it is legal, -1 never
   int fused_pref = 0;  // partitioned mode: 0 one routing pass where it applies, -1 always count + prefix + scatter
+  int records48_pref = 0;  // routing pass, float64 weights: 0 packed 8-byte records while the weights have one sign, -1 never
+  uint32_t* mixed_hint = nullptr;  // pinned host word the GPU sets when a call met weights of both signs (see execute_partitioned_fused)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never
   int arith_pref = 0;  // 0 auto, 1 table-free digitize whenever the edges are arithmetic, -1 never
   int lanes = 0;      // 0 auto, 1 prefer the row-per-lane kernels whenever they are legal, -1 never

@@ -169,6 +169,8 @@ static kernel_fn mixed_pick_ds(int D, int scan) {
 // ------------------------------------------------------------------------------------------
 // one-pass routing of the partitioned mode (xhist_route.hip.h): binary search, <= 2 edges per bucket, or
 // arithmetic edges; up to three inputs; any of the three weight kinds
+constexpr int kWdtPacked48 = 0x100 | XHIST_F64;  // float64 weights, packed 8-byte records (xhist_route.hip.h)
+
 template <typename ST, typename WT>
 static kernel_fn_route route_pick_ds(int D, int scan) {
 #define XH_ROUTE_CASE(DD)                                                        \
@@ -192,6 +194,7 @@ static kernel_fn_route route_pick(int wdt, int D, int scan) {
   if (wdt == -1) return route_pick_ds<ST, NoWeight>(D, scan);
   if (wdt == XHIST_F64) return route_pick_ds<ST, double>(D, scan);
   if (wdt == XHIST_F32) return route_pick_ds<ST, float>(D, scan);
+  if (wdt == kWdtPacked48) return route_pick_ds<ST, Packed48>(D, scan);
   return nullptr;
 }
 

@@ -330,6 +330,7 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
       for (auto& t : dom)
         if (t.blob) (void)hipFree(t.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (p->mixed_hint) (void)hipHostFree(p->mixed_hint);
   }
   delete p;
   return XHIST_OK;
@@ -353,6 +354,9 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->n_seen = 0;
   } else if (!strcmp(key, "fused")) {
     p->fused_pref = value < 0 ? -1 : 0;
+  } else if (!strcmp(key, "records48")) {
+    p->records48_pref = value < 0 ? -1 : 0;
+    if (p->mixed_hint) *p->mixed_hint = 0u;  // (setting the knob also forgets what earlier calls saw)
   } else if (!strcmp(key, "partition")) {
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lanes")) {

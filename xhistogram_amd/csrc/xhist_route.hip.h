@@ -7,7 +7,7 @@
 // 8192-sample tile by partition in LDS and writes the records; a second one adds them up.
 //
 //   part_route              reads x (, y, z), w: 24 B/sample (C5); writes (code u16, weight) records:
-//                           10 B/sample, into chunks of 2^chunk_log2 records that belong to ONE
+//                           10 B/sample (8 when packed, see below), into chunks of 2^chunk_log2 records that belong to ONE
 //                           (workgroup, partition) pair — no other workgroup writes there, so record
 //                           addresses need no atomics; a lane that owns a partition takes a new chunk
 //                           id from a global counter when its chunk is full (one atomic per chunk,
@@ -22,8 +22,15 @@
 // writes 5 GB runs at 4.8-5.1 TB/s on this chip and reading 5 GB back takes 0.86 ms more, whatever the
 // chunk size and whether or not the records would fit the 256 MiB Infinity Cache
 // (tools/ubench/mall.hip, profiles/r02_a_mall.jsonl: 4.1-4.6 ms for the bare traffic of a 5*10^8-sample
-// shard).  Records keep the caller's float64 weights: 32-bit or 48-bit record weights would save
-// 4-8 B/sample but put the 1e-6 contract at the mercy of cancellation between weights of both signs.
+// shard).
+//
+// Packed records.  float64 weights of ONE sign travel as 8-byte records — the weight's upper 48 bits with the bin
+// code in the 16 that go (2^-36 relative per weight, and no cancellation to amplify it): 24 + 8 + 8 = 40 B per sample,
+// one record stream instead of two.  Weights of both signs keep full float64 records; which case a call is in is found
+// out by the routing pass itself and acted on by the GPU (execute_partitioned_fused in xhist_exec_device.hip.h).
+// Measured on C5 shards: the adding-up pass 0.83 -> 0.71 ms, the routing pass 3.5-3.66 ms where the two-stream form
+// takes 3.57 in one process and 4.15 in the next on the same box (its five streams are sensitive to where the driver
+// places the buffers; four streams are not: profiles/r02_u_records48.jsonl).
 //
 // The LDS sort, the aligned 16-byte record groups and the records carried from tile to tile are those
 // of part_scatter (xhist_partition.hip.h), which documents them.
@@ -53,6 +60,21 @@ __host__ __device__ constexpr int route_batch(int P, int chunk_log2, int tile) {
   return 2 * P > 8 * route_max_need(chunk_log2, tile) ? 2 * P : 8 * route_max_need(chunk_log2, tile);
 }
 
+// float64 weights whose records carry 48 bits (sign, exponent, 36 mantissa bits) next to the 16-bit code: ONE 8-byte
+// record per sample instead of 2 + 8 bytes in two streams (see "packed records" below)
+struct Packed48 {};
+
+// weight truncated to its upper 48 bits (sign, exponent, 36 mantissa bits: 2^-36 relative, towards zero), low 16 bits = the bin
+// code: one v_and_or_b32 on the low word.  A NaN whose payload sits only in the bits that go would turn into an infinity: NaNs
+// get their quiet bit set first.
+__device__ __forceinline__ double pack48(double w, uint32_t code) {
+  const uint64_t b = (uint64_t)__double_as_longlong(w);
+  uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+  hi = (w != w) ? (hi | 0x00080000u) : hi;
+  lo = (lo & 0xffff0000u) | code;
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 struct RouteArgs {
   uint32_t* pool;       // [0]: next unused chunk id
   uint32_t* pcount;     // [P]: chunk ids filed per partition
@@ -62,7 +84,20 @@ struct RouteArgs {
   void* wrec;           // [pool_chunks << chunk_log2]: weight (float64, or float32 for float32 weights)
   uint32_t list_cap;    // = chunks in the pool
   int32_t chunk_log2;
+  // packed records: the routing pass ORs into *flags which signs the weights of the kept samples had (1 negative,
+  // 2 positive); kernels with gate_mode != 0 return at once unless (*gate says both signs) == (gate_mode == 2);
+  // a gate_mode-2 routing pass that does run leaves 1 in *hint (host memory: the plan's memory of mixed signs)
+  uint32_t* flags;
+  const uint32_t* gate;
+  uint32_t* hint;
+  int32_t gate_mode;
 };
+
+__device__ __forceinline__ bool route_gate_closed(const RouteArgs& ra) {
+  if (ra.gate_mode == 0) return false;
+  const bool mixed = (__builtin_nontemporal_load(ra.gate) & 3u) == 3u;
+  return (ra.gate_mode == 2) != mixed;
+}
 
 __host__ __device__ constexpr int part_route_slots(int P, int tile) { return tile + 2 * (kRouteGrp - 1) * P + kRouteGrp; }
 __host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted, int tile) {
@@ -104,9 +139,10 @@ __device__ __forceinline__ uint32_t route_take_ids(uint32_t* a, uint32_t need) {
 template <typename ST, typename WT, int D, int SCAN>
 __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const RouteArgs ra) {
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  constexpr bool PACK = __is_same(WT, Packed48);
   constexpr int CMP = (__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
-  using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  using wscalar = typename std::conditional<kWeighted, typename std::conditional<PACK, double, WT>::type, float>::type;
   using RT = typename std::conditional<__is_same(WT, float), float, double>::type;  // record weights keep the caller's precision
   constexpr int RV = 16 / (int)sizeof(RT);
   typedef RT rvec __attribute__((ext_vector_type(RV)));
@@ -117,10 +153,13 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
   typedef ST s4 __attribute__((ext_vector_type(4), aligned(sizeof(ST))));
   typedef wscalar w4 __attribute__((ext_vector_type(4), aligned(sizeof(wscalar))));
 
+  if (route_gate_closed(ra)) return;
   const int tid = threadIdx.x;
   const int P = p.n_parts, shift = p.part_shift, lg = ra.chunk_log2;
   const uint32_t CH = 1u << lg;
   const int64_t n = p.n_cols;
+  if (ra.gate_mode == 2 && blockIdx.x == 0 && tid == 0 && ra.hint) *ra.hint = 1u;
+  double w_lo = 0.0, w_hi = 0.0;  // smallest / largest weight this lane read (packed records: which signs occur)
   const uint64_t* tab = stage_tables(p);
   unsigned char* ctl = xhist_smem + (((size_t)p.table_words * 8 + 15) & ~(size_t)15);
   uint32_t* cnt2 = reinterpret_cast<uint32_t*>(ctl);            // [2][256] rank counters, alternating per tile
@@ -339,8 +378,16 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
           const uint32_t part = flat[u][v] >> shift;
           const uint32_t slot = first[part] + rank[u][v];
           skey[slot] = (part << 16) | (flat[u][v] & code_mask);
-          if (kWeighted) sw[slot] = (RT)wu[v];
+          if constexpr (PACK) sw[slot] = pack48((double)wu[v], flat[u][v] & code_mask);
+          else if constexpr (kWeighted) sw[slot] = (RT)wu[v];
         }
+      if constexpr (PACK) {  // signs of every weight read, dropped samples included (zeros, NaNs and the ragged tail's fill are neutral)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          w_lo = fmin(w_lo, (double)wu[v]);
+          w_hi = fmax(w_hi, (double)wu[v]);
+        }
+      }
     }
     for (int t = tid; t < P * GRP; t += blockDim.x) {  // the carried records go to the head of their block
       const int q = t / GRP, i = t % GRP;
@@ -371,10 +418,12 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
       const uint32_t q = kk[0] >> 16;
       if (g0 + GRP <= endw[q]) {
         const uint64_t dst = (g0 < split[q] ? delta[q] : delta2[q]) + g0;
-        u4 c4;
+        if constexpr (!PACK) {
+          u4 c4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c4[i] = (kk[2 * i] & 0xffffu) | (kk[2 * i + 1] << 16);
-        __builtin_nontemporal_store(c4, reinterpret_cast<u4*>(codes + dst));
+          for (int i = 0; i < 4; ++i) c4[i] = (kk[2 * i] & 0xffffu) | (kk[2 * i + 1] << 16);
+          __builtin_nontemporal_store(c4, reinterpret_cast<u4*>(codes + dst));
+        }
       } else {
         const uint32_t left = enda[q] - g0;  // 1 .. GRP-1 records: the carry
 #pragma unroll
@@ -437,8 +486,8 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
       }
       for (int i = 0; i < GRP; ++i) {
         const bool real = (uint32_t)i < my_carry;
-        codes[cur + i] = real ? (uint16_t)(carry_key[tid * GRP + i] & 0xffffu) : (uint16_t)(kWeighted ? 0u : (1u << shift));
-        if (kWeighted) wrec[cur + i] = real ? carry_w[tid * GRP + i] : (RT)0;
+        if constexpr (!PACK) codes[cur + i] = real ? (uint16_t)(carry_key[tid * GRP + i] & 0xffffu) : (uint16_t)(kWeighted ? 0u : (1u << shift));
+        if (kWeighted) wrec[cur + i] = real ? carry_w[tid * GRP + i] : (RT)0;  // (packed: +0.0 for bin 0)
       }
       cur += GRP;
     }
@@ -453,13 +502,18 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
       }
     }
   }
+  if constexpr (PACK) {
+    const uint32_t signs = (__ballot(w_lo < 0.0) ? 1u : 0u) | (__ballot(w_hi > 0.0) ? 2u : 0u);
+    if ((tid & 63) == 0 && signs) atomicOr(ra.flags, signs);
+  }
 }
 
 // The adding-up pass over chunk lists.  Chunk k of the concatenation of all partitions' lists belongs to the
 // partition whose offset range holds k; every workgroup takes an equal range of k.  Chunks hold whole
 // groups of 8 records and start 2^chunk_log2-aligned, so every load is an aligned quad.
-template <bool WEIGHTED, typename RT = double>
+template <bool WEIGHTED, typename RT = double, bool PACK = false>
 __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs ra, void* out_v, int64_t n_bins, int shift, int P) {
+  if (route_gate_closed(ra)) return;
   using lds_t = typename std::conditional<WEIGHTED, double, uint32_t>::type;
   using out_t = typename std::conditional<WEIGHTED, double, unsigned long long>::type;
   lds_t* hist = reinterpret_cast<lds_t*>(xhist_smem);
@@ -513,7 +567,7 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
             const uint32_t within = (Qg & ((1u << qlg) - 1u)) << 2;
             if (within < (uint32_t)(e >> 32)) {
               const uint64_t at = ((uint64_t)(uint32_t)e << lg) + within;
-              cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
+              if constexpr (!PACK) cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
               if (WEIGHTED) wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
               live[g] = true;
             }
@@ -524,7 +578,10 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
           if (live[g]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
+              if constexpr (PACK) {
+                const uint64_t r = (uint64_t)__double_as_longlong((double)wq[g][k]);
+                unsafeAtomicAdd(reinterpret_cast<double*>(hist) + (uint32_t)(r & 0xffffull), __longlong_as_double((long long)(r & ~0xffffull)));
+              } else if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
               else atomicAdd(reinterpret_cast<uint32_t*>(hist) + cv[g][k], 1u);
             }
           }
