@@ -88,6 +88,10 @@ def one(seed):
     except (NotImplementedError, TypeError, ValueError):
         return None
     conv = (lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a)
+    if resident and rng.random() < 0.35:  # device-resident without torch: DeviceArray in, numpy out
+        from xhistogram_amd.devicearray import DeviceArray
+        conv, resident = DeviceArray.from_numpy, False
+        desc["devicearray"] = True
     # kernel-family overrides on the plan these edges map to (reset afterwards)
     plan, override = None, None
     if rng.random() < 0.5:
