@@ -160,6 +160,35 @@ def spread():
     multigpu.set_dask_exchange("host")
     h, _ = histogram(dsa.from_array(x, chunks=2500), bins=e)
     assert any(k.startswith("sum") for k in h.dask.layers) and not any(k.startswith("reduce_partials") for k in h.dask.layers)
+    # chunks that already live on the GPUs (DeviceArray): chunk k is placed on GPU k mod 8 and its block runs THERE, whatever
+    # the other GPUs are doing.  The double keeps the "device" memory on the host; only placement is under test here.
+    from xhistogram_amd import devicearray
+    from xhistogram_amd.devicearray import DeviceArray, to_device_chunks
+
+    def host_backed(cls, a, device=None):
+        a = np.ascontiguousarray(a)
+        return cls(a, a.ctypes.data, a.shape, a.strides, a.dtype, device)
+
+    def read_back(self):
+        flat = self.owner.reshape(-1).view(np.uint8)[self.ptr - self.owner.ctypes.data:]
+        return np.array(np.lib.stride_tricks.as_strided(flat.view(self.dtype), self.shape, self.strides))
+
+    real = DeviceArray.from_numpy, DeviceArray.to_numpy
+    DeviceArray.from_numpy, DeviceArray.to_numpy = classmethod(host_backed), read_back
+    try:
+        xr = to_device_chunks(dsa.from_array(x, chunks=2500)).persist(scheduler="synchronous")
+        assert [xr.blocks[k].compute().device for k in range(16)] == [k % 8 for k in range(16)]
+        seen.clear()
+        h, _ = histogram(xr, bins=e, weights=dsa.from_array(w, chunks=2500))  # host weight chunks follow the resident ones
+        np.testing.assert_allclose(h.compute(scheduler="threads"), np.histogram(x, bins=e, weights=w)[0], rtol=1e-10)
+        assert sorted(seen) == sorted(list(range(8)) * 2), seen
+        tr = to_device_chunks(dsa.from_array(t, chunks=(3, 18, 36)), devices=[2, 5])
+        seen.clear()
+        h, _ = histogram(tr, bins=e4, axis=[1, 2])
+        np.testing.assert_array_equal(h.compute(scheduler="threads"), want)
+        assert sorted(seen) == [2, 2, 2, 2, 5, 5, 5, 5], seen
+    finally:
+        DeviceArray.from_numpy, DeviceArray.to_numpy = real
     multigpu.set_dask_exchange(None)
     print("SPREAD-OK")
 
