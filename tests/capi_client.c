@@ -72,6 +72,37 @@ int main(void) {
   double mm[2];
   rc = xhist_minmax(0, &xa, 1, COLS, mm, XHIST_MEM_HOST, NULL); /* row 0 holds the NaN */
   if (rc || mm[0] == mm[0]) ++bad;                              /* numpy: min of data with NaN is NaN */
+  /* a block that lives on the GPU: uploaded once, described by strides, histogrammed where it lies (XHIST_MEM_DEVICE, the
+   * result into a device buffer too); and the library's strided copy — the (ROWS, COLS) float32 block transposed and
+   * converted to float64, as the block adapter does for layouts no three strides describe (core.py:218-226) */
+  {
+    void *dx = NULL, *dt = NULL, *dout = NULL;
+    int dev = -1;
+    if (xhist_buffer_alloc(0, sizeof(float) * ROWS * COLS, &dx) || xhist_buffer_alloc(0, sizeof(double) * ROWS * COLS, &dt) ||
+        xhist_buffer_alloc(0, sizeof(int64_t) * ROWS * NB, &dout))
+      ++bad;
+    if (xhist_buffer_copy(0, dx, x, sizeof(float) * ROWS * COLS, 0, NULL)) ++bad;
+    if (xhist_pointer_device(dx, &dev) || dev != 0) ++bad;
+    xhist_array da = {dx, XHIST_F32, 0, COLS, 1, 0, 0};
+    if (xhist_plan_execute(plan, &da, NULL, ROWS, COLS, dout, XHIST_I64, XHIST_MEM_DEVICE, 0, NULL)) ++bad;
+    int64_t* counts_d = (int64_t*)malloc(sizeof(int64_t) * ROWS * NB);
+    if (xhist_buffer_copy(0, counts_d, dout, sizeof(int64_t) * ROWS * NB, 1, NULL)) ++bad;
+    for (int i = 0; i < ROWS * NB; ++i)
+      if (counts_d[i] != counts[i]) ++bad;
+    const int64_t shape[2] = {COLS, ROWS};
+    const int64_t sstr[2] = {sizeof(float), sizeof(float) * COLS};    /* the transpose of the source */
+    const int64_t dstr[2] = {sizeof(double) * ROWS, sizeof(double)};  /* C-contiguous (COLS, ROWS) */
+    if (xhist_buffer_copy_nd(0, 2, shape, dx, XHIST_F32, sstr, dt, XHIST_F64, dstr, NULL)) ++bad;
+    double* tr = (double*)malloc(sizeof(double) * ROWS * COLS);
+    if (xhist_buffer_copy(0, tr, dt, sizeof(double) * ROWS * COLS, 1, NULL)) ++bad;
+    for (int r = 0; r < ROWS; ++r)
+      for (int c = 0; c < COLS; c += 97) {
+        const double want = (double)x[r * COLS + c], got = tr[(size_t)c * ROWS + r];
+        if (!(want == got || (want != want && got != got))) ++bad;
+      }
+    free(counts_d); free(tr);
+    xhist_buffer_free(0, dx); xhist_buffer_free(0, dt); xhist_buffer_free(0, dout);
+  }
   xhist_plan_destroy(plan);
   xhist_shutdown();
   printf("%s: %d mismatches; last launch: %s\n", bad ? "FAIL" : "OK", bad, desc);
