@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(256) copy_nd_kernel(const char* __restrict__ s
       const char* s = src + so + c * ss_in;
       char* d = dst + dof + c * ds_in;
       if constexpr (ITEM == 0) *reinterpret_cast<double*>(d) = load_as<double>(s, src_dt, 0);
+      else if constexpr (ITEM == 16) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
       else if constexpr (ITEM == 8) *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s);
       else if constexpr (ITEM == 4) *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s);
       else if constexpr (ITEM == 2) *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s);
@@ -437,6 +438,20 @@ extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, 
     }
   }
   if (nd.ndim == 0) { nd.ndim = 1; nd.shape[0] = 1; nd.ss[0] = 0; nd.ds[0] = 0; }
+  // a raw copy whose innermost dimension is contiguous on both sides moves wider elements where everything is aligned for it
+  int item_eff = item;
+  if (!convert && nd.ss[nd.ndim - 1] == item && nd.ds[nd.ndim - 1] == item) {
+    for (int wide = 16; wide > item; wide >>= 1) {
+      bool ok = (nd.shape[nd.ndim - 1] * item) % wide == 0 && (reinterpret_cast<uintptr_t>(src) % wide) == 0 && (reinterpret_cast<uintptr_t>(dst) % wide) == 0;
+      for (int k = 0; ok && k < nd.ndim - 1; ++k) ok = nd.ss[k] % wide == 0 && nd.ds[k] % wide == 0;
+      if (!ok) continue;
+      nd.shape[nd.ndim - 1] = nd.shape[nd.ndim - 1] * item / wide;
+      nd.ss[nd.ndim - 1] = nd.ds[nd.ndim - 1] = wide;
+      item_eff = wide;
+      n = n * item / wide;
+      break;
+    }
+  }
   DeviceGuard g;
   if (int rc = g.set(device)) return rc;
   const int64_t inner = nd.shape[nd.ndim - 1], rows = n / inner;
@@ -451,9 +466,10 @@ extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, 
   char* dp = static_cast<char*>(dst);
 #define XHIST_COPY_ND(ITEM) hipLaunchKernelGGL((copy_nd_kernel<ITEM>), dim3(grid), dim3(256), 0, s, sp, dp, nd, wlog2, rows, col_tiles, (int32_t)src_dtype)
   if (convert) XHIST_COPY_ND(0);
-  else if (item == 8) XHIST_COPY_ND(8);
-  else if (item == 4) XHIST_COPY_ND(4);
-  else if (item == 2) XHIST_COPY_ND(2);
+  else if (item_eff == 16) XHIST_COPY_ND(16);
+  else if (item_eff == 8) XHIST_COPY_ND(8);
+  else if (item_eff == 4) XHIST_COPY_ND(4);
+  else if (item_eff == 2) XHIST_COPY_ND(2);
   else XHIST_COPY_ND(1);
 #undef XHIST_COPY_ND
   HIPC(hipGetLastError());
