@@ -173,6 +173,9 @@ def block_device():
 # ---------------------------------------------------------------------------------------------
 # one host thread per GPU
 # ---------------------------------------------------------------------------------------------
+_collective_lock = threading.RLock()
+
+
 class DeviceGroup:
     """One host thread per GPU of ``devices``.  ``run(fn, items)`` executes ``fn(rank, device, item)`` for
     the k-th item on the k-th GPU's thread, all at once, and returns the results in order (the first
@@ -187,8 +190,9 @@ class DeviceGroup:
         self._comms = None
         self._closed = False
         # collectives must be issued in the same order on every GPU: two callers (two dask reduction tasks, two user
-        # threads) that interleaved their per-GPU submissions would deadlock the communicators
-        self.collective = threading.RLock()
+        # threads) that interleaved their per-GPU submissions would deadlock the communicators — and so could two GROUPS
+        # that share a GPU (reductions over different subsets of the node's GPUs), hence one lock for the process
+        self.collective = _collective_lock
 
     def __len__(self):
         return len(self.devices)
