@@ -80,3 +80,48 @@ def test_backend_detection_and_block_placement():
     assert core._backend_of([np.zeros(2), d]) == "device" and core._backend_of([np.zeros(2)]) == "numpy"
     with core._block_placement([np.zeros(2), d], multigpu):
         assert core._host_device() == 3  # a resident chunk pins its block to its own GPU
+
+
+def test_nocopy_reshape_rule_is_numpys():
+    """DeviceArray.reshape decides view-or-copy itself (numpy's in-place shape assignment copies before it refuses, which the
+    dummy-backed views of the module cannot afford): same verdicts and strides as numpy on real arrays"""
+    from xhistogram_amd.devicearray import _nocopy_reshape_strides
+
+    rng = np.random.default_rng(0)
+    checked = refused = 0
+    for _ in range(3000):
+        nd = int(rng.integers(1, 5))
+        shape = tuple(int(n) for n in rng.integers(1, 7, size=nd))
+        a = np.arange(int(np.prod(shape)), dtype=np.float32).reshape(shape)
+        v = a
+        for ax in range(nd):  # a random view: steps, a transposition, a broadcast axis
+            if rng.random() < 0.4:
+                v = v[(slice(None),) * ax + (slice(None, None, int(rng.integers(1, 3))),)]
+        if rng.random() < 0.4:
+            v = v.transpose(rng.permutation(nd))
+        if rng.random() < 0.2:
+            v = np.broadcast_to(v[None], (2,) + v.shape)
+        size = v.size
+        facs = [f for f in (1, 2, 3, 4, 5, 6, 8, 9, 10, 12) if size % f == 0]
+        new = []
+        rest = size
+        while rest > 1 and len(new) < 3:
+            f = int(rng.choice([f for f in facs if rest % f == 0]))
+            new.append(f)
+            rest //= f
+            if f == 1 and rng.random() < 0.5:
+                break
+        new.append(rest)
+        new = tuple(new)
+        got = _nocopy_reshape_strides(v.shape, v.strides, new, v.itemsize)
+        w = v.view()
+        try:
+            w.shape = new  # real memory: numpy may copy and refuse, harmlessly
+        except AttributeError:
+            assert got is None, (v.shape, v.strides, new, got)
+            refused += 1
+            continue
+        assert got is not None, (v.shape, v.strides, new)
+        np.testing.assert_array_equal(np.lib.stride_tricks.as_strided(v, new, got), w)
+        checked += 1
+    assert checked > 500 and refused > 200

@@ -601,6 +601,35 @@ def test_partitioned_mode_a_few_long_rows(xh):
     assert_hist_equal(got, onp.bincount_rows([x, y], edges, np.broadcast_to(w[:1], (rows, n))), True)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_partitioned_mode_several_rows_in_one_pass(xh, dtype, weighted):
+    """rows that follow each other at one stride go through the routing pass several at a time ((row, partition) is the
+    partition): more rows than one pass takes, a ragged row length, a row stride above the row length, weights per row /
+    broadcast over the rows / of both signs"""
+    rng = np.random.default_rng(63)
+    rows, n = 23, 70_001
+    x = rng.standard_normal((rows, n + 5)).astype(dtype)[:, :n]  # row stride n + 5
+    y = (rng.standard_normal((rows, n)) * 1.3).astype(dtype)
+    x[3, ::501] = np.nan
+    y[7, 5::499] = 3.0  # right edge of the last bin
+    edges = [np.linspace(-3, 3, 301), np.linspace(-3, 3, 301)]  # 90 000 bins: 6 partitions (weighted) per row
+    for w in ([None] if not weighted else [rng.uniform(0, 1, (rows, n)), np.broadcast_to(rng.uniform(0, 1, (1, n)), (rows, n)),
+                                          rng.standard_normal((rows, n))]):
+        want = onp.bincount_rows([x, y], edges, w)
+        got, desc = _run(xh, [x, y], edges, w, True, partition=1)
+        assert "hist=partitioned" in desc and "rows_per_pass=1 " not in desc, desc
+        assert_hist_equal(got, want, weighted)
+    # two rows, C5-sized histogram (64 partitions per row: exactly two rows per pass), three rows = one pass + one row
+    e5 = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    for r in (2, 3):
+        xs, ys = rng.standard_normal((r, 300_003)).astype(dtype), rng.standard_normal((r, 300_003)).astype(dtype)
+        ws = rng.uniform(0, 1, xs.shape) if weighted else None
+        got, desc = _run(xh, [xs, ys], e5, ws, True, partition=1)
+        assert "hist=partitioned" in desc, desc
+        assert_hist_equal(got, onp.bincount_rows([xs, ys], e5, ws), weighted)
+
+
 def test_partitioned_mode_tiny_and_ragged_inputs(xh):
     """forced partitioned mode on inputs of a few records: carried records and padding only"""
     edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]

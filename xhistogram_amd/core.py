@@ -24,7 +24,7 @@ from collections.abc import Iterable
 import numpy as np
 
 from . import _native
-from .devicearray import DeviceArray
+from .devicearray import DeviceArray, _nocopy_reshape_strides
 
 # range is a keyword of histogram(), like in the reference
 _range = range
@@ -414,12 +414,12 @@ def _rows_cols(a, axis, do_full_array):
         moved = np.moveaxis(a, axis, tuple(_range(-len(axis), 0)))
         m = int(np.prod(moved.shape[: moved.ndim - len(axis)], dtype=np.int64))
     c = (a.size // m) if m else 0
-    v = moved.view()
-    try:
-        v.shape = (m, c)  # succeeds only when no copy is needed
-        return v
-    except AttributeError:
+    # (numpy's in-place `view.shape = ...` copies the data BEFORE it refuses a shape that needs a copy: ask the rule itself)
+    if _nocopy_reshape_strides(moved.shape, moved.strides, (m, c), moved.itemsize) is None:
         return moved.reshape(m, c)
+    v = moved.view()
+    v.shape = (m, c)
+    return v
 
 
 def _elem_strides(a):

@@ -200,12 +200,17 @@ static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan) {
 // redoes the work with full float64 records.  Every decision is taken on the GPU (no host synchronisation: the call stays
 // asynchronous); the plan remembers mixed signs through a pinned host word the exact pass sets, and later calls skip the
 // packed attempt.  "records48" = -1 or XHIST_AMD_EXACT_RECORDS=1 turn packing off.
+//
+// `rows` > 1: that many rows (uniform row strides) in ONE pass — the routing pass treats (row, partition) as the partition, so
+// a few time steps of a big joint histogram cost one launch pair instead of one per row; rows * parts_per_row <= 128.
 static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
                                      hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
-                                     int n_parts, int profile, LaunchRecord& rec, bool first, bool last) {
+                                     int parts_per_row, int profile, LaunchRecord& rec, bool first, bool last, int rows = 1) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
-  if (n_cols >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
+  const int n_parts = parts_per_row * rows;
+  const int64_t n_total = n_cols * rows;
+  if (n_total >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
   kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
   bool pack = weighted && wdt == XHIST_F64 && p->records48_pref >= 0 && !exact_records_env();
@@ -227,19 +232,19 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
   if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
-  const int64_t n_tiles = (n_cols + tile - 1) / tile;
+  const int64_t n_tiles = ((n_cols + tile - 1) / tile) * rows;
   const int per_cu = std::max<int>(1, std::min<int>(4, (int)((size_t)160 * 1024 / lds_route)));
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
-  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_cols + 65535) / 65536));
+  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_total + 65535) / 65536));
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
-  while (lg < 14 && (((n_cols / G) + tile) >> lg) + n_parts + 16 > kRouteListCap) ++lg;
+  while (lg < 14 && (((n_total / G) + tile) >> lg) + n_parts + 16 > kRouteListCap) ++lg;
   const int64_t GP = (int64_t)G * n_parts;
   // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
   // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
   // and ends with at most two ranges in hand.
-  const int64_t used = ((n_cols + 7 * GP) >> lg) + GP;
+  const int64_t used = ((n_total + 7 * GP) >> lg) + GP;
   const int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
@@ -286,13 +291,14 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   kp.tables = tset.blob;
   kp.table_words = table_words;
   kp.tables_in_lds = 1;
-  kp.n_rows = 1;
+  kp.n_rows = rows;
   kp.n_cols = n_cols;
   kp.n_bins = p->n_bins;
   kp.out = out;
   kp.segs = G;
   kp.part_shift = shift;
   kp.n_parts = n_parts;
+  kp.parts_per_row = parts_per_row;
   RouteArgs ra;
   ra.pool = d_ctr;
   ra.pcount = d_ctr + 2;
@@ -325,7 +331,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     RouteArgs ra48 = ra;
     ra48.gate = d_ctr + 1;
     ra48.gate_mode = 1;  // one sign: add the packed records up
-    hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, stream, ra48, out, p->n_bins, shift, n_parts);
+    hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, stream, ra48, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
     HIPR(hipGetLastError());
     // both signs: the exact pass below runs (its own counters: the second set), otherwise its kernels return at once
     ra.pool = d_ctr + 2 * ctr_words;
@@ -337,14 +343,14 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   }
   hipLaunchKernelGGL(k_route, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);
   HIPR(hipGetLastError());
-  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts);
+  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
   HIPR(hipGetLastError());
   {
     char desc[512];
     snprintf(desc, sizeof desc,
-             "family=fast hist=partitioned route=fused parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
+             "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
              "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
-             n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
+             rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
     if (last)
@@ -891,7 +897,39 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         r_tset = &p->ts[0][0];
         r_f32 = false;
       }
-      for (int64_t r = 0; r < n_rows && rc == XHIST_OK; ++r) {
+      // rows that follow each other at one stride go through the routing pass several at a time
+      // (32 x 3*10^7 float32 pairs + weights, 300 x 300 bins: 8.05 -> 6.02 ms; 8 x 6*10^7 float64, 512 x 512: 5.17 -> 4.18;
+      // rows of 5*10^8 samples gain nothing — 8.63 -> 8.95 ms with 128 partitions in flight — and stay one per pass)
+      bool uniform_rows = fused_pref >= 0 && n_rows > 1 && n_parts * 2 <= 128 && n_cols < ((int64_t)1 << 27) && (!weighted || weights->inner_rows == 0);
+      for (int d = 0; d < D; ++d) uniform_rows &= samples[d].inner_rows == 0;
+      static const bool batch_off = [] { const char* e = getenv("XHIST_AMD_ROW_BATCH"); return e && *e == '0'; }();
+      if (batch_off) uniform_rows = false;
+      int64_t r = 0;
+      while (uniform_rows && r < n_rows && rc == XHIST_OK) {
+        int rows = (int)std::min<int64_t>(n_rows - r, 128 / n_parts);
+        const size_t tab_bytes = r_scan == kScanArith ? 0 : (size_t)r_tset->words * 8;
+        while (rows > 1 && part_route_lds(tab_bytes, rows * (int)n_parts, weighted, r_tile) > p->lds_max) --rows;
+        if (rows < 2) break;  // (one row at a time below)
+        xhist_array row_s[XHIST_MAX_DIMS], row_w;
+        for (int d = 0; d < D; ++d) {
+          row_s[d] = samples[d];
+          row_s[d].data = const_cast<void*>(advance(samples[d].data, samples[d].dtype, r * samples[d].row_stride));
+        }
+        if (weighted) {
+          row_w = *weights;
+          row_w.data = const_cast<void*>(advance(weights->data, weights->dtype, r * weights->row_stride));
+        }
+        void* row_out = static_cast<char*>(out) + (size_t)r * p->n_bins * 8;
+        rc = execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan, r_f32, *r_tset, shift,
+                                       (int)n_parts, profile, rec, r == 0, r + rows == n_rows, rows);
+        if (rc == XHIST_ERR_UNSUPPORTED) {
+          if (r > 0) rc = fail(XHIST_ERR_HIP, "internal: partitioned mode refused rows from %lld after accepting row 0", (long long)r);
+          else rc = XHIST_OK;  // nothing launched: row by row below
+          break;
+        }
+        r += rows;
+      }
+      for (; r < n_rows && rc == XHIST_OK; ++r) {
         xhist_array row_s[XHIST_MAX_DIMS], row_w;
         for (int d = 0; d < D; ++d) {
           row_s[d] = samples[d];

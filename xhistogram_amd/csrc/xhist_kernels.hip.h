@@ -97,6 +97,7 @@ struct Params {
   uint16_t* part_codes;         // record stream: bin index inside its partition
   double* part_w;               // record stream: weight (weighted only)
   int32_t part_shift;           // bins per partition = 1 << part_shift
+  int32_t parts_per_row;        // routing pass over several rows at once: n_parts = n_rows * parts_per_row (0: one row)
   int32_t n_parts;
 };
 

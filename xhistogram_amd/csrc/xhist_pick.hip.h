@@ -21,7 +21,7 @@ typedef void (*kernel_fn_count)(const Params, uint32_t*);
 typedef void (*kernel_fn_lanes)(const Params, int32_t, int64_t);
 typedef void (*kernel_fn_scatter)(const uint32_t*, const void*, int64_t, const uint64_t*, uint16_t*, void*, int, int);
 typedef void (*kernel_fn_route)(const Params, const RouteArgs);
-typedef void (*kernel_fn_acc_chunks)(const RouteArgs, void*, int64_t, int, int);
+typedef void (*kernel_fn_acc_chunks)(const RouteArgs, void*, int64_t, int, int, int);
 
 // Samples a lane bins as one branch-free batch = VEC x UNROLL, capped by register pressure: per
 // sample and dimension the batch keeps the value, its running count and (linear scan) up to

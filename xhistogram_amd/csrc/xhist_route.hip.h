@@ -233,14 +233,22 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
     }
   };
 
-  const int64_t n_tiles = (n + kRouteTile - 1) / kRouteTile;
+  // Several rows in one pass (a few time steps of a big joint histogram): tiles never straddle rows, a tile's partition
+  // ids are offset by its row's share of the partitions, and everything downstream sees n_rows * parts_per_row partitions.
+  const int64_t tiles_per_row = (n + kRouteTile - 1) / kRouteTile;
+  const int64_t n_tiles = tiles_per_row * p.n_rows;
   const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // the grid never exceeds the number of tiles
-  auto tile_base = [&](int64_t k) { return ((int64_t)blockIdx.x + k * gridDim.x) * kRouteTile; };
+  const bool multi = p.n_rows > 1;
+  auto tile_row = [&](int64_t k) -> int64_t { return multi ? ((int64_t)blockIdx.x + k * gridDim.x) / tiles_per_row : 0; };
+  auto tile_base = [&](int64_t k) {  // first sample of the tile inside ITS row
+    const int64_t t = (int64_t)blockIdx.x + k * gridDim.x;
+    return (multi ? t - (t / tiles_per_row) * tiles_per_row : t) * kRouteTile;
+  };
   // Loads are free of control flow (see part_scatter): a quad that would cross the end of the arrays is
   // read 4 elements back from the end and moved into place when it is used.  Requires n >= 4.
   // Addresses: a uniform 64-bit tile pointer (scalar registers) plus ONE 32-bit byte offset per lane and load —
   // twelve 64-bit lane addresses kept across the loop were a third of the register file.
-  auto load_tile = [&](int64_t base, s4 (&x)[D][U], w4 (&w)[U]) {
+  auto load_tile = [&](int64_t base, int64_t row, s4 (&x)[D][U], w4 (&w)[U]) {
     const int64_t origin = min(base, n - 4);  // (a last tile of fewer than 4 samples reads the 4 before the end)
     const uint32_t last = (uint32_t)min(n - 4 - origin, (int64_t)kRouteTile);  // first element of the last whole quad, tile-relative
 #pragma unroll
@@ -248,17 +256,18 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
       const uint32_t e = min((uint32_t)(u * kRouteBlock + tid) * 4u, last);
 #pragma unroll
       for (int d = 0; d < D; ++d)
-        x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + origin) + e * (uint32_t)sizeof(ST)));
+        x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + row * p.s_rs[d] + origin) + e * (uint32_t)sizeof(ST)));
       if (kWeighted)
-        w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(reinterpret_cast<const char*>(wp + origin) + e * (uint32_t)sizeof(wscalar)));
+        w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(reinterpret_cast<const char*>(wp + row * p.w_rs + origin) + e * (uint32_t)sizeof(wscalar)));
     }
   };
   s4 xv[D][U];
   w4 w[U], wn[U];
-  load_tile(tile_base(0), xv, w);
+  load_tile(tile_base(0), tile_row(0), xv, w);
   int cur_set = 0;
   for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
     const int64_t base = tile_base(k);
+    const uint32_t row_off = (uint32_t)tile_row(k) * ((uint32_t)p.parts_per_row << shift);  // this row's first partition, as a flat index
     const bool ragged = base + kRouteTile > n;
     uint32_t* cnt = cnt2 + (cur_set << 8);
     const uint32_t* cin = cin2 + (cur_set << 8);
@@ -302,7 +311,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
           ok &= (b >= 0);
           fl = (d == 0) ? (uint32_t)b : fl * (uint32_t)p.dim[d].nb + (uint32_t)b;
         }
-        flat[u][v] = ok ? fl : 0xffffffffu;
+        flat[u][v] = ok ? fl + row_off : 0xffffffffu;
       }
     }
     uint32_t rank[U][4];
@@ -312,7 +321,10 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
       for (int v = 0; v < 4; ++v) rank[u][v] = (flat[u][v] != 0xffffffffu) ? atomicAdd(cnt + (flat[u][v] >> shift), 1u) : 0u;
     // the next tile's loads (the tile after the last one is the last one again: one redundant load per
     // workgroup instead of a branch around loads); waited for just before this tile's stores go out
-    load_tile(tile_base(k + 1 < my_tiles ? k + 1 : k), xv, wn);
+    {
+      const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
+      load_tile(tile_base(kn), tile_row(kn), xv, wn);
+    }
     __syncthreads();
     // ---- block layout (as in part_scatter) + record space of every partition's block: LDS only -------
     if (tid < ((P + 63) & ~63)) {
@@ -512,7 +524,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
 // partition whose offset range holds k; every workgroup takes an equal range of k.  Chunks hold whole
 // groups of 8 records and start 2^chunk_log2-aligned, so every load is an aligned quad.
 template <bool WEIGHTED, typename RT = double, bool PACK = false>
-__global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs ra, void* out_v, int64_t n_bins, int shift, int P) {
+__global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs ra, void* out_v, int64_t n_bins, int shift, int P, int parts_per_row) {
   if (route_gate_closed(ra)) return;
   using lds_t = typename std::conditional<WEIGHTED, double, uint32_t>::type;
   using out_t = typename std::conditional<WEIGHTED, double, unsigned long long>::type;
@@ -591,10 +603,12 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
     for (uint32_t c = tid; c < bpp; c += blockDim.x) {
       const lds_t v = hist[c];
       if (v != (lds_t)0) {
-        const int64_t bin = ((int64_t)part << shift) + c;
+        // (several rows in one pass: partition = row * parts_per_row + partition inside the row's histogram)
+        const int row = parts_per_row ? part / parts_per_row : 0;
+        const int64_t bin = ((int64_t)(part - row * parts_per_row) << shift) + c;
         if (bin < n_bins) {
-          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(out) + bin, (double)v);
-          else atomicAdd(reinterpret_cast<unsigned long long*>(out) + bin, (unsigned long long)v);
+          if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(out) + row * n_bins + bin, (double)v);
+          else atomicAdd(reinterpret_cast<unsigned long long*>(out) + row * n_bins + bin, (unsigned long long)v);
         }
         hist[c] = (lds_t)0;
       }

@@ -37,6 +37,38 @@ def _c_strides(shape, itemsize):
     return tuple(reversed(strides))
 
 
+def _nocopy_reshape_strides(shape, strides, newshape, itemsize):
+    """Byte strides that show the same elements, in C order, under ``newshape`` — or None when only a copy can (numpy's
+    no-copy reshape rule, restated: numpy's own ``view.shape = ...`` cannot be asked, it COPIES first and compares pointers
+    afterwards, which on the dummy-backed views of this module reads memory that is not there)."""
+    if any(n == 0 for n in newshape) or any(n == 0 for n in shape):
+        return _c_strides(newshape, itemsize)
+    old = [(int(n), int(st)) for n, st in zip(shape, strides) if n != 1]
+    newshape = [int(n) for n in newshape]
+    newstrides = [0] * len(newshape)
+    oi, oj, ni, nj = 0, 1, 0, 1
+    while ni < len(newshape) and oi < len(old):
+        np_, op = newshape[ni], old[oi][0]
+        while np_ != op:
+            if np_ < op:
+                np_ *= newshape[nj]
+                nj += 1
+            else:
+                op *= old[oj][0]
+                oj += 1
+        for k in range(oi, oj - 1):  # the old axes taken together must walk memory as one C-ordered axis
+            if old[k][1] != old[k + 1][0] * old[k + 1][1]:
+                return None
+        newstrides[nj - 1] = old[oj - 1][1]
+        for k in range(nj - 1, ni, -1):
+            newstrides[k - 1] = newstrides[k] * newshape[k]
+        ni, nj, oi, oj = nj, nj + 1, oj, oj + 1
+    last = newstrides[ni - 1] if ni >= 1 else itemsize
+    for k in range(ni, len(newshape)):  # trailing axes of extent 1
+        newstrides[k] = last
+    return tuple(newstrides)
+
+
 def _storage_dtype(dtype):
     """datetime64 / timedelta64 are int64 to the kernels (core.py: the int64 compare domain)"""
     dtype = np.dtype(dtype)
@@ -189,13 +221,11 @@ class DeviceArray:
             shape = tuple((self.size // known if known else 0) if n == -1 else n for n in shape)
         if int(np.prod(shape, dtype=np.int64)) != self.size:
             raise ValueError("cannot reshape array of size %d into shape %r" % (self.size, shape))
-        v = self._fake().view()
-        try:
-            v.shape = shape  # succeeds only when no copy is needed
-        except AttributeError:
+        strides = _nocopy_reshape_strides(self.shape, self.strides, shape, self.itemsize)
+        if strides is None:
             c = self.copy()
             return c._like(c.ptr, shape, _c_strides(shape, self.itemsize))
-        return self._like(self.ptr, v.shape, v.strides)
+        return self._like(self.ptr, shape, strides)
 
     def view(self, dtype):
         dtype = np.dtype(dtype)
