@@ -183,9 +183,9 @@ static bool exact_records_env() {
   return v;
 }
 
-static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan) {
-  if (sdt == XHIST_F64) return xhist_pick_route_f64(wdt, D, scan);
-  if (sdt == XHIST_F32) return xhist_pick_route_f32(wdt, D, scan);
+static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi = false) {
+  if (sdt == XHIST_F64) return xhist_pick_route_f64(wdt, D, scan, multi);
+  if (sdt == XHIST_F32) return xhist_pick_route_f32(wdt, D, scan, multi);
   return nullptr;
 }
 
@@ -211,7 +211,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const int n_parts = parts_per_row * rows;
   const int64_t n_total = n_cols * rows;
   if (n_total >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
-  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan);
+  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan, rows > 1);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
   bool pack = weighted && wdt == XHIST_F64 && p->records48_pref >= 0 && !exact_records_env();
   if (pack && !p->mixed_hint) {
@@ -223,7 +223,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     }
   }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
-  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan) : nullptr;
+  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1) : nullptr;
   if (pack && !k_route48) pack = false;
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
   const int tile = route_tile(dtype_size(sdt));

@@ -171,10 +171,17 @@ static kernel_fn mixed_pick_ds(int D, int scan) {
 // arithmetic edges; up to three inputs; any of the three weight kinds
 constexpr int kWdtPacked48 = 0x100 | XHIST_F64;  // float64 weights, packed 8-byte records (xhist_route.hip.h)
 
+// (several rows per pass: uniform-style edges only — tables with one edge per bucket, or arithmetic — the shapes a census over
+// time steps has; other edges run one row per pass)
 template <typename ST, typename WT>
-static kernel_fn_route route_pick_ds(int D, int scan) {
+static kernel_fn_route route_pick_ds(int D, int scan, bool multi) {
 #define XH_ROUTE_CASE(DD)                                                        \
   case DD:                                                                       \
+    if (multi) {                                                                 \
+      if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, true>;    \
+      if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, true>; \
+      return nullptr;                                                            \
+    }                                                                            \
     if (scan == 0) return (kernel_fn_route)part_route<ST, WT, DD, 0>;            \
     if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1>;            \
     if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2>;            \
@@ -190,11 +197,11 @@ static kernel_fn_route route_pick_ds(int D, int scan) {
 }
 
 template <typename ST>
-static kernel_fn_route route_pick(int wdt, int D, int scan) {
-  if (wdt == -1) return route_pick_ds<ST, NoWeight>(D, scan);
-  if (wdt == XHIST_F64) return route_pick_ds<ST, double>(D, scan);
-  if (wdt == XHIST_F32) return route_pick_ds<ST, float>(D, scan);
-  if (wdt == kWdtPacked48) return route_pick_ds<ST, Packed48>(D, scan);
+static kernel_fn_route route_pick(int wdt, int D, int scan, bool multi) {
+  if (wdt == -1) return route_pick_ds<ST, NoWeight>(D, scan, multi);
+  if (wdt == XHIST_F64) return route_pick_ds<ST, double>(D, scan, multi);
+  if (wdt == XHIST_F32) return route_pick_ds<ST, float>(D, scan, multi);
+  if (wdt == kWdtPacked48) return route_pick_ds<ST, Packed48>(D, scan, multi);
   return nullptr;
 }
 
@@ -207,5 +214,5 @@ kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
 // (xhist_route_f64.hip / xhist_route_f32.hip)
-kernel_fn_route xhist_pick_route_f64(int wdt, int D, int scan);
-kernel_fn_route xhist_pick_route_f32(int wdt, int D, int scan);
+kernel_fn_route xhist_pick_route_f64(int wdt, int D, int scan, bool multi);
+kernel_fn_route xhist_pick_route_f32(int wdt, int D, int scan, bool multi);

@@ -136,7 +136,7 @@ __device__ __forceinline__ uint32_t route_take_ids(uint32_t* a, uint32_t need) {
 // into load, wait, sort, store, one after the other (4.2 ms instead of 3.4 for a C5 shard).  Hence: everything
 // the partition owners keep from tile to tile (record cursors, chunk lists) lives in LDS, and chunk ids come
 // from an LDS-resident stock that one lane refills from the global pool a tile before it runs out.
-template <typename ST, typename WT, int D, int SCAN>
+template <typename ST, typename WT, int D, int SCAN, bool MULTI = false>
 __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const RouteArgs ra) {
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
   constexpr bool PACK = __is_same(WT, Packed48);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kRouteBlock) part_route(const Params p, const 
   const int64_t tiles_per_row = (n + kRouteTile - 1) / kRouteTile;
   const int64_t n_tiles = tiles_per_row * p.n_rows;
   const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // the grid never exceeds the number of tiles
-  const bool multi = p.n_rows > 1;
+  constexpr bool multi = MULTI;  // (a compile-time split: the one-row pass — BASELINE C5 — pays nothing for the row arithmetic)
   auto tile_row = [&](int64_t k) -> int64_t { return multi ? ((int64_t)blockIdx.x + k * gridDim.x) / tiles_per_row : 0; };
   auto tile_base = [&](int64_t k) {  // first sample of the tile inside ITS row
     const int64_t t = (int64_t)blockIdx.x + k * gridDim.x;
