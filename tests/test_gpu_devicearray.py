@@ -98,6 +98,19 @@ def test_big_transposes_and_few_column_tables(DA):
     np.testing.assert_array_equal(DA.from_numpy(big)[::-1].copy().to_numpy(), big[::-1])
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32, np.float64])
+def test_transposing_copies_through_lds_tiles(DA, dtype):
+    """layouts whose fastest source axis is not the destination's: tiled through LDS, with ragged tiles and batch axes"""
+    rng = np.random.default_rng(11)
+    for shape, perm in (((5, 70, 130), (0, 2, 1)), ((129, 257), (1, 0)), ((3, 2, 65, 64), (1, 0, 3, 2)), ((64, 4, 100), (2, 1, 0)),
+                        ((17, 1000), (1, 0)), ((2, 40, 3, 50), (0, 3, 2, 1))):
+        a = _values(rng, shape, dtype)
+        d = DA.from_numpy(a)
+        np.testing.assert_array_equal(d.transpose(*perm).copy().to_numpy(), a.transpose(perm))
+        sl = tuple(slice(1, None, 2) if n > 40 else slice(None) for n in shape)
+        np.testing.assert_array_equal(d[sl].transpose(*perm).copy().to_numpy(), a[sl].transpose(perm))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conversion_to_float64(DA, dtype):
     rng = np.random.default_rng(2)

@@ -405,6 +405,45 @@ __global__ void __launch_bounds__(256) copy_nd_kernel(const char* __restrict__ s
   }
 }
 
+// The transposing case: the destination's fastest dimension (the last) is strided in the source, and another dimension `kd` is
+// the source's fastest.  64 x 64 tiles of the (kd, last) plane go through LDS — reads coalesced along kd, writes along the last
+// dimension; every other dimension is a batch index.  (The general kernel reads such layouts one element per cache line.)
+template <typename T>
+__global__ void __launch_bounds__(256) copy_nd_transpose(const char* __restrict__ src, char* __restrict__ dst, NdCopy nd, int kd,
+                                                         int64_t tiles_k, int64_t tiles_l, int64_t n_tiles) {
+  __shared__ T tile[64][65];
+  const int last = nd.ndim - 1;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    int64_t rem = t;
+    const int64_t tl = rem % tiles_l; rem /= tiles_l;
+    const int64_t tk = rem % tiles_k; rem /= tiles_k;
+    int64_t so = 0, dof = 0;
+    for (int d = last - 1; d >= 0; --d) {
+      if (d == kd) continue;
+      const int64_t q = rem / nd.shape[d], idx = rem - q * nd.shape[d];
+      rem = q;
+      so += idx * nd.ss[d];
+      dof += idx * nd.ds[d];
+    }
+    const int64_t k0 = tk * 64, l0 = tl * 64;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t ik = k0 + tx, il = l0 + ty + 4 * j;
+      if (ik < nd.shape[kd] && il < nd.shape[last])
+        tile[ty + 4 * j][tx] = *reinterpret_cast<const T*>(src + so + ik * nd.ss[kd] + il * nd.ss[last]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t ik = k0 + ty + 4 * j, il = l0 + tx;
+      if (ik < nd.shape[kd] && il < nd.shape[last])
+        *reinterpret_cast<T*>(dst + dof + ik * nd.ds[kd] + il * nd.ds[last]) = tile[tx][ty + 4 * j];
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, const void* src, int src_dtype,
                                     const int64_t* src_strides, void* dst, int dst_dtype, const int64_t* dst_strides, void* stream) {
   if (ndim < 0 || ndim > 8) return fail(XHIST_ERR_INVALID, "copy_nd takes 0..8 dimensions, got %d", ndim);
@@ -454,6 +493,29 @@ extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, 
   }
   DeviceGuard g;
   if (int rc = g.set(device)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* sp = static_cast<const char*>(src);
+  char* dp = static_cast<char*>(dst);
+  if (!convert && nd.ndim >= 2 && nd.ds[nd.ndim - 1] == item && nd.ss[nd.ndim - 1] != item && nd.shape[nd.ndim - 1] >= 16) {
+    int kd = -1;
+    for (int k = 0; k < nd.ndim - 1; ++k)
+      if (nd.ss[k] == item && nd.shape[k] >= 16) kd = k;
+    if (kd >= 0) {
+      const int64_t tiles_k = (nd.shape[kd] + 63) / 64, tiles_l = (nd.shape[nd.ndim - 1] + 63) / 64;
+      int64_t n_tiles = tiles_k * tiles_l;
+      for (int k = 0; k < nd.ndim - 1; ++k)
+        if (k != kd) n_tiles *= nd.shape[k];
+      const int tgrid = (int)std::min<int64_t>(n_tiles, 256 * 16);
+#define XHIST_COPY_T(T) hipLaunchKernelGGL((copy_nd_transpose<T>), dim3(tgrid), dim3(256), 0, s, sp, dp, nd, kd, tiles_k, tiles_l, n_tiles)
+      if (item == 8) XHIST_COPY_T(uint64_t);
+      else if (item == 4) XHIST_COPY_T(uint32_t);
+      else if (item == 2) XHIST_COPY_T(uint16_t);
+      else XHIST_COPY_T(uint8_t);
+#undef XHIST_COPY_T
+      HIPC(hipGetLastError());
+      return XHIST_OK;
+    }
+  }
   const int64_t inner = nd.shape[nd.ndim - 1], rows = n / inner;
   int wlog2 = 0;
   while (wlog2 < 8 && ((int64_t)1 << wlog2) < inner) ++wlog2;
@@ -461,9 +523,6 @@ extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, 
   const int rows_per_wg = 256 >> wlog2;
   const int64_t tiles = ((rows + rows_per_wg - 1) / rows_per_wg) * col_tiles;
   const int grid = (int)std::min<int64_t>(tiles, 256 * 32);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const char* sp = static_cast<const char*>(src);
-  char* dp = static_cast<char*>(dst);
 #define XHIST_COPY_ND(ITEM) hipLaunchKernelGGL((copy_nd_kernel<ITEM>), dim3(grid), dim3(256), 0, s, sp, dp, nd, wlog2, rows, col_tiles, (int32_t)src_dtype)
   if (convert) XHIST_COPY_ND(0);
   else if (item_eff == 16) XHIST_COPY_ND(16);
