@@ -212,6 +212,26 @@ def _compare_domain(sample_dtypes, edges):
 # ---------------------------------------------------------------------------------------------
 # L1: the hot path                                                     (core.py:137-194)
 # ---------------------------------------------------------------------------------------------
+def _torch_contiguous(a):
+    """C-contiguous copy of a GPU tensor: the library's strided-copy kernel (transposing layouts tiled through LDS, 3-5 TB/s
+    moved) instead of torch's generic one (~0.5 TB/s for the same layouts); small tensors and dtypes without a tag go to torch"""
+    if a.is_contiguous():
+        return a
+    if a.numel() < (1 << 16) or a.ndim > 8 or not a.is_cuda:
+        return a.contiguous()
+    try:
+        tag = _torch_tag(a.dtype)
+    except TypeError:
+        return a.contiguous()
+    torch = _torch()
+    out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    item = a.element_size()
+    dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
+    _native.copy_nd(dev, a.shape, a.data_ptr(), tag, [st * item for st in a.stride()], out.data_ptr(), tag,
+                    [st * item for st in out.stride()], torch.cuda.current_stream(dev).cuda_stream)
+    return out
+
+
 def _strided_view(a2d, backend):
     """(pointer, dtype tag, row stride, col stride, 0, 0, keepalive) of a 2-D array, in elements.
     Falls back to a contiguous copy only for layouts the C ABI does not take (negative strides;
@@ -224,7 +244,7 @@ def _strided_view(a2d, backend):
         # (row stride 1 = reductions over leading axes: the library's row-per-lane kernels take
         # those views as they are)
         if rs < 0 or cs < 0 or (cs > 1 and rs > 1 and a2d.shape[1] > 1 and a2d.numel() >= (1 << 16)):
-            a2d = a2d.contiguous()
+            a2d = _torch_contiguous(a2d)
             rs, cs = a2d.stride()
         if a2d.shape[0] <= 1:
             rs = 0 if a2d.shape[0] == 0 else rs
@@ -401,6 +421,10 @@ def _rows_cols(a, axis, do_full_array):
         m = 1
         for k in keep:
             m *= int(k)
+        c = (a.numel() // m) if m else 0
+        item = a.element_size()
+        if m and c and _nocopy_reshape_strides(tuple(moved.shape), tuple(st * item for st in moved.stride()), (m, c), item) is None:
+            moved = _torch_contiguous(moved)  # the reshape needs a copy: ours
         return moved.reshape(m, -1)
     if _is_devarr(a):
         if do_full_array:

@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) copy_nd_kernel(const char* __restrict__ s
 }
 
 // The transposing case: the destination's fastest dimension (the last) is strided in the source, and another dimension `kd` is
-// the source's fastest.  64 x 64 tiles of the (kd, last) plane go through LDS — reads coalesced along kd, writes along the last
+// the source's fastest (stride of one to eight elements).  64 x 64 tiles of the (kd, last) plane go through LDS — reads coalesced along kd, writes along the last
 // dimension; every other dimension is a batch index.  (The general kernel reads such layouts one element per cache line.)
 template <typename T>
 __global__ void __launch_bounds__(256) copy_nd_transpose(const char* __restrict__ src, char* __restrict__ dst, NdCopy nd, int kd,
@@ -501,9 +501,11 @@ extern "C" int xhist_buffer_copy_nd(int device, int ndim, const int64_t* shape, 
   const char* sp = static_cast<const char*>(src);
   char* dp = static_cast<char*>(dst);
   if (!convert && nd.ndim >= 2 && nd.ds[nd.ndim - 1] == item && nd.ss[nd.ndim - 1] != item && nd.shape[nd.ndim - 1] >= 16) {
-    int kd = -1;
+    int kd = -1;  // the source's fastest dimension: smallest positive stride, below the last dimension's (x.T[::2]: 2 elements)
     for (int k = 0; k < nd.ndim - 1; ++k)
-      if (nd.ss[k] == item && nd.shape[k] >= 16) kd = k;
+      if (nd.ss[k] > 0 && nd.shape[k] >= 16 && (kd < 0 || nd.ss[k] < nd.ss[kd])) kd = k;
+    const int64_t ss_last = nd.ss[nd.ndim - 1] < 0 ? -nd.ss[nd.ndim - 1] : nd.ss[nd.ndim - 1];
+    if (kd >= 0 && !(nd.ss[kd] < ss_last && nd.ss[kd] <= 8 * (int64_t)item)) kd = -1;
     if (kd >= 0) {
       const int64_t tiles_k = (nd.shape[kd] + 63) / 64, tiles_l = (nd.shape[nd.ndim - 1] + 63) / 64;
       int64_t n_tiles = tiles_k * tiles_l;
