@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 200 for the sub-millisecond steps of --config c4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; 50 for --config c4)")
     ap.add_argument("--samples", type=int, default=1_000_000_000, help="samples per GPU")
     ap.add_argument("--bins", type=int, default=100)
     ap.add_argument("--unweighted", action="store_true", help="8 B/sample variant (not the headline)")
@@ -65,7 +65,16 @@ def parse():
                          "gathers and the JSON line, which no 1-GPU box can")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
-    return ap.parse_args()
+    args = ap.parse_args()
+    # a C4 shard step is one 0.3 ms kernel: the first tens of launches after an idle GPU run 5-8 % slower (0.309 ms over steps
+    # 6..25, 0.290 ms over steps 51..250 and beyond), so its default run is longer; every other config's kernel takes milliseconds
+    # and does not care (profiles/r02_z_warmup.txt)
+    short_steps = args.config == "c4" and not args.full
+    if args.steps is None:
+        args.steps = 200 if short_steps else 20
+    if args.warmup is None:
+        args.warmup = 50 if short_steps else 3
+    return args
 
 
 def self_spawn(args):
