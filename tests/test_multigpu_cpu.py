@@ -332,3 +332,18 @@ def test_dask_exchange_policy(monkeypatch):
     finally:
         multigpu.set_dask_exchange(None)
         multigpu.set_devices(None)
+
+
+def test_bench_default_run_lengths(monkeypatch):
+    """20 timed steps after 3 warm-up ones, except the sub-millisecond C4 shard step (200 after 50); explicit flags win"""
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    for argv, want in (([], (20, 3)), (["--config", "c4"], (200, 50)), (["--config", "c4", "--full"], (20, 3)), (["--config", "c5"], (20, 3)),
+                       (["--config", "c4", "--steps", "7"], (7, 50)), (["--steps", "5", "--warmup", "2"], (5, 2))):
+        monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+        a = bench.parse()
+        assert (a.steps, a.warmup) == want, (argv, a.steps, a.warmup)
