@@ -253,12 +253,15 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             dist.barrier()
         sync()
 
-    def run_leg(n_cols, steps, warmup):
+    def run_leg(n_cols, steps, warmup, weighted=weighted, outs=outs, cold=0):
         """`warmup` untimed + `steps` timed passes over the first n_cols samples of every row of this rank's
         resident arrays; returns what the JSON line needs.  A step = output zeroing + histogram kernel(s)
-        (+ all-reduce of the partial over RCCL, overlapped with the next step's kernel; + the density epilogue)"""
+        (+ all-reduce of the partial over RCCL, overlapped with the next step's kernel; + the density epilogue).
+        weighted=False on a weighted workload: the same samples without their weights (the 8 B/sample variant).
+        cold > 0: before anything else, that many launches straight after half a second of idle GPU, timed one by one."""
         xv = [_native.make_view(a.data_ptr(), tag[a.dtype], wl["cols"], 1) for a in arrays]
         wv = _native.make_view(w.data_ptr(), tag[w.dtype], wl["cols"], 1) if weighted else None
+        bytes_per_sample = sum(a.element_size() for a in arrays) + (w.element_size() if weighted else 0)
         pending = [None, None]
         dens = [None]
         counter = [0]
@@ -288,6 +291,16 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 finish(k)
             fence()
 
+        cold_ms = None
+        if cold:
+            drain()
+            time.sleep(0.5)
+            plan.set_param("profile", cold)
+            for _ in range(cold):
+                step()
+            drain()
+            cold_ms = plan.profile_read()
+            plan.set_param("profile", 0)
         for _ in range(warmup):
             step()
         drain()
@@ -327,14 +340,23 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             allreduce_ms = (time.perf_counter() - t0) / steps * 1e3
             fence()
         n = n_rows * n_cols
-        return dict(dt=dt, n=n, kernel_ms=kernel_ms, kernel_ms_per_rank=per_rank, allreduce_ms=allreduce_ms,
-                    value=world * n * steps / dt, ms_per_step=dt / steps * 1e3, last=out, dens=dens[0])
+        desc = plan.describe()
+        return dict(desc=desc, dt=dt, n=n, kernel_ms=kernel_ms, kernel_ms_per_rank=per_rank, allreduce_ms=allreduce_ms, cold_ms=cold_ms,
+                    value=world * n * steps / dt, ms_per_step=dt / steps * 1e3, last=out, dens=dens[0], bytes_per_sample=bytes_per_sample)
 
     cols_weak = wl["cols"]
     cols_strong = max(1, wl["cols"] // world)
     legs = {}
     main_leg = args.scaling
-    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup)
+    # sub-millisecond kernels (the C4 shard): the first launches after an idle GPU are reported next to the steady rate
+    cold = 20 if (args.config == "c4" and not args.full and not args.selftest) else 0
+    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold)
+    # the headline's 8 B/sample variant — north_star's target sentence is the 1-D 10^9-sample f64 histogram WITHOUT weights
+    # (BASELINE.md section 3 "headline unweighted variant") — rides along on the same samples: `"unweighted": {...}`
+    unweighted_leg = None
+    if args.config == "c2" and weighted:
+        outs_u = [torch.zeros(out_shape, dtype=torch.int64, device=dev) for _ in range(2)]
+        unweighted_leg = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, weighted=False, outs=outs_u)
     if world > 1:  # the other leg rides along (N = 1: the two legs are the same run)
         other = "strong" if main_leg == "weak" else "weak"
         legs[other] = run_leg(cols_weak if other == "weak" else cols_strong, args.steps, args.warmup)
@@ -343,6 +365,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     if rank == 0:
         def roofline(leg):
             k_ms = float(np.mean(leg["kernel_ms"]))
+            bytes_per_sample = leg["bytes_per_sample"]
             achieved = bytes_per_sample * leg["n"] / (k_ms * 1e-3) / 1e9
             return {
                 "bound": "hbm",
@@ -367,7 +390,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             entry = json.load(open(tpath)).get("configs", {}).get(args.config + ("_full" if args.full else ""))
         except Exception:
             entry = None
-        if entry and entry.get("kernel") == plan.describe() and entry.get("samples_per_launch") == m["n"] and not args.unweighted:
+        if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"] and not args.unweighted:
             roof["traffic"] = entry["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/traffic.json: %s (code state %s)" % (entry.get("source", "?"), entry.get("code_state", "?"))
         else:
@@ -378,6 +401,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 "value": leg["value"], "unit": "samples/s", "ms_per_step": leg["ms_per_step"], "samples_per_gpu": leg["n"],
                 "samples_total": leg["n"] * world, "kernel_ms_per_rank": leg["kernel_ms_per_rank"],
                 "allreduce_ms_alone": leg["allreduce_ms"], "roofline_frac_rank0": roofline(leg)["frac"],
+                "overhead_us_per_step": (leg["ms_per_step"] - float(np.mean(leg["kernel_ms"]))) * 1e3,
             }
 
         line = {
@@ -399,14 +423,34 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 "samples_total": m["n"] * world,
                 "bins": [int(b) for b in plan.bins_shape],
                 "weighted": weighted,
-                "kernel": plan.describe(),
+                "kernel": m["desc"],
                 "parallelism": ("sample-axis shards, one per GPU" if wl["reduce"] == "allreduce" else "kept-axis (time) shards, one per GPU, disjoint output rows")
                 + ("; all-reduce(sum) of the partial histogram over RCCL each step, overlapped with the next step's kernel" if reduce_partials else ""),
             },
             "roofline": roof,
             "kernel_ms_per_rank": m["kernel_ms_per_rank"],
             "allreduce_ms_alone": m["allreduce_ms"],
+            # everything a step costs beyond its histogram kernel(s): zeroing, launch, the exchange's share that does not
+            # overlap, the wait for the buffer's previous reduction (slowest rank's step time - rank 0's kernel time)
+            "overhead_us_per_step": (m["ms_per_step"] - roof["kernel_ms_mean"]) * 1e3,
         }
+        if m["cold_ms"]:
+            c_ms = float(np.mean(m["cold_ms"]))
+            c_ach = m["bytes_per_sample"] * m["n"] / (c_ms * 1e-3) / 1e9
+            roof["cold"] = {"launches": len(m["cold_ms"]), "after_idle_s": 0.5, "kernel_ms_mean": c_ms, "kernel_ms": [round(float(v), 4) for v in m["cold_ms"]],
+                            "achieved": c_ach, "frac": c_ach / HBM_PEAK_GBS}
+            roof["cold_frac"] = c_ach / HBM_PEAK_GBS
+        if unweighted_leg is not None:
+            u = unweighted_leg
+            ur = roofline(u)
+            line["unweighted"] = {
+                "metric": "samples/s binned (f64), 1D %d-bin 10^9 elems per GPU, no weights (8 B/sample)" % plan.bins_shape[0],
+                "value": u["value"], "unit": "samples/s", "ms_per_step": u["ms_per_step"], "kernel_ms_mean": ur["kernel_ms_mean"],
+                "kernel_ms_per_rank": u["kernel_ms_per_rank"], "overhead_us_per_step": (u["ms_per_step"] - ur["kernel_ms_mean"]) * 1e3,
+                "roofline": {k: ur[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_mean", "kernel_ms_min",
+                                                "kernel_launches_timed", "algorithmic_bytes_per_launch")},
+                "kernel": u.get("desc"),
+            }
         for name, leg in legs.items():
             if name != main_leg:
                 line[name] = leg_summary(leg)

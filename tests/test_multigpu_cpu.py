@@ -3,6 +3,7 @@ per-GPU host threads and the reduce logic run here with the rank-local compute s
 double for `core._bincount`; the product default is the HIP path, covered by the gpu-marked tests) and with
 "virtual" device numbers — nothing below touches a GPU."""
 import os
+import re
 import subprocess
 import sys
 import threading
@@ -203,6 +204,12 @@ def test_sharded_inputs_must_match():
     b = _cpu_shards(np.zeros((6, 4)), 2, 1)
     with pytest.raises(ValueError):
         multigpu.histogram(a, b, bins=[np.arange(3.0)] * 2, _local=_local_oracle)
+    # sharded weights are cut like the inputs: another axis or other part shapes is an error, not a silent mismatch
+    with pytest.raises(ValueError, match="sharded weights"):
+        multigpu.histogram(a, bins=[np.arange(3.0)], weights=b, _local=_local_oracle)
+    c = _cpu_shards(np.zeros((8, 4)), 2, 0)
+    with pytest.raises(ValueError, match="sharded weights"):
+        multigpu.histogram(a, bins=[np.arange(3.0)], weights=c, _local=_local_oracle)
     with pytest.raises(TypeError):
         multigpu.histogram(np.zeros(4), bins=3)
 
@@ -215,7 +222,9 @@ def test_bench_spawns_its_ranks_and_fails_per_rank_without_gpus():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert "spawning 2 ranks" in r.stderr
-    assert "rank 1 of 2: needs GPU 1" in r.stderr
+    # torch.distributed.run SIGTERMs the surviving rank as soon as the first one exits: either rank's message may be
+    # the one that makes it to stderr
+    assert re.search(r"rank [01] of 2: needs GPU [01]", r.stderr)
     assert r.stdout.strip() == ""  # stdout carries the JSON line of a successful run, nothing else
 
 
@@ -238,8 +247,14 @@ def test_bench_multi_rank_control_flow_selftest(scaling):
     assert d[other]["samples_total"] == (20_000 if other == "strong" else 40_000)
     assert d["config"]["samples_total"] == (40_000 if scaling == "weak" else 20_000)
     assert len(d[other]["kernel_ms_per_rank"]) == 2
-    for key in ("value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+    for key in ("value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "overhead_us_per_step"):
         assert key in d
+    # the headline's unweighted variant (north_star's target sentence; VERDICT r2 "next" #5) rides along in the same line
+    u = d["unweighted"]
+    assert u["roofline"]["algorithmic_bytes_per_launch"] * 2 == d["roofline"]["algorithmic_bytes_per_launch"]  # 8 vs 16 B/sample
+    for key in ("value", "ms_per_step", "kernel_ms_mean", "overhead_us_per_step"):
+        assert u[key] is not None
+    assert "overhead_us_per_step" in d[other]
 
 
 def test_blocks_in_flight_per_gpu_are_bounded():
@@ -269,8 +284,10 @@ def test_blocks_in_flight_per_gpu_are_bounded():
 
 
 def test_reduce_partials_adds_per_gpu_then_across_gpus():
-    """second stage of the dask graph under the device-resident reduction: partials grouped by GPU, added there, the GPUs'
-    sums all-reduced (test seam instead of RCCL), one copy back; empty blocks arrive as host arrays"""
+    """second stage of the dask graph under the device-resident reduction: partials grouped by GPU, added there INTO A BUFFER
+    OF THE TASK'S OWN, the GPUs' sums all-reduced over the whole configured group (test seam instead of RCCL), one copy
+    back; empty blocks arrive as host arrays.  The upstream partials are neither changed nor freed: running the task twice
+    gives the same answer (a retried reduce task must not double-count or read freed memory)."""
     from xhistogram_amd import _native
 
     log = []
@@ -279,8 +296,12 @@ def test_reduce_partials_adds_per_gpu_then_across_gpus():
         def __init__(self, arr, device):
             self.arr, self.device, self.ptr, self.closed = arr.astype(np.float64).ravel().copy(), device, id(self), False
 
+        def upload(self, host):
+            assert not self.closed
+            self.arr[: host.size] = host.ravel()
+
         def add(self, other, count, tag):
-            assert other.device == self.device and not other.closed
+            assert other.device == self.device and not other.closed and not self.closed
             log.append(("add", self.device))
             self.arr[:count] += other.arr[:count]
 
@@ -291,11 +312,18 @@ def test_reduce_partials_adds_per_gpu_then_across_gpus():
         def close(self):
             self.closed = True
 
+    made = []
+
+    def alloc(device, nbytes):
+        made.append(FakeBuf(np.full(nbytes // 8, 123.0), device))  # (garbage: the task must zero it)
+        return made[-1]
+
     rng = np.random.default_rng(3)
     shape = (4, 1, 1, 7)  # a kept-axis chunk of 4 rows, two reduced axes as single-element dims, 7 bins
     blocks = [rng.integers(0, 9, shape).astype(np.float64) for _ in range(7)]
     devs = [2, 0, 2, 1, 0, 2, 1]
     parts = [_native.DevicePartial(FakeBuf(b, d), shape, np.float64) for b, d in zip(blocks, devs)]
+    before = [p.buf.arr.copy() for p in parts]
     empty = np.zeros(shape)
     nested = [[parts[0], parts[1], [parts[2]]], [parts[3], empty, parts[4]], [parts[5], parts[6]]]
 
@@ -305,18 +333,63 @@ def test_reduce_partials_adds_per_gpu_then_across_gpus():
         for s in sums:
             s.buf.arr[:count] = tot
 
-    got = multigpu.reduce_partials(nested, drop_axes=(1, 2), out_dtype="<f8", _allreduce=allreduce)
-    np.testing.assert_allclose(got, sum(blocks).squeeze((1, 2)))
-    assert got.shape == (4, 7)
-    assert [e for e in log if e[0] == "allreduce"] == [("allreduce", (0, 1, 2))]       # ONE exchange, GPUs in order
-    assert sorted(e[1] for e in log if e[0] == "add") == [0, 1, 2, 2]                     # 7 partials on 3 GPUs: 4 local adds
-    assert [e for e in log if e[0] == "download"] == [("download", 0)]                   # one copy back
-    assert all(p.buf.closed for p in parts)
-    # integer counts; a single GPU needs no exchange
+    multigpu.set_devices([0, 1, 2, 3])  # GPU 3 holds no partial of this chunk: it joins the exchange with zeros
+    try:
+        for attempt in range(2):
+            del log[:], made[:]
+            got = multigpu.reduce_partials(nested, drop_axes=(1, 2), out_dtype="<f8", _allreduce=allreduce, _alloc=alloc)
+            np.testing.assert_allclose(got, sum(blocks).squeeze((1, 2)))
+            assert got.shape == (4, 7)
+            assert [e for e in log if e[0] == "allreduce"] == [("allreduce", (0, 1, 2, 3))]    # ONE exchange, the whole group, in order
+            assert sorted(e[1] for e in log if e[0] == "add") == [0, 0, 1, 1, 2, 2, 2]          # every partial added once, on its GPU
+            assert [e for e in log if e[0] == "download"] == [("download", 0)]                   # one copy back
+            assert len(made) == 4 and all(b.closed for b in made)                                # the task's own buffers, released
+            assert not any(p.buf.closed for p in parts)                                          # upstream outputs: not freed ...
+            assert all(np.array_equal(p.buf.arr, b) for p, b in zip(parts, before))              # ... and not changed
+    finally:
+        multigpu.set_devices(None)
+    # integer counts; a single GPU needs no exchange (and no group beyond that GPU)
     ip = [_native.DevicePartial(FakeBuf(np.full((2, 1, 3), k), 5), (2, 1, 3), np.int64) for k in (1, 2, 3)]
-    got = multigpu.reduce_partials([ip], drop_axes=(1,), out_dtype="<i8", _allreduce=lambda *a: (_ for _ in ()).throw(AssertionError("no exchange for one GPU")))
+    got = multigpu.reduce_partials([ip], drop_axes=(1,), out_dtype="<i8", _alloc=alloc,
+                                   _allreduce=lambda *a: (_ for _ in ()).throw(AssertionError("no exchange for one GPU")))
     np.testing.assert_array_equal(got, np.full((2, 3), 6))
     assert got.dtype == np.int64
+
+
+def test_dask_exchange_follows_the_scheduler(monkeypatch):
+    """device-resident partials are handed from task to task only when dask's scheduler keeps every task
+    in this process; under the multiprocessing scheduler or dask.distributed the reference's host-side sum is the graph"""
+    import types
+
+    monkeypatch.delenv("XHIST_AMD_DASK_EXCHANGE", raising=False)
+    multigpu.set_dask_exchange(None)
+    multigpu.set_devices([0, 1])
+    fake_base = types.ModuleType("dask.base")
+    fake_dask = types.ModuleType("dask")
+    fake_dask.base = fake_base
+    monkeypatch.setitem(sys.modules, "dask", fake_dask)
+    monkeypatch.setitem(sys.modules, "dask.base", fake_base)
+
+    def getter(module, name):
+        def get(*a, **k):
+            return None
+
+        get.__module__, get.__name__ = module, name
+        return get
+
+    try:
+        for module, name, want in [("dask.threaded", "get", "rccl"), ("dask.local", "get_sync", "rccl"),
+                                   ("dask.multiprocessing", "get", "host"), ("distributed.client", "get", "host")]:
+            fake_base.get_scheduler = lambda g=getter(module, name): g
+            assert multigpu.dask_exchange() == want, (module, name)
+        fake_base.get_scheduler = lambda: None  # nothing configured: dask arrays default to the threaded scheduler
+        assert multigpu.dask_exchange() == "rccl"
+        multigpu.set_dask_exchange("rccl")      # an explicit choice wins
+        fake_base.get_scheduler = lambda g=getter("dask.multiprocessing", "get"): g
+        assert multigpu.dask_exchange() == "rccl"
+    finally:
+        multigpu.set_dask_exchange(None)
+        multigpu.set_devices(None)
 
 
 def test_dask_exchange_policy(monkeypatch):
@@ -347,3 +420,61 @@ def test_bench_default_run_lengths(monkeypatch):
         monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
         a = bench.parse()
         assert (a.steps, a.warmup) == want, (argv, a.steps, a.warmup)
+
+
+
+@pytest.mark.parametrize("var", ["LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID"])
+def test_a_launched_rank_keeps_to_its_gpu(monkeypatch, var):
+    """ranks started by srun / mpirun (not only torchrun) must not each grab every GPU of the node"""
+    from xhistogram_amd import core
+
+    for k in core.LOCAL_RANK_VARS + ("XHIST_AMD_DEVICES",):
+        monkeypatch.delenv(k, raising=False)
+    multigpu.set_devices(None)
+    monkeypatch.setattr(multigpu, "visible_devices", lambda: [0, 1, 2, 3, 4, 5, 6, 7])
+    assert multigpu.get_devices() == [0, 1, 2, 3, 4, 5, 6, 7]
+    monkeypatch.setenv(var, "5")
+    assert core.default_device() == 5 and multigpu.get_devices() == [5]
+    monkeypatch.setenv("XHIST_AMD_DEVICE", "2")  # the library's own variable wins
+    assert multigpu.get_devices() == [2]
+    monkeypatch.setenv("XHIST_AMD_DEVICES", "all")  # and an explicit spread wins over both
+    assert multigpu.get_devices() == [0, 1, 2, 3, 4, 5, 6, 7]
+
+
+def test_device_containers_pickle_through_host_memory_or_fail_loudly():
+    """DeviceBuffer / DevicePartial / DeviceArray must never pickle as a bare pointer.  Here (no GPU) the
+    serialising side is a double and the receiving side has no device: unpickling raises instead of producing a foreign
+    pointer; the GPU round trip is in tests/test_gpu_devicearray.py."""
+    import copy
+    import pickle
+
+    from xhistogram_amd import _native
+    from xhistogram_amd.devicearray import DeviceArray
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the real round trip runs in tests/test_gpu_devicearray.py")
+    buf = _native.DeviceBuffer.__new__(_native.DeviceBuffer)
+    buf.device, buf.nbytes, buf.ptr = 0, 24, 0xdead0000
+    payload = np.arange(3, dtype=np.float64)
+    buf.download = lambda host: host.__setitem__(slice(None), payload.view(np.uint8))
+    try:
+        fn, args = buf.__reduce__()
+        assert fn is _native._rebuild_buffer and args[0] == 0 and args[1] == 24
+        np.testing.assert_array_equal(args[2].view(np.float64), payload)  # the BYTES travel, not the pointer
+        blob = pickle.dumps(_native.DevicePartial(buf, (3,), np.float64))
+        assert b"dead0000" not in blob and str(0xdead0000).encode() not in blob
+        with pytest.raises(RuntimeError):  # no GPU on the receiving side: loud, no CPU stand-in
+            pickle.loads(blob)
+        with pytest.raises(RuntimeError):
+            copy.deepcopy(buf)
+        buf.ptr = None
+        with pytest.raises(ValueError):
+            pickle.dumps(buf)
+    finally:
+        buf.ptr = None  # (nothing to free)
+    arr = DeviceArray(None, 0xbeef0000, (2, 2), (16, 8), np.float64, 0)
+    arr_host = np.arange(4.0).reshape(2, 2)
+    fn, args = DeviceArray.__reduce__.__get__(type("A", (), {"to_numpy": lambda self: arr_host, "device": 0})())()
+    np.testing.assert_array_equal(args[0], arr_host)
+    with pytest.raises(RuntimeError):
+        fn(*args)

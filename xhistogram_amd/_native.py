@@ -181,6 +181,20 @@ def device_count():
     return n.value
 
 
+def physical_device(device):
+    """HIP device behind a LOGICAL device index of this library.  The identity, unless $XHIST_AMD_DEVICE_ALIAS ("0,0": two
+    logical devices on GPU 0) is set — a test facility that lets the per-GPU threads, plan caches and buffers of the
+    multi-GPU code run with real kernels on a one-GPU box (the native library parses the same variable)."""
+    env = os.environ.get("XHIST_AMD_DEVICE_ALIAS", "").strip()
+    if not env:
+        return int(device)
+    try:
+        alias = [int(t) for t in env.split(",")]
+    except ValueError:
+        return int(device)
+    return alias[device] if 0 <= device < len(alias) and len(alias) == device_count() else int(device)
+
+
 def device_info(device=0):
     name = C.create_string_buffer(256)
     cus = C.c_int(0)
@@ -398,6 +412,33 @@ class DeviceBuffer:
             self.close()
         except Exception:
             pass
+
+    # A device pointer means nothing in another process and must never be owned twice in this one: pickling (dask's
+    # multiprocessing / distributed schedulers, spilling) and copy / deepcopy go through HOST memory — the bytes are
+    # downloaded here and uploaded into a fresh allocation where the copy is rebuilt.
+    def __reduce__(self):
+        if not self.ptr:
+            raise ValueError("DeviceBuffer was closed: nothing to serialise")
+        host = np.empty(self.nbytes, np.uint8)
+        if self.nbytes:
+            self.download(host)
+        return (_rebuild_buffer, (self.device, self.nbytes, host))
+
+
+def _rebuild_buffer(device, nbytes, host):
+    """unpickle a DeviceBuffer: the same GPU index where the receiving process has one, its own GPU otherwise"""
+    count = C.c_int(0)
+    check(load().xhist_device_count(C.byref(count)))
+    if count.value < 1:
+        raise RuntimeError("xhist_amd: no MI355X visible to the process that unpickles a DeviceBuffer; this library has no CPU path")
+    if device >= count.value:
+        from . import core
+
+        device = core.default_device() % count.value
+    buf = DeviceBuffer(device, nbytes)
+    if nbytes:
+        buf.upload(np.ascontiguousarray(host))
+    return buf
 
 
 class DevicePartial:

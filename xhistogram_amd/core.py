@@ -89,16 +89,43 @@ _TAG_NP = {
 }
 
 
-def default_device():
-    """GPU used for host (numpy) inputs: $XHIST_AMD_DEVICE, else $LOCAL_RANK, else 0."""
-    for key in ("XHIST_AMD_DEVICE", "LOCAL_RANK"):
+# the local rank of a one-process-per-GPU job, as the common launchers export it (torch.distributed.run, srun, Open MPI,
+# MVAPICH2 / MPICH-hydra): such a process keeps to ITS GPU instead of spreading over the node's
+LOCAL_RANK_VARS = ("XHIST_AMD_DEVICE", "LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
+                   "MPI_LOCALRANKID")
+
+
+def launcher_local_rank():
+    """the first of LOCAL_RANK_VARS that is set, as an int; None outside a one-process-per-GPU launcher"""
+    for key in LOCAL_RANK_VARS:
         v = os.environ.get(key)
         if v not in (None, ""):
-            return int(v)
-    return 0
+            try:
+                return int(v)
+            except ValueError:
+                continue
+    return None
+
+
+def default_device():
+    """GPU used for host (numpy) inputs: $XHIST_AMD_DEVICE, else the launcher's local rank ($LOCAL_RANK, $SLURM_LOCALID,
+    $OMPI_COMM_WORLD_LOCAL_RANK, …), else 0."""
+    r = launcher_local_rank()
+    return 0 if r is None else r
 
 
 _tls = threading.local()
+
+
+def _torch_device_index(device):
+    """(logical) device index of this library for a torch.device: the tensor's own index — except under
+    $XHIST_AMD_DEVICE_ALIAS (tests: several logical devices on one GPU), where a thread that multigpu bound to logical
+    device k keeps k for the tensors that live on k's physical GPU"""
+    idx = device.index if device.index is not None else _torch().cuda.current_device()
+    bound = getattr(_tls, "device", None)
+    if bound is not None and bound != idx and os.environ.get("XHIST_AMD_DEVICE_ALIAS") and _native.physical_device(bound) == idx:
+        return bound
+    return idx
 
 
 def _host_device():
@@ -226,9 +253,9 @@ def _torch_contiguous(a):
     torch = _torch()
     out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
     item = a.element_size()
-    dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
+    dev = _torch_device_index(a.device)
     _native.copy_nd(dev, a.shape, a.data_ptr(), tag, [st * item for st in a.stride()], out.data_ptr(), tag,
-                    [st * item for st in out.stride()], torch.cuda.current_stream(dev).cuda_stream)
+                    [st * item for st in out.stride()], torch.cuda.current_stream(a.device).cuda_stream)
     return out
 
 
@@ -291,8 +318,8 @@ def _execute_views(views, wview, nrows, ncols, sample_dtypes, bins, backend, lik
         torch = _torch()
         if like.device.type != "cuda":
             raise RuntimeError("torch inputs must live on an MI355X (device='cuda'); got %s" % like.device)
-        device = like.device.index if like.device.index is not None else torch.cuda.current_device()
-        stream = torch.cuda.current_stream(device).cuda_stream
+        device = _torch_device_index(like.device)
+        stream = torch.cuda.current_stream(like.device).cuda_stream
         mem = _native.MEM_DEVICE
     _native.require_device(device)
     plan = _get_plan(edges, cmp_domain, device)
@@ -733,8 +760,8 @@ def _device_bin_edges(a, b, r, has_weights):
             dev, stream = a.device, 0
         else:
             torch = _torch()
-            dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            dev = _torch_device_index(a.device)
+            stream = torch.cuda.current_stream(a.device).cuda_stream
         lo, hi = _native.minmax(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev, stream)
         return np.histogram_bin_edges(np.array([lo, hi]).astype(proto_dtype), bins=b, range=None)
     return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=r)
@@ -944,7 +971,7 @@ def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
     sig, per_input = _fast_signature(bins, len(args))
     if sig is None:
         return None
-    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    dev_index = _torch_device_index(device)
     key = (dev_index, sig)
     with _plans_lock:
         hit = _FAST.get(key)
@@ -973,7 +1000,7 @@ def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
         views = [_native.make_view(a.data_ptr(), tag, cols, 1) for a in args]
         wview = _native.make_view(weights.data_ptr(), wtag, cols, 1) if weighted else None
         plan.execute(views, wview, rows, cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False,
-                     stream=torch.cuda.current_stream(dev_index).cuda_stream)
+                     stream=torch.cuda.current_stream(device).cuda_stream)
     h = out.reshape(tuple(shape[:kept]) + plan.bins_shape)
     if density:
         h = _density(h, edges, len(args))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Build libxhist_amd.so in-tree for gfx950 (cross-compiles without a GPU).  Six translation units,
-# compiled in parallel: five that instantiate the float64 / float32 / mixed-dtype vector and routing kernels, and the rest.
+# Build libxhist_amd.so in-tree for gfx950 (cross-compiles without a GPU).  Eight translation units,
+# compiled in parallel: seven that instantiate the float64 / float32 / mixed-dtype vector and routing kernels, and the rest.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libxhist_amd.so"
@@ -9,7 +9,7 @@ obj="$(mktemp -d)"
 trap 'rm -rf "$obj"' EXIT
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
 pids=()
-tus=(xhist_capi xhist_pick_f64 xhist_pick_f32 xhist_pick_mixed xhist_route_f64 xhist_route_f32)
+tus=(xhist_capi xhist_pick_f64 xhist_pick_f32 xhist_pick_mixed xhist_route_f64_b1024 xhist_route_f64_b512 xhist_route_f32_b1024 xhist_route_f32_b512)
 for tu in "${tus[@]}"; do
   "$HIPCC" "${flags[@]}" -c -o "$obj/$tu.o" "$here/$tu.hip" &
   pids+=($!)

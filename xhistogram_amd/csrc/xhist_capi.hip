@@ -548,7 +548,7 @@ extern "C" int xhist_pointer_device(const void* ptr, int* device) {
     (void)hipGetLastError();
     return fail(XHIST_ERR_INVALID, "%p is not device memory of this process", ptr);
   }
-  *device = attr.device;
+  *device = logical_device(attr.device);
   return XHIST_OK;
 }
 

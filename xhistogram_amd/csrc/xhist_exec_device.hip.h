@@ -183,11 +183,17 @@ static bool exact_records_env() {
   return v;
 }
 
-static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi = false) {
-  if (sdt == XHIST_F64) return xhist_pick_route_f64(wdt, D, scan, multi);
-  if (sdt == XHIST_F32) return xhist_pick_route_f32(wdt, D, scan, multi);
+static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi, int block) {
+  if (sdt == XHIST_F64)
+    return block == 1024 ? xhist_pick_route_f64_b1024(wdt, D, scan, multi) : block == 512 ? xhist_pick_route_f64_b512(wdt, D, scan, multi) : nullptr;
+  if (sdt == XHIST_F32)
+    return block == 1024 ? xhist_pick_route_f32_b1024(wdt, D, scan, multi) : block == 512 ? xhist_pick_route_f32_b512(wdt, D, scan, multi) : nullptr;
   return nullptr;
 }
+
+// workgroup size of the routing pass ("route_block" overrides): two 512-thread workgroups per CU where records carry
+// weights, one of 1024 threads for the 2-byte records of counts (see xhist_route.hip.h for the measurements)
+static int route_block_for(const xhist_plan* p, bool weighted) { return p->route_block ? p->route_block : (weighted ? 512 : 1024); }
 
 //
 // Packed records (float64 weights).  A record is normally a 16-bit bin code plus the float64 weight: 10 bytes in two streams.
@@ -211,22 +217,23 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const int n_parts = parts_per_row * rows;
   const int64_t n_total = n_cols * rows;
   if (n_total >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
-  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan, rows > 1);
+  const int block = route_block_for(p, weighted);
+  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan, rows > 1, block);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
   bool pack = weighted && wdt == XHIST_F64 && p->records48_pref >= 0 && !exact_records_env();
-  if (pack && !p->mixed_hint) {
+  if (!p->mixed_hint) {  // pinned host words the GPU writes: [0] a call met weights of both signs, [1] a chunk pool ran dry
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->mixed_hint) {
       uint32_t* h = nullptr;
-      if (hipHostMalloc((void**)&h, 64, hipHostMallocDefault) == hipSuccess) { *h = 0u; p->mixed_hint = h; }
+      if (hipHostMalloc((void**)&h, 64, hipHostMallocDefault) == hipSuccess) { h[0] = h[1] = 0u; p->mixed_hint = h; }
       else (void)hipGetLastError();
     }
   }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
-  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1) : nullptr;
+  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block) : nullptr;
   if (pack && !k_route48) pack = false;
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
-  const int tile = route_tile(dtype_size(sdt));
+  const int tile = route_tile(block);
   const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile);
   const bool rec_f32 = wdt == XHIST_F32;
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
@@ -238,14 +245,16 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_total + 65535) / 65536));
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
-  while (lg < 14 && (((n_total / G) + tile) >> lg) + n_parts + 16 > kRouteListCap) ++lg;
+  while (lg < 14 && (((n_total / G) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
   const int64_t GP = (int64_t)G * n_parts;
   // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
   // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
   // and ends with at most two ranges in hand.
   const int64_t used = ((n_total + 7 * GP) >> lg) + GP;
-  const int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
+  int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
+  // "route_pool_pct" < 100 (tests): a pool too small on purpose — what finds no chunk goes straight into the output
+  if (p->route_pool_pct > 0 && p->route_pool_pct < 100) pool_chunks = std::max<int64_t>(1, pool_chunks * p->route_pool_pct / 100);
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
@@ -312,6 +321,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   ra.gate = nullptr;
   ra.hint = nullptr;
   ra.gate_mode = 0;
+  ra.dry = p->mixed_hint ? p->mixed_hint + 1 : nullptr;
 
   if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
   kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
@@ -326,7 +336,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     kernel_fn_acc_chunks k_acc48 = (kernel_fn_acc_chunks)part_accumulate_chunks<true, double, true>;
     if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
     if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-    hipLaunchKernelGGL(k_route48, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);  // packed records, notes the signs
+    hipLaunchKernelGGL(k_route48, dim3(G), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
     HIPR(hipGetLastError());
     RouteArgs ra48 = ra;
     ra48.gate = d_ctr + 1;
@@ -341,7 +351,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     ra.gate_mode = 2;
     ra.hint = p->mixed_hint;
   }
-  hipLaunchKernelGGL(k_route, dim3(G), dim3(kRouteBlock), lds_route, stream, kp, ra);
+  hipLaunchKernelGGL(k_route, dim3(G), dim3(block), lds_route, stream, kp, ra);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
   HIPR(hipGetLastError());
@@ -350,7 +360,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
              "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
-             rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, kRouteBlock, G, Gb, lds_route, lds_acc, scan,
+             rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
     if (last)
@@ -889,7 +899,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       int r_scan = scan;
       const TableSet* r_tset = tset;
       bool r_f32 = use_f32;
-      const int r_tile = route_tile(dtype_size(sdt));
+      const int r_tile = route_tile(route_block_for(p, weighted));
       const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, r_tile), lds_notab = part_route_lds(0, (int)n_parts, weighted, r_tile);
       if (p->arith && arith_pref >= 0 && scan != kScanArith && n_parts <= 128 &&
           (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab)) {

@@ -53,6 +53,10 @@ struct DimTable {
   // edge by edge at plan creation: digitize needs no table at all (count_le_scan<.., kScanArith>)
   double step, inv_step;
   int32_t arith;
+  // 0.5 - delta, where delta bounds |fl(fl(e_j - e_0) * inv_step) - j| over every edge j (measured at plan creation with
+  // the kernels' own arithmetic, doubled for margin): a sample whose position t = (x - e_0) * inv_step has a fractional
+  // part with |frac - 0.5| < arith_h lies strictly inside bin floor(t) (bin_arith_fast).  0 = never decide by arithmetic.
+  double arith_h;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
   int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
@@ -249,6 +253,28 @@ __device__ __forceinline__ uint32_t count_le_arith(double x, const DimTable& t) 
   const uint32_t g = (uint32_t)(int)gd;
   const double e_g1 = (int)g + 1 == t.nb ? t.eL_f : m1 + t.e0_f;
   return g + (e_g <= x ? 1u : 0u) + (e_g1 <= x ? 1u : 0u);
+}
+
+// Bin of x for arithmetic edges WITHOUT recomputing edges, when x is not within delta bins of one.
+//   t(x) = fl(fl(x - e_0) * inv_step) is monotone non-decreasing in x (IEEE subtraction and multiplication by a positive
+//   constant are), and plan creation has measured |t(e_j) - j| <= delta for EVERY edge with the same two operations.
+//   Hence e_j <= x < e_{j+1} implies j - delta <= t(x) <= j + 1 + delta, and conversely a sample with g = floor(t(x)) and
+//   delta < frac(t(x)) < 1 - delta cannot lie below e_g (t(x) <= g + delta would follow) nor at or above e_{g+1}
+//   (t(x) >= g + 1 - delta): it is in bin g exactly when 0 <= g < nb, below e_0 when g < 0 (t(x) < 0 means x < e_0) and
+//   above e_last when g >= nb.  Everything else — on or next to an edge, NaN, +-inf (frac is NaN) — sets `near` and is
+//   decided by count_le_arith's exact compares.  9 full-rate float64 operations per sample and dimension instead of ~25
+//   (C5's routing pass spent more than half of its instruction issue on the exact form).
+// Returns the bin, or -1 for samples below e_0 / above e_last / NaN; valid only when `near` comes back false.
+__device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool& near) {
+  const double tt = (x - t.e0_f) * t.inv_step;
+  const double fl = __builtin_floor(tt);
+  const double f = tt - fl;
+  near = !(__builtin_fabs(f - 0.5) < t.arith_h);  // (NaN compares false: near)
+  // fl as an integer without a conversion instruction (quarter rate): the low word of fl + 1.5 * 2^52 is fl mod 2^32
+  const double magic = fl + 6755399441055744.0;
+  const int g = (int)(uint32_t)(uint64_t)__double_as_longlong(magic);
+  const bool inside = (fl >= 0.0) & (fl < (double)t.nb);
+  return inside ? g : -1;
 }
 
 template <int CMP, int SCAN, typename TabPtr>

@@ -204,11 +204,11 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   p->n_dims = n_inputs;
   p->cmp = cmp_domain;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+  if (hipGetDeviceProperties(&prop, physical_device(device)) == hipSuccess) {
     p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     p->lds_max = prop.sharedMemPerBlock;
     int optin = 0;
-    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > 0)
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, physical_device(device)) == hipSuccess && optin > 0)
       p->lds_max = std::max(p->lds_max, (size_t)optin);
   }
 
@@ -308,11 +308,27 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
       }
       if (ok) ok = e[nb] >= e[nb - 1];
       all = ok;
+      // delta of bin_arith_fast: how far fl(fl(e_j - e_0) * inv_step) is from j, over EVERY edge (the last included),
+      // with the kernel's two operations (no fma can form: the subtraction feeds the product); doubled plus 2^-40 for
+      // strictness.  Bins resolved so badly that delta reaches 2^-10 keep the exact compares for every sample.
+      double arith_h = 0.0;
+      if (ok) {
+        const double inv = 1.0 / step;
+        double delta = 0.0;
+        for (int j = 0; j <= nb; ++j) {
+          volatile double off = e[j] - e[0];
+          volatile double tj = off * inv;
+          delta = std::max(delta, std::fabs(tj - (double)j));
+        }
+        delta = 2.0 * delta + 0x1p-40;
+        if (delta < 0x1p-10) arith_h = 0.5 - delta;
+      }
       if (ok)
         for (auto& dom : p->ts[0]) {
           dom.dim[d].step = step;
           dom.dim[d].inv_step = 1.0 / step;
           dom.dim[d].arith = 1;
+          dom.dim[d].arith_h = arith_h;
         }
     }
     p->arith = all;
@@ -357,6 +373,13 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
   } else if (!strcmp(key, "records48")) {
     p->records48_pref = value < 0 ? -1 : 0;
     if (p->mixed_hint) *p->mixed_hint = 0u;  // (setting the knob also forgets what earlier calls saw)
+  } else if (!strcmp(key, "route_block")) {
+    if (value != 0 && value != 512 && value != 1024) return fail(XHIST_ERR_INVALID, "route_block must be 0 (auto), 512 or 1024");
+    p->route_block = (int)value;
+  } else if (!strcmp(key, "route_pool_pct")) {
+    if (value < 0 || value > 100) return fail(XHIST_ERR_INVALID, "route_pool_pct must be in [0, 100]");
+    p->route_pool_pct = (int)value;
+    if (value != 0 && p->mixed_hint) p->mixed_hint[1] = 0u;  // (a new setting forgets what earlier calls ran into; 0 keeps the note readable)
   } else if (!strcmp(key, "partition")) {
     p->partition = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lanes")) {
@@ -390,7 +413,9 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
 extern "C" int xhist_plan_describe(xhist_plan* p, char* buf, size_t cap) {
   if (!p || !buf || !cap) return fail(XHIST_ERR_INVALID, "plan / buf is NULL");
   std::lock_guard<std::mutex> lk(p->mu);
-  strncpy(buf, p->desc.c_str(), cap - 1);
+  // (the pool-dry note is written by the GPU: it is current once the caller has synchronised with the launch)
+  const std::string d = p->desc + ((p->mixed_hint && p->mixed_hint[1]) ? " pool_dry=1" : "");
+  strncpy(buf, d.c_str(), cap - 1);
   buf[cap - 1] = 0;
   return XHIST_OK;
 }

@@ -1,0 +1,4 @@
+// xhist_route_f64_b512.hip — instantiates part_route for double samples, 512-thread workgroups (see xhist_pick.hip.h, xhist_route.hip.h)
+#include "xhist_pick.hip.h"
+
+kernel_fn_route xhist_pick_route_f64_b512(int wdt, int D, int scan, bool multi) { return route_pick<double, 512>(wdt, D, scan, multi); }

@@ -91,6 +91,12 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.device = int(device)
 
+    # pickling / copy.copy / copy.deepcopy: through host memory, into a fresh allocation (a device pointer means nothing in
+    # another process, and two owners of one allocation would free it twice).  A view pickles as a contiguous copy of what
+    # it shows; foreign owners (torch tensors) are not dragged along.
+    def __reduce__(self):
+        return (_rebuild, (self.to_numpy(), self.device))
+
     # ---- construction ---------------------------------------------------------------------------------
     @classmethod
     def empty(cls, shape, dtype, device=None):
@@ -283,6 +289,15 @@ class DeviceArray:
         if impl is None:
             return NotImplemented
         return impl(*args, **kwargs)
+
+
+def _rebuild(host, device):
+    """unpickle: upload to the same GPU index where the receiving process has one, else to its own GPU"""
+    try:
+        n = _native.device_count()
+    except Exception:
+        n = 0
+    return DeviceArray.from_numpy(host, device if device < n else None)
 
 
 def _concatenate(arrays, axis=0, out=None, dtype=None, casting=None):

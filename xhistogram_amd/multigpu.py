@@ -24,7 +24,7 @@ own RCCL communicator (``xhist_comm_*`` of the C ABI; RCCL is thread-safe with o
 thread).  ctypes releases the GIL for the duration of every native call, so the threads overlap.
 
 Which GPUs: ``set_devices`` / ``$XHIST_AMD_DEVICES`` ("all", or "0,2,5"); default = every visible
-GPU, except under a one-rank-per-GPU launcher (``$LOCAL_RANK`` / ``$XHIST_AMD_DEVICE`` set), where a
+GPU, except under a one-rank-per-GPU launcher (``$LOCAL_RANK`` / ``$SLURM_LOCALID`` / ``$OMPI_COMM_WORLD_LOCAL_RANK`` / … or ``$XHIST_AMD_DEVICE`` set), where a
 process must keep to its own GPU.  Nothing here computes on the CPU: a shard whose GPU path fails
 raises.
 """
@@ -87,8 +87,8 @@ def get_devices():
         env = os.environ.get("XHIST_AMD_DEVICES", "").strip()
         if env:
             spec = "all" if env.lower() == "all" else [int(t) for t in env.split(",") if t.strip() != ""]
-    if spec is None and any(os.environ.get(k) not in (None, "") for k in ("XHIST_AMD_DEVICE", "LOCAL_RANK")):
-        return [core.default_device()]  # a rank of a one-process-per-GPU job keeps to its GPU
+    if spec is None and core.launcher_local_rank() is not None:
+        return [core.default_device()]  # a rank of a one-process-per-GPU job (torchrun, srun, mpirun) keeps to its GPU
     if spec is None or spec == "all":
         return visible_devices() or [core.default_device()]
     return list(spec)
@@ -104,13 +104,31 @@ def set_dask_exchange(mode):
     _dask_exchange = mode
 
 
+def _scheduler_shares_memory():
+    """True when dask's active scheduler runs every task in THIS process (threaded — the default for arrays — or
+    synchronous): only then may a block hand a device-resident partial to the reduce task as it is.  Under the
+    multiprocessing scheduler or dask.distributed a partial crosses a process boundary; it survives that (DeviceBuffer
+    pickles through host memory) but then the reference's own host-side sum is the cheaper graph."""
+    try:
+        from dask.base import get_scheduler
+
+        get = get_scheduler()
+    except Exception:
+        return True
+    if get is None:
+        return True
+    mod, name = getattr(get, "__module__", "") or "", getattr(get, "__name__", "") or ""
+    return mod.startswith("dask.threaded") or (mod.startswith("dask.local") and name == "get_sync")
+
+
 def dask_exchange():
-    """"rccl" when the blocks are spread over more than one GPU (or $XHIST_AMD_DASK_EXCHANGE / set_dask_exchange says so),
-    else "host": with one GPU the partials of an output chunk meet on the host anyway and the reference's own graph is kept"""
+    """"rccl" when the blocks are spread over more than one GPU and the scheduler keeps every task in this process (or
+    $XHIST_AMD_DASK_EXCHANGE / set_dask_exchange says so), else "host": with one GPU the partials of an output chunk meet
+    on the host anyway and the reference's own graph is kept"""
     mode = _dask_exchange or os.environ.get("XHIST_AMD_DASK_EXCHANGE", "").strip().lower() or None
     if mode in ("host", "rccl"):
         return mode
-    return "rccl" if len(get_devices()) > 1 else "host"
+    return "rccl" if len(get_devices()) > 1 and _scheduler_shares_memory() else "host"
 
 
 @contextlib.contextmanager
@@ -413,13 +431,17 @@ def _flatten(nested):
         yield nested
 
 
-def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None):
+def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None, _alloc=None):
     """Second stage of the dask graph under ``dask_exchange() == "rccl"`` — replaces ``bin_counts.sum(drop_axes)``
     (core.py:439) for ONE output chunk.  ``nested`` holds the partial histograms of every block that contributes to the
     chunk (``_native.DevicePartial`` on the GPU that computed each; host arrays for empty blocks), all of one shape with
-    the reduced axes as single-element dims.  The partials of each GPU are added up on that GPU (``xhist_buffer_add``), the
-    GPUs' sums by ONE in-place RCCL all-reduce issued from the GPUs' host threads, and the first GPU's copy comes back to
-    the host: one device-to-host copy per output chunk instead of one per block.  ``_allreduce`` is a test seam."""
+    the reduced axes as single-element dims.  The partials of each GPU are added up on that GPU (``xhist_buffer_add``) in a
+    buffer of this task's OWN — the upstream partials are task outputs and stay untouched, so a re-run of this task (a
+    retry, a recompute) sees what the first run saw; they are freed when dask drops them — the GPUs' sums by ONE in-place
+    RCCL all-reduce issued from the GPUs' host threads, and the first GPU's copy comes back to the host: one
+    device-to-host copy per output chunk instead of one per block.  The all-reduce always spans the WHOLE configured
+    device group (GPUs without a partial for this chunk contribute zeros), so one set of communicators serves every chunk
+    instead of one per subset of GPUs.  ``_allreduce`` / ``_alloc`` are test seams."""
     parts = list(_flatten(nested))
     dtype = np.dtype(out_dtype)
     host = [np.asarray(p) for p in parts if not isinstance(p, _native.DevicePartial)]
@@ -432,29 +454,34 @@ def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None):
         for p in on_gpu:
             assert p.shape == shape and p.dtype == pdtype, (p.shape, shape)
             by_dev.setdefault(p.device, []).append(p)
-        devices = sorted(by_dev)
+        group_devices = sorted(set(get_devices()) | set(by_dev)) if len(by_dev) > 1 else sorted(by_dev)
+        alloc = _alloc or (lambda device, nbytes: _native.DeviceBuffer(device, nbytes))
+        zeros = np.zeros(count, pdtype)
         sums = []
-        for d in devices:  # this GPU's partials -> its first partial (same GPU, NULL stream: ordered)
-            acc = by_dev[d][0]
-            for other in by_dev[d][1:]:
-                acc.buf.add(other.buf, count, tag)
-            sums.append(acc)
-        if len(devices) > 1:
-            if _allreduce is not None:
-                _allreduce(sums, count, tag)
-            else:
-                group = group_for(devices)
-                with group.collective:
-                    comms = group.comms()
+        try:
+            for d in group_devices:  # this GPU's partials -> a zeroed buffer of this task (same GPU, NULL stream: ordered)
+                acc = _native.DevicePartial(alloc(d, count * pdtype.itemsize), shape, pdtype)
+                sums.append(acc)
+                acc.buf.upload(zeros)
+                for other in by_dev.get(d, ()):
+                    acc.buf.add(other.buf, count, tag)
+            if len(group_devices) > 1:
+                if _allreduce is not None:
+                    _allreduce(sums, count, tag)
+                else:
+                    group = group_for(group_devices)
+                    with group.collective:
+                        comms = group.comms()
 
-                    def one(rank, device, acc):
-                        comms[rank].allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
-                        acc.buf.synchronize()
+                        def one(rank, device, acc):
+                            comms[rank].allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
+                            acc.buf.synchronize()
 
-                    group.run(one, sums)
-        total = sums[0].to_numpy()  # (download waits for the NULL stream of that GPU)
-        for p in on_gpu:
-            p.buf.close()
+                        group.run(one, sums)
+            total = sums[0].to_numpy()  # (download waits for the NULL stream of that GPU)
+        finally:
+            for acc in sums:
+                acc.buf.close()
     for h in host:
         total = h.astype(dtype, copy=True) if total is None else total + h
     if total is None:
@@ -510,7 +537,7 @@ def scatter(array, devices=None, axis=0):
         piece = _take(array, axis % array.ndim, lo, hi)
         if not core._is_torch(piece):
             piece = torch.from_numpy(np.ascontiguousarray(piece))
-        return piece.to(torch.device("cuda", device)).contiguous()
+        return piece.to(torch.device("cuda", _native.physical_device(device))).contiguous()
 
     return Sharded(group.run(one, [None] * len(devs)), axis % array.ndim, devs)
 
@@ -566,6 +593,9 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     if has_weights and isinstance(weights, Sharded):
         if weights.devices != first.devices:
             raise ValueError("weights must be sharded over the same devices")
+        if weights.axis != first.axis or [tuple(p.shape) for p in weights.parts] != [tuple(p.shape) for p in first.parts]:
+            raise ValueError("sharded weights must be cut like the inputs (axis %d, part shapes %s); weights that broadcast "
+                             "go in as ONE plain tensor" % (first.axis, [tuple(p.shape) for p in first.parts]))
         w_parts = weights.parts
     else:
         w_parts = [weights] * world
@@ -583,7 +613,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         w = w_parts[rank]
         if _local is not None:
             return _local(arrays + ([w] if has_weights else []), has_weights, axis, edges, block_size)
-        torch.cuda.set_device(device)
+        torch.cuda.set_device(_native.physical_device(device))
         dev = arrays[0].device
         w_raw = None
         if has_weights:
@@ -612,12 +642,12 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
 
             def allreduce(rank, device, t):
                 torch = core._torch()
-                torch.cuda.set_device(device)
+                torch.cuda.set_device(_native.physical_device(device))
                 t = t.contiguous()
                 tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
-                stream = torch.cuda.current_stream(device).cuda_stream
+                stream = torch.cuda.current_stream(t.device).cuda_stream
                 comms[rank].allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
-                torch.cuda.current_stream(device).synchronize()
+                torch.cuda.current_stream(t.device).synchronize()
                 return t
 
             counts = group.run(allreduce, parts)[0]
