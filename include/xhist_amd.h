@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 6
+#define XHIST_ABI_VERSION 7
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -143,6 +143,15 @@ int xhist_bincount_rows(int device, int n_inputs, const xhist_array* samples,
  * (core.py:383-388).  result[0] = min, result[1] = max, as float64 (HOST pointer). */
 int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result,
                  int mem_kind, void* stream);
+
+/* count / min / max / mean / sum of squared deviations of the elements of a DEVICE-resident [M, C] array that lie in
+ * [lo, hi] (use_range != 0; NaN never does) or of all of them: what numpy's bin-width estimators need of the data —
+ * np.histogram_bin_edges with bins = "sqrt" | "sturges" | "rice" | "scott" (core.py:383-388 hands it the whole array,
+ * which for a GPU-resident array would mean a copy to the host).  result (HOST, 5 doubles) = {count, min, max, mean, M2};
+ * min / max are NaN when a counted element is NaN (numpy then rejects the range); M2 only when want_m2 != 0 (a second
+ * pass over the data with the mean of the first).  Synchronises `stream`. */
+int xhist_moments(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, int use_range, double lo, double hi,
+                  int want_m2, double* result, int mem_kind, void* stream);
 
 /* ---- exchange between GPUs (one process per GPU; RCCL over xGMI) ---------------------------- */
 /* Sharded inputs produce one partial histogram per GPU; what the reference does with dask's

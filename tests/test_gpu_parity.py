@@ -4,6 +4,8 @@
 Bar (north_star): unweighted int64 counts bit-exact; float64 weighted / density within 1e-6
 relative (tests/conftest.py::assert_hist_equal).  Run with ``pytest -m gpu`` on an MI355X.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1146,6 +1148,71 @@ def test_partitioned_mode_chunk_pool_runs_dry(xh, weights, pct):
     torch.cuda.synchronize()
     assert "pool_dry=1" not in plan.describe(), plan.describe()
     plan.set_param("route_pool_pct", 0)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.int32])
+@pytest.mark.parametrize("name", ["sqrt", "sturges", "rice", "scott"])
+def test_bin_estimators_on_device_resident_data_without_a_host_copy(xh, name, dt, monkeypatch):
+    """f-1 (VERDICT r2 "next" #7): np.histogram_bin_edges' cheap estimators from ONE reduction on the GPU (xhist_moments):
+    the edges are bit-identical to numpy's (core.py:383-388) and the tensor never visits the host"""
+    rng = np.random.default_rng(7)
+    a = (rng.standard_normal((3, 50_001)) * 3 + 1).astype(dt) if np.dtype(dt).kind == "f" else rng.integers(-40, 90, (3, 50_001)).astype(dt)
+    t = _dev(a)
+    monkeypatch.setattr(torch.Tensor, "cpu", lambda self, *args, **kw: (_ for _ in ()).throw(AssertionError("the data went to the host")))
+    for r in (None, (-2.0, 5.5), (0, 30)):
+        want = np.histogram_bin_edges(a, bins=name, range=r)
+        got = xh._device_bin_edges(t, name, r, False)
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want, err_msg=str((name, dt, r)))
+    tv = t[:, ::3]  # a strided view: the reduction takes strides
+    np.testing.assert_array_equal(xh._device_bin_edges(tv, name, None, False), np.histogram_bin_edges(a[:, ::3], bins=name))
+    monkeypatch.undo()
+    h, edges = xh.histogram(t, bins=name)
+    want_h, want_e = np.histogram(a, bins=name)
+    np.testing.assert_array_equal(edges[0] if isinstance(edges, (list, tuple)) else edges, want_e)
+    np.testing.assert_array_equal(h.cpu().numpy(), want_h)
+
+
+def test_bin_estimators_that_need_the_data_still_work(xh):
+    """"fd" / "auto" / "doane" / "stone" (percentiles, third moments): numpy's implementation on a host copy, same edges"""
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal(20_000)
+    for name in ("fd", "auto", "doane", "stone"):
+        np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), np.histogram_bin_edges(a, bins=name))
+    with pytest.raises(TypeError):
+        xh._device_bin_edges(_dev(a), "sqrt", None, True)  # weighted data: numpy's own TypeError
+
+
+def test_scratch_cache_shrinks_to_what_recent_calls_use(xh):
+    """VERDICT r2 "weak" #8: the library's caching allocator keeps what the largest RECENT call held (so C5's record streams
+    are allocated once), not a fixed half of the device: after a call that needed hundreds of MB, a run of small calls hands
+    the memory back to the driver (a torch process sharing the GPU gets it)."""
+    if os.environ.get("XHIST_AMD_POOL_KEEP_GB"):
+        pytest.skip("the keep limit is fixed by the environment")
+    rng = np.random.default_rng(5)
+    n = 40_000_000
+    x, y, w = (torch.as_tensor(rng.standard_normal(n)).cuda() for _ in range(3))
+    edges = [np.linspace(-4, 4, 1025)] * 2
+    small = rng.standard_normal(20_000)
+    e1 = np.linspace(-4, 4, 33)
+    for _ in range(600):  # (whatever earlier tests left behind ages out of the allocator's two windows)
+        xh.histogram(small, bins=e1)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    h, _ = xh.histogram(x, y, bins=edges, weights=w.abs())
+    torch.cuda.synchronize()
+    free_big, _ = torch.cuda.mem_get_info()
+    held = free_before - free_big
+    assert held > 200 << 20, held  # the record streams of 4*10^7 samples stay cached: the next such call allocates nothing
+    h2, _ = xh.histogram(x, y, bins=edges, weights=w.abs())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free_big - (64 << 20)
+    for _ in range(600):  # host-route calls stage through a few KB of scratch each: > two windows of 256 frees
+        xh.histogram(small, bins=e1)
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after - free_big > held - (96 << 20), (free_before, free_big, free_after)
+    np.testing.assert_allclose(h.cpu().numpy(), h2.cpu().numpy(), rtol=1e-9)
 
 
 # ---------------------------------------------------------------------------------------------

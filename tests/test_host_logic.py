@@ -237,3 +237,70 @@ def test_overlapping_rows_and_unaligned_fields_take_the_copying_route():
     ptr, tag, rs, cs, _, _, keep = core._strided_view(col, "numpy")
     assert keep is not col and keep.flags.c_contiguous and (rs, cs) == (1, 1)
     np.testing.assert_array_equal(keep.ravel(), np.arange(7.0))
+
+
+def test_bin_width_estimators_restated_from_moments_match_numpy(monkeypatch):
+    """VERDICT r2 "next" #7 (f-1): bins="sqrt" | "sturges" | "rice" | "scott" on device-resident data come from one fused
+    count / min / max / mean / M2 reduction (xhist_moments) instead of a host copy of the array.  Here the reduction is
+    a numpy double, so what is pinned is the host logic around it: the edges must be BIT-identical to
+    np.histogram_bin_edges (core.py:383-388) — same dtype, same errors — for float64 / float32 / integer data, with and
+    without a range, or the function must decline (None = numpy decides on a host copy)."""
+    from xhistogram_amd import _native, core
+
+    cur = {}
+
+    def fake_moments(view, nr, nc, lo, hi, want_m2, dev, stream):
+        x = cur["a"].ravel().astype(np.float64)
+        if lo is not None:
+            x = x[(x >= lo) & (x <= hi)]
+        if x.size == 0:
+            return 0, np.inf, -np.inf, np.nan, np.nan
+        return x.size, x.min(), x.max(), x.mean(), ((x - x.mean()) ** 2).sum()
+
+    monkeypatch.setattr(_native, "moments", fake_moments)
+    monkeypatch.setattr(core, "_strided_view", lambda flat, backend: (0, 0, 0, 1, 0, 0, None))
+
+    class Resident:
+        def __init__(self, a):
+            self.size, self.device, self.shape = a.size, 0, (1, a.size)
+
+        def reshape(self, *shape):
+            return self
+
+    rng = np.random.default_rng(0)
+    declined = checked = 0
+    for dt in (np.float64, np.float32, np.int32, np.uint8, np.int64):
+        for trial in range(40):
+            n = int(rng.integers(1, 5000))
+            if np.dtype(dt).kind == "f":
+                a = (rng.standard_normal(n) * rng.uniform(0.1, 100)).astype(dt)
+            else:
+                a = rng.integers(0 if np.dtype(dt).kind == "u" else -50, 200, n).astype(dt)
+            if trial % 7 == 0:
+                a[:] = a[0]
+            if trial % 13 == 5 and np.dtype(dt).kind == "f":
+                a[0] = np.nan
+            cur["a"] = a
+            for name in ("sqrt", "sturges", "rice", "scott"):
+                for r in (None, (-1.0, 2.5), (0, 100), (5, 5), (np.float32(0.1), np.float32(7.3)), (2, 1)):
+                    try:
+                        want = np.histogram_bin_edges(a, bins=name, range=r)
+                    except Exception as exc:  # noqa: BLE001 - compared below
+                        want = (type(exc), str(exc))
+                    try:
+                        got = core._device_estimator_edges(Resident(a), name, r, np.dtype(dt), True)
+                    except Exception as exc:  # noqa: BLE001
+                        got = (type(exc), str(exc))
+                    if got is None:
+                        declined += 1
+                        continue
+                    checked += 1
+                    if isinstance(want, tuple) or isinstance(got, tuple):
+                        assert want == got, (dt, name, r)
+                    else:
+                        assert want.dtype == got.dtype and want.shape == got.shape, (dt, name, r, want.shape, got.shape)
+                        np.testing.assert_array_equal(got, want, err_msg=str((dt, name, r)))
+    assert checked > 10 * declined  # declining (constant data under "scott", ties) is the exception
+    for other in ("fd", "auto", "doane", "stone"):
+        assert core._device_estimator_edges(Resident(np.zeros(3)), other, None, np.dtype("f8"), True) is None
+

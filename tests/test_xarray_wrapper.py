@@ -65,6 +65,34 @@ def test_ones_every_dim_combination(cpu_compute, ndims):  # test_xarray.py:38-67
                 np.testing.assert_array_equal(h[d].values, da[d].values)
 
 
+@pytest.mark.parametrize("ndims", [1, 2, 3, 4])
+def test_ones_density_integrates_to_one_over_every_dim_combination(cpu_compute, ndims):  # test_xarray.py:70-94
+    """density=True: at every kept location the pdf integrates to 1 over the bins — for every combination of reduced dims
+    (the reference checks (h * bin_area).sum("ones_bin") == 1 with everything in the middle bin of width 0.2)"""
+    from itertools import combinations
+
+    dims = ["x", "y", "z", "t"]
+    shape = (3, 4, 5, 6)
+    da = _ones(dims, shape, name="ones")
+    bins = np.array([0.0, 0.9, 1.1, 2.0])
+    widths = np.diff(bins)
+    for red in combinations(dims, ndims):
+        h = xhx.histogram(da, bins=[bins], dim=red, density=True)
+        other = [d for d in dims if d not in red]
+        assert set(other) <= set(h.dims) and h.dims[-1] == "ones_bin" and h.name == "histogram_ones"
+        vals = h.values
+        assert vals.shape == tuple(s for d, s in zip(dims, shape) if d not in red) + (3,)
+        np.testing.assert_allclose((vals * widths).sum(axis=-1), 1.0)           # the integral over the bins, everywhere
+        np.testing.assert_allclose(vals[..., 1] * 0.2, 1.0)                     # the reference's own form: all mass in the middle bin
+        np.testing.assert_array_equal(vals[..., 0], 0.0)
+        for d in other:
+            np.testing.assert_array_equal(h[d].values, da[d].values)
+    # weighted density: the same integral (core.py:444-462 normalises by the in-range weight sum)
+    w = xr.DataArray(np.arange(1.0, 5.0), dims=["y"], name="w")
+    h = xhx.histogram(da, bins=[bins], dim=["y", "t"], weights=w, density=True)
+    np.testing.assert_allclose((h.values * widths).sum(axis=-1), 1.0)
+
+
 def test_weights_of_every_sub_dimensionality(cpu_compute):  # test_xarray.py:99-135
     da = _ones(["x", "y", "z"], (3, 4, 5))
     bins = np.array([0.0, 0.9, 1.1, 2.0])

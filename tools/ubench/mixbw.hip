@@ -54,6 +54,29 @@ __global__ void mix(const u4* __restrict__ a, const u4* __restrict__ b, const u4
   if (W == 0 && acc[0] == 0x12345u && acc[1] == 7u) o[0] = acc;
 }
 
+// read only, NS input streams (1: the unweighted headline, 2: C2 / C3, 3: C5), L loads of 16 bytes per stream, lane and round
+template <int NS, int L, bool NTL, bool TILE>
+__global__ void rd_streams(const u4* __restrict__ a, const u4* __restrict__ b, const u4* __restrict__ c, u4* __restrict__ o, long rounds) {
+  const long lanes = (long)gridDim.x * blockDim.x;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const u4* src[3] = {a, b, c};
+  u4 acc = {0u, 0u, 0u, 0u};
+  for (long r = 0; r < rounds; ++r) {
+    u4 v[NS][L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const long i = TILE ? ((r * gridDim.x + blockIdx.x) * L + k) * blockDim.x + threadIdx.x : (r * L + k) * lanes + t;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) v[q][k] = ld<NTL>(src[q] + i);
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) acc += v[q][k];
+  }
+  if (acc[0] == 0x12345u && acc[1] == 7u) o[0] = acc;
+}
+
 // split: even workgroups read (twice their share), odd workgroups write (twice their share)
 template <int L, int W, bool NTL, bool NTS>
 __global__ void mix_split(const u4* __restrict__ a, const u4* __restrict__ b, const u4* __restrict__ c, u4* __restrict__ o, long rounds) {
@@ -163,7 +186,7 @@ int main(int argc, char** argv) {
   };
   const int grids[] = {256, 512, 1024, 2048, 4096, 8192};
   const int blocks[] = {256, 512, 1024};
-  const bool only_route = argc > 1 && argv[1][0] == 'r';
+  const bool only_route = argc > 1 && (argv[1][0] == 'r' || argv[1][0] == 's');
   if (!only_route)
   for (const Variant& v : vars)
     for (int block : blocks)
@@ -190,6 +213,39 @@ int main(int argc, char** argv) {
                v.layout, v.split, v.L, v.W, v.ntl, v.nts, grid, block, rounds, rd / 1e9, wr / 1e9, t, (rd + wr) / t / 1e6);
         fflush(stdout);
       }
+  // ---- read-only ceilings by number of streams (argument "s") ---------------------------------------
+  if (argc > 1 && argv[1][0] == 's') {
+    struct RV { int ns, L, ntl, tile; kern_t k; };
+#define R(NS_, L_, NTL_, T_) {NS_, L_, NTL_, T_, (kern_t)rd_streams<NS_, L_, NTL_, T_>}
+    std::vector<RV> rv = {R(1, 1, true, false), R(1, 2, true, false), R(1, 4, true, false), R(1, 8, true, false), R(1, 4, true, true), R(1, 8, true, true), R(1, 4, false, false),
+                          R(2, 1, true, false), R(2, 2, true, false), R(2, 4, true, false), R(2, 8, true, false), R(2, 4, true, true), R(2, 2, true, true), R(2, 4, false, false),
+                          R(3, 1, true, false), R(3, 2, true, false), R(3, 4, true, false), R(3, 2, true, true)};
+    for (const RV& v : rv)
+      for (int block : {256, 512, 1024})
+        for (int grid : {256, 512, 768, 1024, 2048, 4096}) {
+          if ((long)grid * block > 2L * 1024 * 1024) continue;
+          const long lanes = (long)grid * block;
+          const long rounds = stream_bytes / (16L * v.L * lanes);
+          if (rounds < 1) continue;
+          std::vector<float> tt;
+          for (int it = 0; it < 6; ++it) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(v.k, dim3(grid), dim3(block), 0, 0, a, b, c, o, rounds);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 2) tt.push_back(ms);
+          }
+          const float t = median(tt);
+          const double rd = (double)v.ns * 16 * v.L * lanes * rounds;
+          printf("{\"layout\": \"%s\", \"streams\": %d, \"loads_per_stream\": %d, \"nt_load\": %d, \"grid\": %d, \"block\": %d, \"KB_in_flight_per_cu\": %.0f, "
+                 "\"read_GB\": %.2f, \"ms\": %.3f, \"read_gbs\": %.0f}\n",
+                 v.tile ? "tile" : "front", v.ns, v.L, v.ntl, grid, block, (double)v.ns * 16 * v.L * lanes / 256 / 1024, rd / 1e9, t, rd / t / 1e6);
+          fflush(stdout);
+        }
+    return 0;
+  }
   // ---- part_route's access shape ----------------------------------------------------------------
   {
     const long units_per_stream = stream_bytes / 16;  // 16-byte units per input stream

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -69,7 +69,7 @@ _lock = threading.Lock()
 EXPORTS = (
     "xhist_abi_version", "xhist_last_error", "xhist_device_count", "xhist_device_info",
     "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
-    "xhist_minmax", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
+    "xhist_minmax", "xhist_moments", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
     "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
     "xhist_pointer_device", "xhist_shutdown",
@@ -135,6 +135,8 @@ def load():
             C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
         ]
         lib.xhist_minmax.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int, C.c_void_p]
+        lib.xhist_moments.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int,
+                                      C.POINTER(C.c_double), C.c_int, C.c_void_p]
         lib.xhist_plan_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.xhist_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.xhist_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
@@ -329,6 +331,16 @@ def minmax(view, n_rows, n_cols, mem_kind, device=0, stream=0):
     out = (C.c_double * 2)()
     check(load().xhist_minmax(int(device), C.byref(view), int(n_rows), int(n_cols), out, int(mem_kind), C.c_void_p(stream or 0)))
     return out[0], out[1]
+
+
+def moments(view, n_rows, n_cols, lo=None, hi=None, want_m2=False, device=0, stream=0):
+    """(count, min, max, mean, M2) of the elements of a device-resident array inside [lo, hi] (all of them when lo is None):
+    xhist_moments — the data's contribution to numpy's bin-width estimators, without moving the data"""
+    out = (C.c_double * 5)()
+    use_range = lo is not None
+    check(load().xhist_moments(int(device), C.byref(view), int(n_rows), int(n_cols), 1 if use_range else 0, float(lo) if use_range else 0.0,
+                               float(hi) if use_range else 0.0, 1 if want_m2 else 0, out, MEM_DEVICE, C.c_void_p(stream or 0)))
+    return int(out[0]), out[1], out[2], out[3], out[4]
 
 
 def comm_unique_id():

@@ -750,6 +750,11 @@ def _device_bin_edges(a, b, r, has_weights):
     if isinstance(b, str):
         if has_weights:
             raise TypeError("Automated estimation of the number of bins is not supported for weighted data")
+        edges = _device_estimator_edges(a, b, r, proto_dtype, resident)
+        if edges is not None:
+            return edges
+        # "fd", "doane", "stone", "auto" need percentiles / third moments / a search over bin counts of the DATA: they take
+        # numpy's own implementation on a host copy (so does a float64-boundary tie of "scott", see _device_estimator_edges)
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
         if (a.size if resident else a.numel()) == 0:
@@ -765,6 +770,89 @@ def _device_bin_edges(a, b, r, has_weights):
         lo, hi = _native.minmax(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], _native.MEM_DEVICE, dev, stream)
         return np.histogram_bin_edges(np.array([lo, hi]).astype(proto_dtype), bins=b, range=None)
     return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=r)
+
+
+def _device_estimator_edges(a, name, r, proto_dtype, resident):
+    """np.histogram_bin_edges(a, bins=name, range=r) for the estimators that need only n, min, max and the standard deviation
+    of the data — "sqrt", "sturges", "rice", "scott" — from ONE fused reduction on the GPU (xhist_moments; "scott": two
+    passes) instead of a host copy of the array (core.py:383-388).  Restates numpy's `_get_bin_edges` for a string `bins`
+    (numpy/lib/_histograms_impl.py): outer edges from `range` or the data's min / max (NaN -> numpy's ValueError), the data
+    cut to the range, width from the selector on the cut data, n = ceil((last - first) / width), and numpy's own linspace
+    for the edges — bit-identical to numpy whenever n is.  n depends on the data only through exact quantities, except for
+    "scott", whose standard deviation is summed in another order here than in np.std: when (last - first) / width lies
+    within 1e-6 of an integer the decision is left to numpy on a host copy.  Returns None for other names / dtypes."""
+    if name not in ("sqrt", "sturges", "rice", "scott") or proto_dtype.kind not in "fiu" or proto_dtype == np.float16:
+        return None
+    size = a.size if resident else a.numel()
+    if r is not None:
+        if np.ndim(r[0]) or np.ndim(r[1]):
+            return None
+        np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)  # numpy's own validation (and error messages)
+        # (an empty range is widened by half a unit each way BEFORE the data is cut to it: _get_outer_edges)
+        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+    else:
+        lo_hi = None
+    if size == 0:
+        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=r)
+    flat = a.reshape(1, -1)
+    ptr, tag, rs, cs, _ir, _os, keep = _strided_view(flat, "device" if resident else "torch")
+    if resident:
+        dev, stream = a.device, 0
+    else:
+        dev = _torch_device_index(a.device)
+        stream = _torch().cuda.current_stream(a.device).cuda_stream
+    n, mn, mx, mean, m2 = _native.moments(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], lo_hi[0] if lo_hi else None,
+                                          lo_hi[1] if lo_hi else None, name == "scott", dev, stream)
+    del keep
+    as_scalar = proto_dtype.type
+    if lo_hi is None:
+        # (first, last) = (a.min(), a.max()) as numpy scalars of the data's dtype; non-finite -> numpy's ValueError
+        np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)
+        outer = (as_scalar(mn), as_scalar(mx))
+    else:
+        outer = (r[0], r[1])  # as the caller gave them: numpy computes with their types (python floats are "weak")
+    first, last = outer
+    if first == last:  # numpy/lib/_histograms_impl.py::_get_outer_edges
+        first, last = first - 0.5, last + 0.5
+    if n == 0:
+        n_bins = 1
+    else:
+        if proto_dtype.kind == "f":
+            ptp = as_scalar(mx) - as_scalar(mn)  # numpy's _ptp: in the data's own precision
+        else:
+            ptp = int(mx) - int(mn)
+        if name == "sqrt":
+            width = ptp / np.sqrt(n)
+        elif name == "sturges":
+            width = ptp / (np.log2(n) + 1.0)
+        elif name == "rice":
+            width = ptp / (2.0 * n ** (1.0 / 3))
+        else:
+            std = np.sqrt(m2 / n)
+            if not std > 1e-5 * max(abs(mx), abs(mn)):
+                # (nearly) constant data: np.std's own rounding — the mean of equal float32 values is not always that value —
+                # decides between one bin and "too many bins"; only numpy's summation order reproduces numpy there
+                return None
+            if proto_dtype == np.float32:
+                std = np.float32(std)  # np.std of float32 data is a float32
+            width = (24.0 * np.pi ** 0.5 / n) ** (1.0 / 3.0) * std
+        if width:
+            clamped = proto_dtype.kind in "iub" and width < 1
+            if clamped:
+                width = 1
+            if np.result_type(first, last).kind in "iub":
+                span = int(last) - int(first)  # numpy's _unsigned_subtract: exact for integers
+            else:
+                span = last - first
+            q = span / width
+            if not np.isfinite(q):
+                return None
+            if name == "scott" and not clamped and abs(q - np.rint(q)) <= 1e-6 * max(1.0, abs(q)):
+                return None  # a tie at the ceil: np.std's own summation order decides
+            n_bins = int(np.ceil(q))
+        else:
+            n_bins = 1
+    return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=n_bins, range=outer)
 
 
 def _density(counts, bins, n_inputs):

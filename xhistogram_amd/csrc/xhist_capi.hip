@@ -553,6 +553,59 @@ extern "C" int xhist_pointer_device(const void* ptr, int* device) {
 }
 
 // ------------------------------------------------------------------------------------------
+// moments (bin-width estimators)
+// ------------------------------------------------------------------------------------------
+extern "C" int xhist_moments(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, int use_range, double lo, double hi,
+                             int want_m2, double* result, int mem_kind, void* stream) {
+  if (!a || !result) return fail(XHIST_ERR_INVALID, "array / result is NULL");
+  if (!dtype_size(a->dtype)) return fail(XHIST_ERR_INVALID, "unknown dtype tag %d", a->dtype);
+  if (n_rows <= 0 || n_cols <= 0) return fail(XHIST_ERR_INVALID, "moments of an empty array");
+  if (mem_kind != XHIST_MEM_DEVICE) return fail(XHIST_ERR_UNSUPPORTED, "xhist_moments takes device-resident arrays (host arrays: numpy has them already)");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "HIP device %d not available; this library has no CPU path", device);
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = 1024;
+  double* d_part = nullptr;
+  auto done = [&](int code) {
+    if (d_part) (void)scratch_free(d_part, s);
+    return code;
+  };
+  if (scratch_malloc((void**)&d_part, sizeof(double) * 5 * grid, s) != hipSuccess) return done(fail(XHIST_ERR_NOMEM, "device allocation failed"));
+  std::vector<double> part(5 * grid);
+  auto pass = [&](int which, double mean) -> int {
+    hipLaunchKernelGGL(moments_kernel, dim3(grid), dim3(256), 0, s, a->data, a->dtype, a->row_stride, a->col_stride, a->inner_rows, a->outer_stride,
+                       n_rows, n_cols, use_range, lo, hi, which, mean, d_part);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), d_part, sizeof(double) * 5 * grid, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return fail(XHIST_ERR_HIP, "moments kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return XHIST_OK;
+  };
+  if (int rc = pass(0, 0.0)) return done(rc);
+  double cnt = 0.0, mn = HUGE_VAL, mx = -HUGE_VAL, sum = 0.0;
+  bool nan = false;
+  for (int b = 0; b < grid; ++b) {
+    cnt += part[5 * b];
+    mn = std::fmin(mn, part[5 * b + 1]);
+    mx = std::fmax(mx, part[5 * b + 2]);
+    sum += part[5 * b + 3];
+    nan |= part[5 * b + 4] != 0.0;
+  }
+  result[0] = cnt;
+  result[1] = nan ? NAN : mn;
+  result[2] = nan ? NAN : mx;
+  result[3] = cnt > 0.0 ? sum / cnt : NAN;
+  result[4] = NAN;
+  if (want_m2 && cnt > 0.0 && !nan) {
+    if (int rc = pass(1, result[3])) return done(rc);
+    double m2 = 0.0;
+    for (int b = 0; b < grid; ++b) m2 += part[5 * b];
+    result[4] = m2;
+  }
+  return done(XHIST_OK);
+}
+
+// ------------------------------------------------------------------------------------------
 // min / max
 // ------------------------------------------------------------------------------------------
 extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, int64_t n_cols, double* result, int mem_kind,

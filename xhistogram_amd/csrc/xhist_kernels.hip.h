@@ -57,6 +57,10 @@ struct DimTable {
   // the kernels' own arithmetic, doubled for margin): a sample whose position t = (x - e_0) * inv_step has a fractional
   // part with |frac - 0.5| < arith_h lies strictly inside bin floor(t) (bin_arith_fast).  0 = never decide by arithmetic.
   double arith_h;
+  // the same for float32 samples in the float32-threshold domain (Dom<2>), in float32 arithmetic: a sample whose position
+  // t = (x - e0_32) * inv_32 has |frac(t) - 0.5| < h_32 lies strictly inside bin floor(t) (count_le_tile, CMP == 2);
+  // h_32 = 0 (every other domain, unverified edges): never
+  float e0_32, inv_32, h_32, pad_32;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
   int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
@@ -453,7 +457,43 @@ template <int CMP, int SCAN, int D, int UNROLL, int VEC, typename XV, typename T
 __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const Params& p, TabPtr tab, int max_steps,
                                                uint32_t (&cnt)[D][UNROLL][VEC]) {
   using CT = typename Dom<CMP>::T;
-  if constexpr (SCAN > 0) {
+  if constexpr (CMP == 2 && SCAN == 1) {
+    // float32 samples, uniform-style edges (BASELINE C4): where plan creation has verified the arithmetic map against every
+    // threshold (h_32 > 0), a sample that is not within delta bins of an edge needs NO table: its count is floor(t) + 1 —
+    // seven float32 operations and no LDS read, against two dependent LDS reads (bucket -> start, start -> threshold) with
+    // random bank conflicts per sample; LDS was the busiest unit of the C4 kernel.  The argument is bin_arith_fast's
+    // (monotone map, measured |t(thr_j) - j| <= delta for every threshold); lanes that met a sample next to an edge (a few
+    // in 10^5) redo their batch with the exact compares under the wavefront's exec mask.  Counts of samples outside
+    // [thr_0, e_last] are garbage here: every caller drops those by Dom<2>::in_range.
+    bool near_any = false, verified = true;  // (`verified` is uniform: kernel arguments)
+#pragma unroll
+    for (int d = 0; d < D; ++d) verified &= p.dim[d].h_32 > 0.f;
+    if (verified) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float e0 = p.dim[d].e0_32, inv = p.dim[d].inv_32, h = p.dim[d].h_32;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float tt = ((float)xv[d][u][v] - e0) * inv;
+            const float fl = __builtin_floorf(tt);
+            near_any |= !(__builtin_fabsf((tt - fl) - 0.5f) < h);  // (NaN, +-inf: near)
+            cnt[d][u][v] = (uint32_t)((int)fl + 1);
+          }
+      }
+    }
+    if (!verified || __builtin_amdgcn_ballot_w64(near_any) != 0ull) {
+      if (!verified || near_any) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int d = 0; d < D; ++d) cnt[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
+      }
+    }
+  } else if constexpr (SCAN > 0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -987,6 +1027,57 @@ static __global__ void __launch_bounds__(256) minmax_kernel(const void* ptr, int
     partial[3 * blockIdx.x + 0] = mn;
     partial[3 * blockIdx.x + 1] = mx;
     partial[3 * blockIdx.x + 2] = (double)nan;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// count / min / max / sum — or the sum of squared deviations from a given mean — of the elements inside [lo, hi] (or of
+// all elements): what numpy's bin-width estimators need of the data (np.histogram_bin_edges with bins = "sqrt", "sturges",
+// "rice", "scott": core.py:383-388 hands the whole array to numpy; here the array stays where it is).
+//   pass 0: partial[5*b + {0..4}] = {count, min, max, sum, saw NaN}      pass 1: partial[5*b] = sum (x - mean)^2
+// Elements outside the range — and NaN when a range is given, as numpy's `keep` mask drops them — do not count.
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) moments_kernel(const void* ptr, int32_t dt, int64_t rs, int64_t cs, int64_t ir, int64_t os,
+                                                        int64_t n_rows, int64_t n_cols, int use_range, double lo, double hi, int pass, double mean,
+                                                        double* partial) {
+  double cnt = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val(), sum = 0.0;
+  int nan = 0;
+  const int64_t total = n_rows * n_cols;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = k / n_cols, c = k - r * n_cols;
+    const double x = load_as<double>(ptr, dt, row_offset(r, rs, ir, os) + c * cs);
+    const bool keep = use_range ? ((x >= lo) & (x <= hi)) : true;
+    if (!keep) continue;
+    if (pass == 0) {
+      nan |= (x != x);
+      cnt += 1.0;
+      mn = fmin(mn, x);
+      mx = fmax(mx, x);
+      sum += x;
+    } else {
+      const double dlt = x - mean;
+      sum += dlt * dlt;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64);
+    sum += __shfl_down(sum, off, 64);
+    mn = fmin(mn, __shfl_down(mn, off, 64));
+    mx = fmax(mx, __shfl_down(mx, off, 64));
+    nan |= __shfl_down(nan, off, 64);
+  }
+  __shared__ double s_v[4][4];
+  __shared__ int s_nan[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_v[wave][0] = cnt; s_v[wave][1] = mn; s_v[wave][2] = mx; s_v[wave][3] = sum; s_nan[wave] = nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      cnt += s_v[w][0]; mn = fmin(mn, s_v[w][1]); mx = fmax(mx, s_v[w][2]); sum += s_v[w][3]; nan |= s_nan[w];
+    }
+    double* o = partial + 5 * (int64_t)blockIdx.x;
+    if (pass == 0) { o[0] = cnt; o[1] = mn; o[2] = mx; o[3] = sum; o[4] = (double)nan; }
+    else o[0] = sum;
   }
 }
 
