@@ -1009,7 +1009,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   //  32 x 312500 f64, 1000 bins: 4896 workgroups 45 us, 32 x 8 of 512 threads 19 us.)
   const int64_t sample_bytes = lane_bytes / (fast ? (int64_t)vec * kUnroll : 4);
   const double total_samples = (double)n_rows * (double)n_cols;
-  int over = n_rows <= 16 ? 1 : 8;
+  // (C4 shard, 456 rows: 18 workgroups per row 0.2875 ms, 36: 0.2839 — and an ODD number per row is 2.5-7 % slower than its
+  // even neighbours: 17 / 19 / 21 / 23 / 27 / 31 per row 0.2946 / 0.2942 / 0.2980 / 0.2965 / 0.3067 / 0.3013 ms against
+  // 0.2854-0.2876 for 16 ... 28, profiles/r03_n_c4_segs_per_row.txt: the workgroups of a row walk its 16 KiB tiles interleaved,
+  // and an odd stride between a workgroup's tiles lands on the memory channels worse.  Hence 16 x, and an even count below.)
+  static const bool segs_legacy = [] { const char* e = getenv("XHIST_AMD_SEGS_LEGACY"); return e && *e == '1'; }();  // A/B switch
+  int over = n_rows <= 16 ? 1 : (segs_legacy ? 8 : 16);
   if (!grid_blocks && over > 1) {
     const double t_stream = total_samples * (double)sample_bytes / 6.0e12;
     while (over > 1) {
@@ -1092,7 +1097,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // One workgroup per row (many short rows): its LDS histogram IS the row's result, so it is stored
   // with plain writes — no zeroing pass over the output, no global atomics (10^5 rows x 1000 f32,
   // 50 bins: the 5 x 10^6 flush atomics alone took the whole 0.18 ms).
-  const int64_t segs0 = std::max<int64_t>(1, std::min<int64_t>((std::min(col_chunk, n_cols) + tile - 1) / tile, (target + n_rows - 1) / n_rows));
+  int64_t segs0 = std::max<int64_t>(1, std::min<int64_t>((std::min(col_chunk, n_cols) + tile - 1) / tile, (target + n_rows - 1) / n_rows));
+  if (!segs_legacy && !exact && !grid_blocks && segs0 > 1 && (segs0 & 1) && segs0 + 1 <= (std::min(col_chunk, n_cols) + tile - 1) / tile) ++segs0;
   const bool direct = !accumulate && !two && fast && hist == kHistLds && n_slices == 1 && col_chunk >= n_cols && segs0 == 1 &&
                       n_rows <= kMaxGrid;
   if (!accumulate && !direct && !two)
@@ -1105,6 +1111,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const int64_t tpr = (nc + tile - 1) / tile;
     for (int64_t r0 = 0; r0 < n_rows;) {
       int64_t segs = std::max<int64_t>(1, std::min<int64_t>(tpr, (target + (n_rows - r0) - 1) / (n_rows - r0)));
+      if (!segs_legacy && !exact && !grid_blocks && segs > 1 && (segs & 1) && segs + 1 <= tpr) ++segs;  // oversubscribed rows: an even number each
       const int64_t nr = std::min<int64_t>(n_rows - r0, kMaxGrid / segs);
       Params kp;
       memset(&kp, 0, sizeof kp);

@@ -57,10 +57,6 @@ struct DimTable {
   // the kernels' own arithmetic, doubled for margin): a sample whose position t = (x - e_0) * inv_step has a fractional
   // part with |frac - 0.5| < arith_h lies strictly inside bin floor(t) (bin_arith_fast).  0 = never decide by arithmetic.
   double arith_h;
-  // the same for float32 samples in the float32-threshold domain (Dom<2>), in float32 arithmetic: a sample whose position
-  // t = (x - e0_32) * inv_32 has |frac(t) - 0.5| < h_32 lies strictly inside bin floor(t) (count_le_tile, CMP == 2);
-  // h_32 = 0 (every other domain, unverified edges): never
-  float e0_32, inv_32, h_32, pad_32;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
   int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
@@ -270,7 +266,8 @@ __device__ __forceinline__ uint32_t count_le_arith(double x, const DimTable& t) 
 //   (C5's routing pass spent more than half of its instruction issue on the exact form).
 // Returns the bin, or -1 for samples below e_0 / above e_last / NaN; valid only when `near` comes back false.
 __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool& near) {
-  const double tt = (x - t.e0_f) * t.inv_step;
+  double tt = (x - t.e0_f) * t.inv_step;
+  asm volatile("" : "+v"(tt));  // the ROUNDED product, as plan creation measured it: left alone, the compiler fuses it into `tt - fl` below
   const double fl = __builtin_floor(tt);
   const double f = tt - fl;
   near = !(__builtin_fabs(f - 0.5) < t.arith_h);  // (NaN compares false: near)
@@ -457,43 +454,7 @@ template <int CMP, int SCAN, int D, int UNROLL, int VEC, typename XV, typename T
 __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const Params& p, TabPtr tab, int max_steps,
                                                uint32_t (&cnt)[D][UNROLL][VEC]) {
   using CT = typename Dom<CMP>::T;
-  if constexpr (CMP == 2 && SCAN == 1) {
-    // float32 samples, uniform-style edges (BASELINE C4): where plan creation has verified the arithmetic map against every
-    // threshold (h_32 > 0), a sample that is not within delta bins of an edge needs NO table: its count is floor(t) + 1 —
-    // seven float32 operations and no LDS read, against two dependent LDS reads (bucket -> start, start -> threshold) with
-    // random bank conflicts per sample; LDS was the busiest unit of the C4 kernel.  The argument is bin_arith_fast's
-    // (monotone map, measured |t(thr_j) - j| <= delta for every threshold); lanes that met a sample next to an edge (a few
-    // in 10^5) redo their batch with the exact compares under the wavefront's exec mask.  Counts of samples outside
-    // [thr_0, e_last] are garbage here: every caller drops those by Dom<2>::in_range.
-    bool near_any = false, verified = true;  // (`verified` is uniform: kernel arguments)
-#pragma unroll
-    for (int d = 0; d < D; ++d) verified &= p.dim[d].h_32 > 0.f;
-    if (verified) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const float e0 = p.dim[d].e0_32, inv = p.dim[d].inv_32, h = p.dim[d].h_32;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float tt = ((float)xv[d][u][v] - e0) * inv;
-            const float fl = __builtin_floorf(tt);
-            near_any |= !(__builtin_fabsf((tt - fl) - 0.5f) < h);  // (NaN, +-inf: near)
-            cnt[d][u][v] = (uint32_t)((int)fl + 1);
-          }
-      }
-    }
-    if (!verified || __builtin_amdgcn_ballot_w64(near_any) != 0ull) {
-      if (!verified || near_any) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int d = 0; d < D; ++d) cnt[d][u][v] = count_le_scan<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], tab);
-      }
-    }
-  } else if constexpr (SCAN > 0) {
+  if constexpr (SCAN > 0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
 #pragma unroll

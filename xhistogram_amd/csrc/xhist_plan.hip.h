@@ -274,36 +274,6 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     }
     rc = build_domain(p, 2, false, n_inputs, n_edges, words, edges, &p->ts[1][0]);
     if (rc == XHIST_OK) rc = build_domain(p, 2, true, n_inputs, n_edges, words, edges, &p->ts[1][1]);
-    // float32 arithmetic map of count_le_tile<2, 1>: t(x) = fl32(fl32(x - thr_0) * inv), inv = fl32(nb / (thr_nb - thr_0)).
-    // delta = max over EVERY threshold of |t(thr_j) - j|, measured here with the kernel's two float32 operations (no fma can
-    // form: the subtraction feeds the product); doubled, plus 2^-20 for the rounding of (frac - 0.5) and strictness.  Used
-    // only while delta < 2^-12 (uniform-style edges of up to a few hundred bins: beyond, too many samples would be "near").
-    if (rc == XHIST_OK)
-      for (int d = 0; d < n_inputs; ++d) {
-        const int E = (int)n_edges[d], nb = E - 1;
-        const float* thr = reinterpret_cast<const float*>(words[d].data());
-        float e0 = 0.f, inv = 0.f, h = 0.f;
-        if (nb >= 1 && std::isfinite(thr[0]) && std::isfinite(thr[nb]) && thr[nb] > thr[0]) {
-          e0 = thr[0];
-          inv = (float)((double)nb / ((double)thr[nb] - (double)thr[0]));
-          double delta = 0.0;
-          bool ok = std::isfinite(inv) && inv > 0.f;
-          for (int j = 0; j <= nb && ok; ++j) {
-            volatile float off = thr[j] - e0;
-            volatile float tj = off * inv;
-            ok = std::isfinite((float)tj);
-            delta = std::max(delta, std::fabs((double)tj - (double)j));
-          }
-          delta = 2.0 * delta + 0x1p-20;
-          static const bool off_env = [] { const char* e = getenv("XHIST_AMD_F32_ARITH"); return e && *e == '0'; }();  // A/B switch
-          if (ok && delta < 0x1p-12 && !off_env) h = std::nextafterf((float)(0.5 - delta), 0.f);
-        }
-        for (auto& dom : p->ts[1]) {
-          dom.dim[d].e0_32 = e0;
-          dom.dim[d].inv_32 = inv;
-          dom.dim[d].h_32 = h;
-        }
-      }
   }
   if (rc != XHIST_OK) {
     for (auto& dom : p->ts)

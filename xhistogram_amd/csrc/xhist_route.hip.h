@@ -300,15 +300,26 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   };
   // EARLY (off): issuing the loads of tile k + 1 at the TOP of iteration k, into registers of their own, keeps them in
-  // flight through digitize and rank as well — and measured SLOWER (C5 shard, 512-thread workgroups: 3.35 -> 3.46 ms;
-  // 1024: 3.43 -> 3.65, gpurun r03_e): gfx950 has ONE counter for loads and stores, the compiler guards the prefetch
-  // registers against the stores still reading them (s_waitcnt vmcnt(8) right behind the loads = "the oldest store of the
-  // last tile has completed"), and every tile then starts with a store round trip.  The late prefetch below issues its
-  // loads when those stores have had digitize + rank to complete.  Kept as a switch for the next compiler.
+  // flight through digitize and rank as well — and is SLOWER, twice over.  First form: 3.35 -> 3.46 ms (C5 shard, 512-thread
+  // workgroups), because with tile 0 still pending at the loop header the compiler had to place a wait at the top of the loop
+  // that on the way round meant "the stores of the last tile have completed" (gfx950 counts loads and stores with one
+  // in-order counter).  With the first tile drained ahead of the loop (the empty asm below) that wait is gone and the pass
+  // still takes 3.47 ms against 3.35-3.37 (1024 threads: 3.56 against 3.43-3.48; gpurun r03_e / r03_p): like the bare-traffic
+  // sweeps (profiles/r03_a_*, r03_d_*: the best geometries keep 24-48 KB per CU in flight, not more), this chip moves a
+  // read-write mix FASTER with fewer bytes in flight.  The late prefetch below has a tile's loads in flight during scan and
+  // sort only.  Kept as a switch.
   constexpr bool EARLY = false;
   s4 xv[D][U], xn[EARLY ? D : 1][U];
   w4 w[U], wn[U];
   load_tile(tile_base(0), tile_row(0), xv, w);
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kWeighted) asm volatile("" : "+v"(w[u]));
+#pragma unroll
+      for (int d = 0; d < D; ++d) asm volatile("" : "+v"(xv[d][u]));
+    }
+  }
   int cur_set = 0;
   for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
     if constexpr (EARLY) {
