@@ -164,7 +164,19 @@ int main(int argc, char** argv) {
   const long GB = 1L << 30;
   const long stream_bytes = 4 * GB;  // per input stream: 12 GB read in all for L:W = 3:1
   u4 *a, *b, *c, *o;
+  // MIXBW_SKEW=<bytes>: the four streams are carved out of ONE allocation, stream k starting k * (4 GiB + skew) into it —
+  // separate hipMallocs of 4 GiB put the streams exactly 4 GiB apart, i.e. the same offset of every stream on the same
+  // memory channel at the same time; the skew shows how much of a "ceiling" is that aliasing
+  const char* skew_env = getenv("MIXBW_SKEW");
+  const long skew = skew_env ? atol(skew_env) : -1;
+  if (skew >= 0) {
+    char* base;
+    CK(hipMalloc(&base, 4 * (stream_bytes + skew) + (2L << 20)));
+    a = (u4*)base; b = (u4*)(base + (stream_bytes + skew)); c = (u4*)(base + 2 * (stream_bytes + skew)); o = (u4*)(base + 3 * (stream_bytes + skew));
+  } else {
   CK(hipMalloc(&a, stream_bytes)); CK(hipMalloc(&b, stream_bytes)); CK(hipMalloc(&c, stream_bytes)); CK(hipMalloc(&o, stream_bytes + (1L << 20)));
+  }
+  printf("{\"skew\": %ld, \"a\": \"%p\", \"b\": \"%p\", \"c\": \"%p\", \"o\": \"%p\"}\n", skew, (void*)a, (void*)b, (void*)c, (void*)o);
   CK(hipMemset(a, 0x11, stream_bytes)); CK(hipMemset(b, 0x22, stream_bytes)); CK(hipMemset(c, 0x33, stream_bytes)); CK(hipMemset(o, 0, stream_bytes));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -187,11 +199,13 @@ int main(int argc, char** argv) {
   const int grids[] = {256, 512, 1024, 2048, 4096, 8192};
   const int blocks[] = {256, 512, 1024};
   const bool only_route = argc > 1 && (argv[1][0] == 'r' || argv[1][0] == 's');
+  const bool quick_mix = argc > 1 && argv[1][0] == 'm';  // the 24:8 mix only, nt loads
   if (!only_route)
   for (const Variant& v : vars)
     for (int block : blocks)
       for (int grid : grids) {
         if ((long)grid * block > 4L * 1024 * 1024) continue;
+        if (quick_mix && !(v.L == v.W && v.L > 0 && v.ntl && v.split == 0 && grid <= 2048)) continue;
         const long lanes = (long)grid * block;
         const int unit = std::max(v.L, v.W);
         const long rounds = stream_bytes / (16L * unit * lanes);
@@ -214,6 +228,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
       }
   // ---- read-only ceilings by number of streams (argument "s") ---------------------------------------
+  if (quick_mix) return 0;
   if (argc > 1 && argv[1][0] == 's') {
     struct RV { int ns, L, ntl, tile; kern_t k; };
 #define R(NS_, L_, NTL_, T_) {NS_, L_, NTL_, T_, (kern_t)rd_streams<NS_, L_, NTL_, T_>}

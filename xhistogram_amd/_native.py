@@ -72,7 +72,7 @@ EXPORTS = (
     "xhist_minmax", "xhist_moments", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
     "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
-    "xhist_pointer_device", "xhist_shutdown",
+    "xhist_pointer_device", "xhist_scratch_stats", "xhist_shutdown",
 )
 
 
@@ -137,6 +137,7 @@ def load():
         lib.xhist_minmax.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int, C.c_void_p]
         lib.xhist_moments.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_int, C.c_void_p]
+        lib.xhist_scratch_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
         lib.xhist_plan_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.xhist_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.xhist_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
@@ -341,6 +342,13 @@ def moments(view, n_rows, n_cols, lo=None, hi=None, want_m2=False, device=0, str
     check(load().xhist_moments(int(device), C.byref(view), int(n_rows), int(n_cols), 1 if use_range else 0, float(lo) if use_range else 0.0,
                                float(hi) if use_range else 0.0, 1 if want_m2 else 0, out, MEM_DEVICE, C.c_void_p(stream or 0)))
     return int(out[0]), out[1], out[2], out[3], out[4]
+
+
+def scratch_stats(device=0):
+    """the library's scratch cache on a GPU: bytes cached, bytes in use, bytes it may keep, recent peak of bytes in use"""
+    out = (C.c_uint64 * 4)()
+    check(load().xhist_scratch_stats(int(device), out, 4))
+    return {"cached": int(out[0]), "live": int(out[1]), "limit": int(out[2]), "recent_peak": int(out[3])}
 
 
 def comm_unique_id():

@@ -3,11 +3,11 @@
 # compiled in parallel: seven that instantiate the float64 / float32 / mixed-dtype vector and routing kernels, and the rest.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/../libxhist_amd.so"
+out="${XHIST_BUILD_OUT:-$here/../libxhist_amd.so}"  # (development: XHIST_BUILD_OUT / XHIST_BUILD_FLAGS build an A/B variant next to the library)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 obj="$(mktemp -d)"
 trap 'rm -rf "$obj"' EXIT
-flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${XHIST_BUILD_FLAGS:-})
 pids=()
 tus=(xhist_capi xhist_pick_f64 xhist_pick_f32 xhist_pick_mixed xhist_route_f64_b1024 xhist_route_f64_b512 xhist_route_f32_b1024 xhist_route_f32_b512)
 for tu in "${tus[@]}"; do

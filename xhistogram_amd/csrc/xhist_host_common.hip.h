@@ -323,6 +323,20 @@ static hipError_t scratch_free(void* p, hipStream_t stream, bool synced = false)
   return hipSuccess;
 }
 
+extern "C" int xhist_scratch_stats(int device, uint64_t* stats, int n) {
+  if (!stats || n < 4) return fail(XHIST_ERR_INVALID, "stats is NULL / shorter than 4");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "device %d not available", device);
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  const int phys = physical_device(device);
+  std::lock_guard<std::mutex> lk(g_sc_mu);
+  stats[0] = phys < 64 ? g_sc_cached[phys] : 0;
+  stats[1] = phys < 64 ? g_sc_live_b[phys] : 0;
+  stats[2] = scratch_limit(phys);
+  stats[3] = phys < 64 ? std::max(g_sc_win_peak[phys], g_sc_prev_peak[phys]) : 0;
+  return XHIST_OK;
+}
+
 static void trim_pools() {  // xhist_shutdown: every cached block of every device goes back to the driver
   std::lock_guard<std::mutex> lk(g_sc_mu);
   int prev = -1;

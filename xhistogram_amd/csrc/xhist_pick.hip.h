@@ -52,7 +52,12 @@ static kernel_fn fast_pick(int hist) {
   }
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
-    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+#ifdef XHIST_PACKED_UNROLL  // development A/B only (XHIST_BUILD_FLAGS=-DXHIST_PACKED_UNROLL=2): samples per lane and tile of the packed-counter kernels
+    constexpr int UP = XHIST_PACKED_UNROLL;
+#else
+    constexpr int UP = U;
+#endif
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, UP, kHistPacked, SCAN>;
     else return nullptr;
   }
   return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
