@@ -224,8 +224,8 @@ int xhist_plan_describe(xhist_plan* plan, char* buf, size_t cap);
 int xhist_plan_profile_read(xhist_plan* plan, float* ms, int cap, int* n_out);
 
 /* the library's scratch cache on `device` (staging buffers, record streams of the partitioned mode, transposes): stats[0] = bytes
- * cached (free, kept for reuse), [1] = bytes callers hold right now, [2] = bytes the cache may keep — what the largest recent
- * call held at once, at least 64 MiB, at most half of the device; $XHIST_AMD_POOL_KEEP_GB fixes it — [3] = that recent peak. */
+ * cached (free, kept for reuse), [1] = bytes callers hold right now, [2] = bytes the cache may keep — twice what the largest
+ * recent call held at once, at least 64 MiB, at most half of the device; $XHIST_AMD_POOL_KEEP_GB fixes it — [3] = that recent peak. */
 int xhist_scratch_stats(int device, uint64_t* stats, int n);
 
 /* free cached plans and scratch on every device */

@@ -246,6 +246,8 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
   while (lg < 14 && (((n_total / G) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
+  static const int lg_env = [] { const char* e = getenv("XHIST_AMD_ROUTE_CHUNK_LOG2"); return e && *e ? atoi(e) : 0; }();  // A/B runs only
+  if (lg_env >= 10 && lg_env <= 14 && lg_env > lg) lg = lg_env;
   const int64_t GP = (int64_t)G * n_parts;
   // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than

@@ -148,7 +148,9 @@ struct ScratchBlock {
   uint64_t owner = 0;            // (hipStreamPerThread names a different stream in every thread)
   hipEvent_t ev = nullptr;
   bool pending = false;          // `ev` marks the point on `stream` after which the block is free
+  uint64_t freed_at = 0;         // tick of the free that put it into the cache (eviction: oldest first)
 };
+static uint64_t g_sc_tick = 0;
 static std::mutex g_sc_mu;
 static std::vector<ScratchBlock> g_sc_free;
 static std::map<void*, ScratchBlock> g_sc_live;
@@ -188,8 +190,8 @@ static size_t scratch_round(size_t b) {  // size classes 1/8 apart: a cached blo
   return (b + step - 1) / step * step;
 }
 
-// bytes the cache of `device` may keep: what the largest call of the last 256-512 frees held at once (at least 64 MiB, at
-// most half of the device); $XHIST_AMD_POOL_KEEP_GB fixes it instead.  Call with g_sc_mu held and `device` current.
+// bytes the cache of `device` may keep: twice what the largest call of the last 256-512 frees held at once (at least 64 MiB,
+// at most half of the device); $XHIST_AMD_POOL_KEEP_GB fixes it instead.  Call with g_sc_mu held and `device` current.
 static uint64_t scratch_limit(int device) {
   if (device < 0 || device >= 64) return (uint64_t)2 << 30;
   static const double env_gb = [] { const char* e = getenv("XHIST_AMD_POOL_KEEP_GB"); return e && *e ? atof(e) : -1.0; }();
@@ -200,8 +202,11 @@ static uint64_t scratch_limit(int device) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) cap = std::max<uint64_t>(cap, (uint64_t)total_b / 2);
     g_sc_limit[device] = cap;
   }
+  // twice the recent peak: the blocks ONE call cycles through are more than it ever holds at once (three routing passes over
+  // 11 + 11 + 10 rows ask for three sets of sizes, 16.8 GB of blocks for 12.3 GB held) — a cache of exactly the peak evicted,
+  // oldest first, precisely what the next call asks for first: 8 -> 700 ms per call
   const uint64_t recent = std::max(g_sc_win_peak[device], g_sc_prev_peak[device]);
-  return std::min(g_sc_limit[device], std::max(kScratchFloor, recent));
+  return std::min(g_sc_limit[device], std::max(kScratchFloor, 2 * recent));
 }
 
 // give cached blocks of `device` back to the driver until at most `keep` bytes stay (blocks still in flight are skipped
@@ -214,7 +219,9 @@ static void scratch_evict(int device, uint64_t keep, bool sync) {
       ScratchBlock& b = g_sc_free[(size_t)i];
       if (b.device != device) continue;
       if (b.pending && !sync && hipEventQuery(b.ev) != hipSuccess) continue;
-      if (best < 0 || b.size > g_sc_free[(size_t)best].size) best = i;
+      // the block that has sat in the cache longest goes first: what the current calls reuse is the newest (evicting by size
+      // threw out the record streams a call had just freed, in favour of stale blocks of an earlier shape: 7 -> 418 ms per call)
+      if (best < 0 || b.freed_at < g_sc_free[(size_t)best].freed_at) best = i;
     }
     if (best < 0) break;
     ScratchBlock b = g_sc_free[(size_t)best];
@@ -307,6 +314,7 @@ static hipError_t scratch_free(void* p, hipStream_t stream, bool synced = false)
   b.stream = stream;
   b.owner = scratch_owner(stream);
   b.pending = false;
+  b.freed_at = ++g_sc_tick;
   if (!synced) {
     if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) b.ev = nullptr;
     if (b.ev && hipEventRecord(b.ev, stream) == hipSuccess) {

@@ -60,6 +60,10 @@ constexpr uint64_t kRouteDirect = ~(uint64_t)0;
 constexpr int kRouteBlock = 1024;  // the largest workgroup (sizes the host-side worst cases)
 __host__ __device__ constexpr int route_tile(int block) { return 4 * block; }
 // chunks one workgroup can file in its LDS list (beyond: filed one by one, slowly)
+// (= the workgroup size.  1024 for every size was tried — shorter lists force bigger chunks, and every workgroup ends with one
+// to two batches of unused chunk ids, so 12 rows x 10^8 samples with 8192-record chunks size their pool at 19 GB for 7 GB of
+// records — and lost: 4 KB more LDS per workgroup cost the second workgroup per CU at 128 partitions, 3.95 -> 4.8 ms for
+// 8 x 6*10^7 float64 pairs into 512 x 512 bins, and 32 x 3*10^7 float32 pairs went 5.9 -> 7.5 ms with 1024-record chunks.)
 __host__ __device__ constexpr int route_list_cap(int block) { return block; }
 __host__ __device__ constexpr int route_ctl(int block) { return 18496 + 2 * 4 * route_list_cap(block); }  // control arrays of part_route (see the kernel)
 constexpr int kAccBatch = 1024;                // chunks a workgroup of part_accumulate_chunks stages at a time
@@ -286,16 +290,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   // read 4 elements back from the end and moved into place when it is used.  Requires n >= 4.
   // Addresses: a uniform 64-bit tile pointer (scalar registers) plus ONE 32-bit byte offset per lane and load —
   // twelve 64-bit lane addresses kept across the loop were a third of the register file.
-  auto load_tile = [&](int64_t base, int64_t row, s4 (&x)[D][U], w4 (&w)[U]) {
+  auto load_tile = [&](int64_t base, int64_t row, s4 (&x)[D][U], w4 (&w)[U], bool do_x = true, bool do_w = true) {
     const int64_t origin = min(base, n - 4);  // (a last tile of fewer than 4 samples reads the 4 before the end)
     const uint32_t last = (uint32_t)min(n - 4 - origin, (int64_t)kRouteTile);  // first element of the last whole quad, tile-relative
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t e = min((uint32_t)(u * BLOCK + tid) * 4u, last);
+      if (do_x)
 #pragma unroll
-      for (int d = 0; d < D; ++d)
-        x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + row * p.s_rs[d] + origin) + e * (uint32_t)sizeof(ST)));
-      if (kWeighted)
+        for (int d = 0; d < D; ++d)
+          x[d][u] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + row * p.s_rs[d] + origin) + e * (uint32_t)sizeof(ST)));
+      if (kWeighted && do_w)
         w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(reinterpret_cast<const char*>(wp + row * p.w_rs + origin) + e * (uint32_t)sizeof(wscalar)));
     }
   };
@@ -309,13 +314,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   // read-write mix FASTER with fewer bytes in flight.  The late prefetch below has a tile's loads in flight during scan and
   // sort only.  Kept as a switch.
   constexpr bool EARLY = false;
+  // WSPLIT: the weights of a tile are not needed before its records are sorted, so they are loaded at the top of the tile's
+  // OWN iteration (and waited for ahead of the sort) instead of with the samples of the tile a whole iteration earlier:
+  // the loads of a workgroup come in two smaller bursts, and the registers of the second weight buffer are free
+  constexpr bool WSPLIT = kWeighted && !EARLY;
   s4 xv[D][U], xn[EARLY ? D : 1][U];
   w4 w[U], wn[U];
-  load_tile(tile_base(0), tile_row(0), xv, w);
-  if constexpr (EARLY) {
+  load_tile(tile_base(0), tile_row(0), xv, w, true, !WSPLIT);
+  if constexpr (EARLY || WSPLIT) {  // (tile 0 has arrived before the loop is entered: see EARLY)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (kWeighted) asm volatile("" : "+v"(w[u]));
+      if (kWeighted && !WSPLIT) asm volatile("" : "+v"(w[u]));
 #pragma unroll
       for (int d = 0; d < D; ++d) asm volatile("" : "+v"(xv[d][u]));
     }
@@ -326,6 +335,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
       load_tile(tile_base(kn), tile_row(kn), xn, wn);
     }
+    if constexpr (WSPLIT) load_tile(tile_base(k), tile_row(k), xv, w, false, true);
     const int64_t base = tile_base(k);
     const uint32_t row_off = (uint32_t)tile_row(k) * ((uint32_t)p.parts_per_row << shift);  // this row's first partition, as a flat index
     const bool ragged = base + kRouteTile > n;
@@ -407,7 +417,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     // workgroup instead of a branch around loads); waited for just before this tile's stores go out
     if constexpr (!EARLY) {
       const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
-      load_tile(tile_base(kn), tile_row(kn), xv, wn);
+      load_tile(tile_base(kn), tile_row(kn), xv, wn, true, !WSPLIT);
     }
     __syncthreads();
     // ---- block layout (as in part_scatter) + record space of every partition's block: LDS only -------
@@ -502,8 +512,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      w[u] = wn[u];
-      if (kWeighted) asm volatile("" : "+v"(w[u]));  // the wait for the prefetch sits here, ahead of the stores
+      if constexpr (!WSPLIT) {
+        w[u] = wn[u];
+        if (kWeighted) asm volatile("" : "+v"(w[u]));  // the wait for the prefetch sits here, ahead of the stores
+      }
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if constexpr (EARLY) xv[d][u] = xn[d][u];
