@@ -64,6 +64,9 @@ def parse():
                          "replaced by a no-op (nothing is measured; `metric` says so) — exercises rank spawn, both scaling legs, the "
                          "gathers and the JSON line, which no 1-GPU box can")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profiler-pass", action="store_true",
+                    help="only the main leg's launches: no 8 B/sample leg riding along (c2), no cold burst (c4) — for rocprofv3 passes "
+                         "that attribute counters and launch counts to ONE kernel")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     args = ap.parse_args()
     # a C4 shard step is one 0.3 ms kernel: the first tens of launches after an idle GPU run 5-8 % slower (0.309 ms over steps
@@ -350,12 +353,12 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     legs = {}
     main_leg = args.scaling
     # sub-millisecond kernels (the C4 shard): the first launches after an idle GPU are reported next to the steady rate
-    cold = 20 if (args.config == "c4" and not args.full and not args.selftest) else 0
+    cold = 20 if (args.config == "c4" and not args.full and not args.selftest and not args.profiler_pass) else 0
     legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold)
     # the headline's 8 B/sample variant — north_star's target sentence is the 1-D 10^9-sample f64 histogram WITHOUT weights
     # (BASELINE.md section 3 "headline unweighted variant") — rides along on the same samples: `"unweighted": {...}`
     unweighted_leg = None
-    if args.config == "c2" and weighted:
+    if args.config == "c2" and weighted and not args.profiler_pass:
         outs_u = [torch.zeros(out_shape, dtype=torch.int64, device=dev) for _ in range(2)]
         unweighted_leg = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, weighted=False, outs=outs_u)
     if world > 1:  # the other leg rides along (N = 1: the two legs are the same run)
@@ -388,10 +391,10 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         # `traffic_source` says where and on which code state; otherwise null
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         try:
-            entry = json.load(open(tpath)).get("configs", {}).get(args.config + ("_full" if args.full else ""))
+            entry = json.load(open(tpath)).get("configs", {}).get(args.config + ("u" if args.unweighted else "") + ("_full" if args.full else ""))
         except Exception:
             entry = None
-        if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"] and not args.unweighted:
+        if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"]:
             roof["traffic"] = entry["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/traffic.json: %s (code state %s)" % (entry.get("source", "?"), entry.get("code_state", "?"))
         else:
