@@ -66,6 +66,11 @@ def main():
         want, wedges = onp.histogram(x, bins=20)
         np.testing.assert_array_equal(edges[0], wedges[0])
         close(h.cpu().numpy(), want, False)
+        for name in ("sqrt", "sturges", "rice", "scott"):  # bin estimators from the two GPUs' moments (xhist_moments on each)
+            h, edges = multigpu.histogram(xs, bins=name, exchange="p2p")
+            want, wedges = np.histogram(x, bins=name)
+            np.testing.assert_array_equal(edges[0], wedges)
+            close(h.cpu().numpy(), want, False)
     finally:
         core._counts_one_device = orig
     assert {d for _, d in threads_seen} == {0, 1} and len({t for t, _ in threads_seen}) == 2, threads_seen

@@ -39,6 +39,10 @@ CASES = {
     "bins_int_global_minmax": ((1001,), 1, dict(bins=17), 0, True),
     "bins_int_range_density": ((64, 33), 1, dict(bins=9, range=(-2, 2), density=True, axis=1, weights=True), 1, False),
     "density_full": ((500,), 1, dict(bins=np.linspace(-4, 4, 13), density=True), 0, True),
+    # bin estimators from per-rank moments (n, min, max, mean, M2), combined after ONE all-gather of five numbers per rank
+    "bins_scott_from_rank_moments": ((2001,), 1, dict(bins="scott"), 0, True),
+    "bins_sturges_range_kept_rows": ((40, 101), 1, dict(bins="sturges", range=(-2, 2.5), axis=1), 1, False),
+    "bins_sqrt_rice_two_args": ((33, 57), 2, dict(bins=["sqrt", "rice"]), 0, True),
 }
 
 

@@ -267,6 +267,7 @@ def test_bin_width_estimators_restated_from_moments_match_numpy(monkeypatch):
         def reshape(self, *shape):
             return self
 
+    monkeypatch.setattr(core, "_is_devarr", lambda a: isinstance(a, Resident))
     rng = np.random.default_rng(0)
     declined = checked = 0
     for dt in (np.float64, np.float32, np.int32, np.uint8, np.int64):
@@ -303,4 +304,25 @@ def test_bin_width_estimators_restated_from_moments_match_numpy(monkeypatch):
     assert checked > 10 * declined  # declining (constant data under "scott", ties) is the exception
     for other in ("fd", "auto", "doane", "stone"):
         assert core._device_estimator_edges(Resident(np.zeros(3)), other, None, np.dtype("f8"), True) is None
+
+
+def test_moments_of_shards_combine_to_the_moments_of_the_whole():
+    """sharded inputs (multigpu): every GPU reduces its shard to (n, min, max, mean, M2); the host combines them"""
+    from xhistogram_amd import core
+
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(10_000) * 7 + 3
+    cuts = [0, 1, 1, 4000, 4001, 10_000]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p = x[lo:hi]
+        parts.append((p.size, p.min() if p.size else np.inf, p.max() if p.size else -np.inf, p.mean() if p.size else np.nan,
+                      ((p - p.mean()) ** 2).sum() if p.size else np.nan))
+    n, mn, mx, mean, m2 = core.combine_moments(parts)
+    assert n == x.size and mn == x.min() and mx == x.max()
+    np.testing.assert_allclose(mean, x.mean(), rtol=1e-13)
+    np.testing.assert_allclose(m2, ((x - x.mean()) ** 2).sum(), rtol=1e-12)
+    assert core.combine_moments([(0, np.inf, -np.inf, np.nan, np.nan)])[0] == 0
+    nan_part = (3, np.nan, np.nan, np.nan, np.nan)
+    assert np.isnan(core.combine_moments([parts[0], nan_part, parts[3]])[1])
 

@@ -214,6 +214,33 @@ def test_sharded_inputs_must_match():
         multigpu.histogram(np.zeros(4), bins=3)
 
 
+@pytest.mark.parametrize("name", ["sqrt", "sturges", "rice", "scott"])
+def test_sharded_inputs_take_the_cheap_bin_estimators(name):
+    """f-1 on sharded data: bins="sqrt" | "sturges" | "rice" | "scott" from per-GPU moments combined on the host — the edges of
+    np.histogram_bin_edges on the whole array, with and without a range; "fd" & co. still need all the data in one place"""
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((7, 3001)) * 2.5 + 1).astype(np.float64)
+
+    def moments(part, lo_hi, want_m2):
+        v = np.asarray(part).ravel().astype(np.float64)
+        if lo_hi is not None:
+            v = v[(v >= lo_hi[0]) & (v <= lo_hi[1])]
+        if v.size == 0:
+            return 0, np.inf, -np.inf, np.nan, np.nan
+        return v.size, v.min(), v.max(), v.mean(), ((v - v.mean()) ** 2).sum()
+
+    for shard_axis in (0, 1):
+        sx = _cpu_shards(x, 3, shard_axis)
+        for r in (None, (-2.0, 4.5)):
+            got, edges = multigpu.histogram(sx, bins=name, range=r, _local=_local_oracle, _moments=moments,
+                                            _reduce=lambda parts: sum(parts[1:], parts[0].clone()))
+            want_e = np.histogram_bin_edges(x, bins=name, range=r)
+            np.testing.assert_array_equal(edges[0], want_e)
+            np.testing.assert_array_equal(np.asarray(got), np.histogram(x, bins=want_e)[0])
+    with pytest.raises(TypeError, match="estimators"):
+        multigpu.histogram(_cpu_shards(x, 2, 0), bins="fd", _local=_local_oracle, _moments=moments)
+
+
 # ---- bench.py --gpus N spawns its own ranks -------------------------------------------------------
 def test_bench_spawns_its_ranks_and_fails_per_rank_without_gpus():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:

@@ -772,28 +772,28 @@ def _device_bin_edges(a, b, r, has_weights):
     return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=b, range=r)
 
 
-def _device_estimator_edges(a, name, r, proto_dtype, resident):
-    """np.histogram_bin_edges(a, bins=name, range=r) for the estimators that need only n, min, max and the standard deviation
-    of the data — "sqrt", "sturges", "rice", "scott" — from ONE fused reduction on the GPU (xhist_moments; "scott": two
-    passes) instead of a host copy of the array (core.py:383-388).  Restates numpy's `_get_bin_edges` for a string `bins`
-    (numpy/lib/_histograms_impl.py): outer edges from `range` or the data's min / max (NaN -> numpy's ValueError), the data
-    cut to the range, width from the selector on the cut data, n = ceil((last - first) / width), and numpy's own linspace
-    for the edges — bit-identical to numpy whenever n is.  n depends on the data only through exact quantities, except for
-    "scott", whose standard deviation is summed in another order here than in np.std: when (last - first) / width lies
-    within 1e-6 of an integer the decision is left to numpy on a host copy.  Returns None for other names / dtypes."""
-    if name not in ("sqrt", "sturges", "rice", "scott") or proto_dtype.kind not in "fiu" or proto_dtype == np.float16:
-        return None
-    size = a.size if resident else a.numel()
-    if r is not None:
-        if np.ndim(r[0]) or np.ndim(r[1]):
-            return None
-        np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)  # numpy's own validation (and error messages)
-        # (an empty range is widened by half a unit each way BEFORE the data is cut to it: _get_outer_edges)
-        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
-    else:
-        lo_hi = None
-    if size == 0:
-        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=r)
+ESTIMATORS_FROM_MOMENTS = ("sqrt", "sturges", "rice", "scott")
+
+
+def _estimator_cut(name, r, proto_dtype):
+    """(supported, lo_hi): whether `name` is one of the estimators that need only moments of data of this dtype, and the
+    range the data is cut to before the selector sees it (None: all of it).  numpy validates the range (its own errors)."""
+    if name not in ESTIMATORS_FROM_MOMENTS or proto_dtype.kind not in "fiu" or proto_dtype == np.float16:
+        return False, None
+    if r is None:
+        return True, None
+    if np.ndim(r[0]) or np.ndim(r[1]):
+        return False, None
+    np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
+    # (an empty range is widened by half a unit each way BEFORE the data is cut to it: _get_outer_edges)
+    return True, ((float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1])))
+
+
+def _device_moments(a, lo_hi, want_m2):
+    """(n, min, max, mean, M2) of the elements of a GPU-resident array inside lo_hi (all of them for None): xhist_moments"""
+    resident = _is_devarr(a)
+    if (a.size if resident else a.numel()) == 0:
+        return 0, np.inf, -np.inf, np.nan, np.nan
     flat = a.reshape(1, -1)
     ptr, tag, rs, cs, _ir, _os, keep = _strided_view(flat, "device" if resident else "torch")
     if resident:
@@ -801,11 +801,42 @@ def _device_estimator_edges(a, name, r, proto_dtype, resident):
     else:
         dev = _torch_device_index(a.device)
         stream = _torch().cuda.current_stream(a.device).cuda_stream
-    n, mn, mx, mean, m2 = _native.moments(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], lo_hi[0] if lo_hi else None,
-                                          lo_hi[1] if lo_hi else None, name == "scott", dev, stream)
+    out = _native.moments(_native.make_view(ptr, tag, rs, cs), 1, flat.shape[1], lo_hi[0] if lo_hi else None,
+                          lo_hi[1] if lo_hi else None, want_m2, dev, stream)
     del keep
+    return out
+
+
+def combine_moments(parts):
+    """moments of the union of disjoint shards from the shards' own (n, min, max, mean, M2) — Chan et al.'s pairwise update"""
+    n, mn, mx, mean, m2 = 0, np.inf, -np.inf, 0.0, 0.0
+    for pn, pmn, pmx, pmean, pm2 in parts:
+        if pn == 0:
+            continue
+        if pmn != pmn or pmx != pmx:  # a NaN among the kept elements: numpy rejects the range
+            mn = mx = np.nan
+        tot = n + pn
+        d = pmean - mean
+        m2 = m2 + (0.0 if pm2 != pm2 else pm2) + d * d * n * pn / tot
+        mean = mean + d * pn / tot
+        if mn == mn:
+            mn, mx = min(mn, pmn), max(mx, pmx)
+        n = tot
+    return n, mn, mx, (mean if n else np.nan), (m2 if n else np.nan)
+
+
+def _edges_from_moments(name, r, proto_dtype, size, moments):
+    """np.histogram_bin_edges(a, bins=name, range=r) from the moments of the cut data — numpy's `_get_bin_edges` for a string
+    `bins` restated (numpy/lib/_histograms_impl.py): outer edges from `range` or the data's min / max (NaN -> numpy's
+    ValueError), width from the selector, n = ceil((last - first) / width), and numpy's own linspace for the edges —
+    bit-identical to numpy whenever n is.  n depends on the data only through exact quantities, except for "scott", whose
+    standard deviation is summed in another order than np.std does: when (last - first) / width lies within 1e-6 of an
+    integer, or the data are (nearly) constant, the answer is None and numpy decides on a host copy."""
+    if size == 0:
+        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=r)
+    n, mn, mx, mean, m2 = moments
     as_scalar = proto_dtype.type
-    if lo_hi is None:
+    if r is None:
         # (first, last) = (a.min(), a.max()) as numpy scalars of the data's dtype; non-finite -> numpy's ValueError
         np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)
         outer = (as_scalar(mn), as_scalar(mx))
@@ -853,6 +884,19 @@ def _device_estimator_edges(a, name, r, proto_dtype, resident):
         else:
             n_bins = 1
     return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=n_bins, range=outer)
+
+
+def _device_estimator_edges(a, name, r, proto_dtype, resident):
+    """np.histogram_bin_edges(a, bins=name, range=r) for the estimators that need only n, min, max and the standard deviation
+    of the data — "sqrt", "sturges", "rice", "scott" — from ONE fused reduction on the GPU (xhist_moments; "scott": two
+    passes) instead of a host copy of the array (core.py:383-388).  None: another estimator / dtype, or a case only numpy's
+    own summation order decides (_edges_from_moments) — the caller then lets numpy work on a host copy."""
+    ok, lo_hi = _estimator_cut(name, r, proto_dtype)
+    if not ok:
+        return None
+    size = a.size if resident else a.numel()
+    moments = _device_moments(a, lo_hi, name == "scott") if size else None
+    return _edges_from_moments(name, r, proto_dtype, size, moments)
 
 
 def _density(counts, bins, n_inputs):

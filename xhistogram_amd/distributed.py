@@ -17,7 +17,8 @@ histograms.  Here the blocks are the ranks' shards:
 
 Bin edges must be the same on every rank: arrays are taken as given; an integer ``bins`` with no
 ``range`` uses the GLOBAL min/max (all-reduce of the local extrema), which is what the reference
-computes on the unchunked array.  String estimators need the whole data set and raise, like the
+computes on the unchunked array.  The string estimators that need only moments ("sqrt", "sturges", "rice", "scott") are combined across ranks; the others need
+the whole data set and raise, like the
 reference does for dask inputs (core.py:377-381).
 """
 
@@ -156,15 +157,44 @@ def _local_extrema(a):
     return (np.inf if nan else lo), (-np.inf if nan else hi), nan
 
 
+def _local_moments(a, lo_hi, want_m2):
+    """(n, min, max, mean, M2) of a local shard inside lo_hi, without moving it off its device"""
+    if core._is_torch(a) and a.is_cuda:
+        return core._device_moments(a, lo_hi, want_m2)
+    v = (a.detach().cpu().numpy() if core._is_torch(a) else np.asarray(a)).reshape(-1).astype(np.float64)
+    if lo_hi is not None:
+        v = v[(v >= lo_hi[0]) & (v <= lo_hi[1])]
+    if v.size == 0:
+        return 0, np.inf, -np.inf, np.nan, np.nan
+    mean = v.mean()
+    return int(v.size), float(v.min()), float(v.max()), float(mean), float(((v - mean) ** 2).sum())
+
+
 def _global_edges(arrays, bins, ranges, ex):
     """np.histogram_bin_edges (core.py:383-388) on data that is spread over the ranks"""
     import torch
 
     out = []
     for a, b, r in zip(arrays, bins, ranges):
-        if isinstance(b, str):
-            raise TypeError("When the data is sharded over GPUs, bins must be edges or an int (estimators need all the data)")
         proto = core._np_dtype_of(a) if core._is_torch(a) else np.asarray(a).dtype
+        if isinstance(b, str):
+            # "sqrt" / "sturges" / "rice" / "scott": every rank reduces its shard to (n, min, max, mean, M2) — on its GPU when
+            # the shard lives there — and one all-gather of five numbers per rank gives every rank the same combination
+            ok, lo_hi = core._estimator_cut(b, r, proto)
+            if not ok:
+                raise TypeError("When the data is sharded over GPUs, bins must be edges, an int or one of %s (the other "
+                                "estimators need all the data in one place)" % (core.ESTIMATORS_FROM_MOMENTS,))
+            mine = _local_moments(a, lo_hi, b == "scott")
+            size = int(a.numel() if core._is_torch(a) else np.asarray(a).size)
+            t = torch.tensor([float(v) for v in mine] + [float(size)], dtype=torch.float64, device=ex.device)
+            rows = [[float(v) for v in g.tolist()] for g in ex.all_gather(t)]
+            moments = core.combine_moments([(int(g[0]), g[1], g[2], g[3], g[4]) for g in rows])
+            edges = core._edges_from_moments(b, r, proto, int(sum(g[5] for g in rows)), moments)
+            if edges is None:
+                raise TypeError("bins=%r on sharded data: the data are (nearly) constant or sit on a bin-count tie that only numpy's "
+                                "own summation order over ALL the data decides; pass edges or an int" % (b,))
+            out.append(edges)
+            continue
         if np.ndim(b) == 0 and r is None:
             lo, hi, nan = _local_extrema(a)
             mn = torch.tensor([lo], dtype=torch.float64, device=ex.device)

@@ -542,15 +542,28 @@ def scatter(array, devices=None, axis=0):
     return Sharded(group.run(one, [None] * len(devs)), axis % array.ndim, devs)
 
 
-def _global_edges(args, bins, ranges, group, _extrema):
+def _global_edges(args, bins, ranges, group, _extrema, _moments=None):
     """np.histogram_bin_edges (core.py:383-388) of data spread over GPUs: explicit edges and ranges go through
     numpy; an integer ``bins`` with no range needs the GLOBAL min / max — reduced on every GPU by the library's
     kernel, combined on the host (two numbers per GPU)"""
     out = []
     for a, b, r in zip(args, bins, ranges):
-        if isinstance(b, str):
-            raise TypeError("When the data is sharded over GPUs, bins must be edges or an int (estimators need all the data)")
         proto = core._np_dtype_of(a.parts[0])
+        if isinstance(b, str):
+            # "sqrt" / "sturges" / "rice" / "scott": every GPU reduces its shard to five numbers, combined on the host
+            ok, lo_hi = core._estimator_cut(b, r, proto)
+            if not ok:
+                raise TypeError("When the data is sharded over GPUs, bins must be edges, an int or one of %s (the other "
+                                "estimators need all the data in one place)" % (core.ESTIMATORS_FROM_MOMENTS,))
+            get = _moments or core._device_moments
+            parts = group.run(lambda rank, device, part: get(part, lo_hi, b == "scott"), a.parts)
+            size = sum(int(np.prod(p.shape)) for p in a.parts)
+            edges = core._edges_from_moments(b, r, proto, size, core.combine_moments(parts))
+            if edges is None:  # (nearly constant data or a tie under "scott": numpy's own summation order decides)
+                whole = np.concatenate([np.asarray(p.detach().cpu().numpy() if core._is_torch(p) else p).reshape(-1) for p in a.parts])
+                edges = np.histogram_bin_edges(whole, bins=b, range=r)
+            out.append(edges)
+            continue
         if np.ndim(b) == 0 and r is None:
             ext = group.run(lambda rank, device, part: _extrema(part), a.parts)
             nan = any(e[2] for e in ext)
@@ -567,7 +580,7 @@ def _global_edges(args, bins, ranges, group, _extrema):
 
 
 def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", exchange="rccl",
-              _local=None, _reduce=None, _extrema=None):
+              _local=None, _reduce=None, _extrema=None, _moments=None):
     """``core.histogram`` of :class:`Sharded` inputs (same shard axis and devices for all; ``weights`` a
     Sharded too, or an array every shard broadcasts against).  Each GPU's thread bins its shard with the
     fused kernel; then
@@ -577,7 +590,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     * shard axis kept               -> the shards' rows are copied to the first GPU and concatenated;
 
     density (core.py:444-462) is applied after the exchange.  Returns ``(hist, edges)`` with ``hist`` a
-    torch tensor on ``devices[0]``.  ``_local`` / ``_reduce`` / ``_extrema`` are test seams (the CPU tests
+    torch tensor on ``devices[0]``.  ``_local`` / ``_reduce`` / ``_extrema`` / ``_moments`` are test seams (the CPU tests
     run the sharding and exchange logic with the oracle as the per-shard compute); production never sets them."""
     if not args or not all(isinstance(a, Sharded) for a in args):
         raise TypeError("multigpu.histogram takes Sharded inputs (see multigpu.scatter); plain arrays go to core.histogram")
@@ -603,7 +616,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         from .distributed import _local_extrema as _extrema
     bins = core._ensure_correctly_formatted_bins(bins, n_inputs)
     range = core._ensure_correctly_formatted_range(range, n_inputs)
-    edges = _global_edges(args, bins, range, group, _extrema)
+    edges = _global_edges(args, bins, range, group, _extrema, _moments)
     kwargs = dict(weights=has_weights, axis=axis, bins=edges, density=False, block_size=block_size)
     reduce_shards = first.axis in drop_axes
 
