@@ -1150,6 +1150,24 @@ def test_partitioned_mode_chunk_pool_runs_dry(xh, weights, pct):
     plan.set_param("route_pool_pct", 0)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_partitioned_mode_chunk_pool_runs_dry_with_several_rows_per_pass(xh, weighted):
+    """the pool-dry path addresses the output by (row, partition): several rows in one routing pass, pool cut to 3 %"""
+    rng = np.random.default_rng(64)
+    rows, n = 9, 90_001
+    x, y = rng.standard_normal((rows, n)), rng.standard_normal((rows, n)) * 1.2
+    edges = [np.linspace(-3, 3, 301), np.linspace(-3, 3, 301)]
+    w = rng.uniform(0, 1, (rows, n)) if weighted else None
+    got, desc = _run(xh, [x, y], edges, w, True, partition=1, route_pool_pct=3)
+    assert "hist=partitioned" in desc and "rows_per_pass=1 " not in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([x, y], edges, w), weighted)
+    torch.cuda.synchronize()
+    plan = _plan_for(xh, [_dev(x), _dev(y)], edges)
+    assert "pool_dry=1" in plan.describe(), plan.describe()
+    plan.set_param("route_pool_pct", 100)
+    plan.set_param("route_pool_pct", 0)
+
+
 @pytest.mark.parametrize("dt", [np.float64, np.float32, np.int32])
 @pytest.mark.parametrize("name", ["sqrt", "sturges", "rice", "scott"])
 def test_bin_estimators_on_device_resident_data_without_a_host_copy(xh, name, dt, monkeypatch):
