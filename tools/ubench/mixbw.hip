@@ -151,6 +151,72 @@ __global__ void route_shape(const u4* __restrict__ a, const u4* __restrict__ b, 
   (void)cursor;
 }
 
+// route_phases: route_shape's traffic with part_route's PHASE structure added step by step, to see which step costs the
+// 12 % between the bare traffic (5.3 TB/s) and the real pass (4.75):
+//   MODE 0  load tile -> use -> store tile                       (= route_shape, PAIR loads, 64 streams of 512-byte pieces)
+//   MODE 1  + __syncthreads() between load, use and store        (the workgroup moves in lockstep)
+//   MODE 2  + the tile's records go through LDS (write, barrier, read back by another lane) before they are stored
+//   MODE 3  + late prefetch: the NEXT tile's loads are issued before this tile's LDS round trip and waited for ahead of the stores
+//   MODE 4  = MODE 3 + returning LDS atomics (4 per lane, 64 counters) ahead of the prefetch, a 64-lane scan phase between barriers
+template <int MODE>
+__global__ void route_phases(const u4* __restrict__ a, const u4* __restrict__ b, const u4* __restrict__ c, u4* __restrict__ o, long tiles_per_wg,
+                             int piece16, int streams, long stream_stride16) {
+  extern __shared__ u4 lds[];
+  unsigned* cnt = reinterpret_cast<unsigned*>(lds + 2 * blockDim.x + 64);
+  const int tid = threadIdx.x, B = blockDim.x;
+  const long wg_out = (long)blockIdx.x * streams * stream_stride16;
+  const long per_tile = (2L * B) / piece16 / streams;
+  auto tile_at = [&](long k) { return ((long)blockIdx.x + k * gridDim.x) * (2L * B); };
+  u4 v[3][2], n[3][2];
+  auto load = [&](long k, u4 (&r)[3][2]) {
+    const long i0 = tile_at(k) + 2L * tid, i1 = i0 + 1;
+    r[0][0] = __builtin_nontemporal_load(a + i0); r[0][1] = __builtin_nontemporal_load(a + i1);
+    r[1][0] = __builtin_nontemporal_load(b + i0); r[1][1] = __builtin_nontemporal_load(b + i1);
+    r[2][0] = __builtin_nontemporal_load(c + i0); r[2][1] = __builtin_nontemporal_load(c + i1);
+  };
+  if (MODE >= 4) { if (tid < 64) cnt[tid] = 0; __syncthreads(); }
+  load(0, v);
+  for (long k = 0; k < tiles_per_wg; ++k) {
+    if (MODE < 3 && k > 0) load(k, v);
+    u4 rec0 = v[0][0] ^ v[1][0] ^ v[2][0], rec1 = v[0][1] ^ v[1][1] ^ v[2][1];
+    unsigned rk = 0;
+    if (MODE >= 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rk += atomicAdd(cnt + ((rec0[q] + tid * 7 + q * 13) & 63), 1u);
+    }
+    if (MODE >= 3) { const long kn = k + 1 < tiles_per_wg ? k + 1 : k; load(kn, n); }
+    if (MODE >= 1) __syncthreads();
+    if (MODE >= 4) {
+      if (tid < 64) {  // a scan over the 64 counters by one wavefront, as the block layout of part_route
+        unsigned x = cnt[tid];
+        for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off, 64); x += (tid >= off) ? y : 0u; }
+        cnt[tid] = x & 0u;  // (and cleared for the next tile)
+      }
+      __syncthreads();
+    }
+    if (MODE >= 2) {
+      rec0[1] += rk;
+      lds[tid] = rec0; lds[B + tid] = rec1;
+      __syncthreads();
+      const int src = (tid * 17 + 5) % B;  // another lane's records: the sort
+      rec0 = lds[src]; rec1 = lds[B + src];
+    }
+    if (MODE >= 3) {
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) { asm volatile("" : "+v"(n[s3][0])); asm volatile("" : "+v"(n[s3][1])); v[s3][0] = n[s3][0]; v[s3][1] = n[s3][1]; }
+    }
+    if (MODE >= 1) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long u = (long)j * B + tid;
+      const long pc = u / piece16, within = u % piece16;
+      const long sidx = pc % streams, nth = pc / streams;
+      const long dst = wg_out + sidx * stream_stride16 + (k * per_tile + nth) * piece16 + within;
+      __builtin_nontemporal_store(j ? rec1 : rec0, o + dst);
+    }
+  }
+}
+
 static float median(std::vector<float>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 typedef void (*kern_t)(const u4*, const u4*, const u4*, u4*, long);
@@ -198,7 +264,7 @@ int main(int argc, char** argv) {
   };
   const int grids[] = {256, 512, 1024, 2048, 4096, 8192};
   const int blocks[] = {256, 512, 1024};
-  const bool only_route = argc > 1 && (argv[1][0] == 'r' || argv[1][0] == 's');
+  const bool only_route = argc > 1 && (argv[1][0] == 'r' || argv[1][0] == 's' || argv[1][0] == 'p');
   const bool quick_mix = argc > 1 && argv[1][0] == 'm';  // the 24:8 mix only, nt loads
   if (!only_route)
   for (const Variant& v : vars)
@@ -257,6 +323,41 @@ int main(int argc, char** argv) {
           printf("{\"layout\": \"%s\", \"streams\": %d, \"loads_per_stream\": %d, \"nt_load\": %d, \"grid\": %d, \"block\": %d, \"KB_in_flight_per_cu\": %.0f, "
                  "\"read_GB\": %.2f, \"ms\": %.3f, \"read_gbs\": %.0f}\n",
                  v.tile ? "tile" : "front", v.ns, v.L, v.ntl, grid, block, (double)v.ns * 16 * v.L * lanes / 256 / 1024, rd / 1e9, t, rd / t / 1e6);
+          fflush(stdout);
+        }
+    return 0;
+  }
+  // ---- part_route's phase structure, step by step (argument "p") ----------------------------------
+  if (argc > 1 && argv[1][0] == 'p') {
+    const long units_per_stream = stream_bytes / 16;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int block : {512, 1024})
+        for (int mode = 0; mode <= 4; ++mode) {
+          const int per_cu = 1024 / block, grid = 256 * per_cu, streams = 64;
+          const long tiles_per_wg = units_per_stream / (2L * block) / grid;
+          const int piece16 = (2 * block) / streams;
+          const long stream_stride16 = tiles_per_wg * piece16;
+          const size_t lds_bytes = (size_t)(2 * block + 64) * 16 + 256;
+          std::vector<float> tt;
+          for (int it = 0; it < 6; ++it) {
+            CK(hipEventRecord(e0));
+            switch (mode) {
+              case 0: hipLaunchKernelGGL(route_phases<0>, dim3(grid), dim3(block), lds_bytes, 0, a, b, c, o, tiles_per_wg, piece16, streams, stream_stride16); break;
+              case 1: hipLaunchKernelGGL(route_phases<1>, dim3(grid), dim3(block), lds_bytes, 0, a, b, c, o, tiles_per_wg, piece16, streams, stream_stride16); break;
+              case 2: hipLaunchKernelGGL(route_phases<2>, dim3(grid), dim3(block), lds_bytes, 0, a, b, c, o, tiles_per_wg, piece16, streams, stream_stride16); break;
+              case 3: hipLaunchKernelGGL(route_phases<3>, dim3(grid), dim3(block), lds_bytes, 0, a, b, c, o, tiles_per_wg, piece16, streams, stream_stride16); break;
+              default: hipLaunchKernelGGL(route_phases<4>, dim3(grid), dim3(block), lds_bytes, 0, a, b, c, o, tiles_per_wg, piece16, streams, stream_stride16); break;
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 2) tt.push_back(ms);
+          }
+          const float t = median(tt);
+          const double rd = 3.0 * 16 * 2.0 * block * tiles_per_wg * grid, wr = 16.0 * 2.0 * block * tiles_per_wg * grid;
+          printf("{\"layout\": \"route_phases\", \"mode\": %d, \"block\": %d, \"wg_per_cu\": %d, \"read_GB\": %.2f, \"write_GB\": %.2f, \"ms\": %.3f, \"moved_gbs\": %.0f}\n",
+                 mode, block, per_cu, rd / 1e9, wr / 1e9, t, (rd + wr) / t / 1e6);
           fflush(stdout);
         }
     return 0;
