@@ -793,6 +793,10 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     // uniform bins stay on the streaming kernels instead of 43 ms/10^9 samples of global atomics.
     // Also when the tables fit but only with 3-4 edges per bucket (float32, 20000 bins: 1.17 against 1.39 ms);
     // with 1-2 edges per bucket the tables win (C2: 2.28 against 2.40 ms, float32 50 bins: 0.69 against 1.12).
+    // (Round 3: the arithmetic digitize needs no edge any more unless the sample is next to one — bin_arith_fast, 4-19 % off
+    // every table-free launch — and on one box it beat the one-edge-per-bucket tables for float64 samples too, 1.33 -> 1.22 ms
+    // for the unweighted headline; on another the two were level (1.19 / 1.21), 10^6 samples went 8.8 -> 12.7 us and a 20^3
+    // float64 histogram 1.97 -> 2.06 ms: the rule stays as it was.  profiles/r03_ar_arith_ab.txt)
     if (fast && (float_samples || mixed) && p->arith && arith_pref >= 0 &&
         (!tables_fit || hist == kHistGlobal || scan == 0 || scan >= 3 || arith_pref > 0)) {
       const int h0 = hist, c0 = cl2;

@@ -459,7 +459,32 @@ template <int CMP, int SCAN, int D, int UNROLL, int VEC, typename XV, typename T
 __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const Params& p, TabPtr tab, int max_steps,
                                                uint32_t (&cnt)[D][UNROLL][VEC]) {
   using CT = typename Dom<CMP>::T;
-  if constexpr (SCAN > 0) {
+  if constexpr (SCAN == kScanArith) {
+    // arithmetic edges: the bin by arithmetic alone for every sample that is not within delta bins of an edge
+    // (bin_arith_fast: 9 float64 operations instead of ~25); a wavefront in which some lane met such a sample — or NaN,
+    // +-inf — redoes that lane's batch with the exact compares.  Counts of dropped samples are 0 (callers test the range).
+    bool near_any = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          bool near;
+          cnt[d][u][v] = (uint32_t)(bin_arith_fast((double)xv[d][u][v], p.dim[d], near) + 1);
+          near_any |= near;
+        }
+    if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {
+      if (near_any) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_arith((double)xv[d][u][v], p.dim[d]);
+      }
+    }
+  } else if constexpr (SCAN > 0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
