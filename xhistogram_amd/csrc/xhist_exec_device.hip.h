@@ -834,6 +834,17 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     fn = fast ? (i64dom ? int64_domain_kernel(wdt, D, scan, hist, &vec) : fast_kernel(sdt, wdt, D, scan, hist, &vec))
               : generic_kernel(p->cmp, weighted, lds_hist, tables_in_lds);
   }
+  // One long float64 row without weights (the headline's 8 B/sample variant): 16 samples per lane and tile — the 128 bytes per
+  // lane in flight that the weighted kernel has with its two streams.  10^9 samples, 100 bins: 1.20-1.24 -> 1.14-1.15 ms
+  // (0.83 -> 0.88 of 8 TB/s; profiles/r03_u8_unroll8.txt).  Short or many rows keep 8 (their geometry rules were fitted to it).
+  bool long_tiles = false;
+  if (fn && fast && !mixed && !two && !i64dom && sdt == XHIST_F64 && !weighted && D == 1 && hist == kHistLds && (scan == 1 || scan == 2) &&
+      n_rows == 1 && n_cols >= ((int64_t)1 << 26) && !block_threads && !grid_blocks) {
+    if (kernel_fn lf = xhist_pick_f64_long(scan)) {
+      fn = lf;
+      long_tiles = true;
+    }
+  }
   if (two && !accumulate) {
     if (int zrc = zero_output(out, out_elems, stream)) return zrc;
     if (int zrc = zero_output(out2, out_elems, stream)) return zrc;
@@ -972,7 +983,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       accumulate = 1;  // the output has just been zeroed
     }
   }
-  const int kUnroll = mixed ? mixed_unroll(D) : (fast ? unroll_for(D, vec, scan) : 1);
+  const int kUnroll = long_tiles ? 8 : (mixed ? mixed_unroll(D) : (fast ? unroll_for(D, vec, scan) : 1));
 
   // ---- geometry -----------------------------------------------------------------------------
   // Workgroups per CU are sized by bytes in flight, not by occupancy: measured on MI355X
