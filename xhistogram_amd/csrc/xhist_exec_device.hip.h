@@ -834,13 +834,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     fn = fast ? (i64dom ? int64_domain_kernel(wdt, D, scan, hist, &vec) : fast_kernel(sdt, wdt, D, scan, hist, &vec))
               : generic_kernel(p->cmp, weighted, lds_hist, tables_in_lds);
   }
-  // One long float64 row without weights (the headline's 8 B/sample variant): 16 samples per lane and tile — the 128 bytes per
-  // lane in flight that the weighted kernel has with its two streams.  10^9 samples, 100 bins: 1.20-1.24 -> 1.14-1.15 ms
-  // (0.83 -> 0.88 of 8 TB/s; profiles/r03_u8_unroll8.txt).  Short or many rows keep 8 (their geometry rules were fitted to it).
+  // One input without weights, long rows: twice the samples per lane and tile — the 128 bytes per lane in flight that the
+  // weighted kernel has with its two streams.  float64, one row of 10^9 samples, 100 bins (the headline's 8 B/sample variant):
+  // 1.20-1.24 -> 1.14-1.16 ms (0.83 -> 0.86-0.88 of 8 TB/s); float32, BASELINE C4 (456 / 3650 rows of 1 036 800): 0.2872 ->
+  // 0.2838 ms (0.823 -> 0.833) and 2.228 -> 2.208 ms (0.849 -> 0.857), profiles/r03_u8_unroll8.txt.  Short rows keep their tiles
+  // (the geometry rules further down were fitted to them); float64 with many rows was not measured and stays as it was.
   bool long_tiles = false;
-  if (fn && fast && !mixed && !two && !i64dom && sdt == XHIST_F64 && !weighted && D == 1 && hist == kHistLds && (scan == 1 || scan == 2) &&
-      n_rows == 1 && n_cols >= ((int64_t)1 << 26) && !block_threads && !grid_blocks) {
-    if (kernel_fn lf = xhist_pick_f64_long(scan)) {
+  if (fn && fast && !mixed && !two && !i64dom && !weighted && D == 1 && hist == kHistLds && (scan == 1 || scan == 2) && !block_threads && !grid_blocks) {
+    kernel_fn lf = nullptr;
+    // (exactly the two shape classes that were measured: one float32 row of 3*10^7 ... 10^9 samples came out 4-10 % SLOWER
+    // with the long tiles in tools/size_ramp.py — its one-workgroup-per-CU geometry already has 64 KiB per CU in flight)
+    if (sdt == XHIST_F64 && n_rows == 1 && n_cols >= ((int64_t)1 << 29)) lf = xhist_pick_f64_long(scan);
+    else if (sdt == XHIST_F32 && n_rows >= 64 && n_cols >= ((int64_t)1 << 19)) lf = xhist_pick_f32_long(scan);
+    if (lf) {
       fn = lf;
       long_tiles = true;
     }

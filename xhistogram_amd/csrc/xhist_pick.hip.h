@@ -216,6 +216,7 @@ static kernel_fn_route route_pick(int wdt, int D, int scan, bool multi) {
 kernel_fn xhist_pick_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_f64_long(int scan);  // hist_fast<double, NoWeight, 1, 2, 8, kHistLds, scan>
+kernel_fn xhist_pick_f32_long(int scan);  // hist_fast<float, NoWeight, 1, 4, 8, kHistLds, scan>
 kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
