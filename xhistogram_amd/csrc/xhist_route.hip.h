@@ -4,25 +4,25 @@
 // samples only to size the record slots, spills a 4-byte flat index), prefix, scatter — and moves
 // 52.5 B per C5 sample for 24 algorithmic.  Here the slots are not counted in advance: record space is
 // handed out on demand in CHUNKS, so one kernel reads the samples, digitizes them, sorts each
-// 8192-sample tile by partition in LDS and writes the records; a second one adds them up.
+// tile (4 samples per lane: 2048 or 4096) by partition in LDS and writes the records; a second one adds them up.
 //
 //   part_route              reads x (, y, z), w: 24 B/sample (C5); writes (code u16, weight) records:
 //                           10 B/sample (8 when packed, see below), into chunks of 2^chunk_log2 records that belong to ONE
 //                           (workgroup, partition) pair — no other workgroup writes there, so record
 //                           addresses need no atomics; a lane that owns a partition takes a new chunk
-//                           id from a global counter when its chunk is full (one atomic per chunk,
-//                           issued a whole chunk ahead so nobody waits for it) and files the id in the
-//                           partition's chunk list
+//                           id from an LDS-resident stock (refilled from a global counter a tile ahead, so
+//                           nobody waits for it) and files the id in the partition's chunk list; when the
+//                           pool has no chunk left, records go straight to the output (kRouteDirect)
 //   part_accumulate_chunks  every workgroup takes an equal share of the concatenated chunk lists
 //                           (balanced for any distribution of the samples), streams the chunks
 //                           (contiguous, 16-byte aligned), ds_adds into a 2^shift-bin LDS histogram
-//                           and flushes it at partition boundaries: 10 B/sample read
+//                           and flushes it at partition boundaries: 10 (8) B/sample read
 //
-// HBM traffic 24 + 10 + 10 = 44 B per C5 sample.  What bounds it: a kernel that reads 12 GB and
-// writes 5 GB runs at 4.8-5.1 TB/s on this chip and reading 5 GB back takes 0.86 ms more, whatever the
-// chunk size and whether or not the records would fit the 256 MiB Infinity Cache
-// (tools/ubench/mall.hip, profiles/r02_a_mall.jsonl: 4.1-4.6 ms for the bare traffic of a 5*10^8-sample
-// shard).
+// HBM traffic 24 + 10 + 10 = 44 B per C5 sample, 40 with packed records.  What bounds it (round 3): the
+// chip moves this read/write mix at 5.3-5.6 TB/s in the pass's access shape (32-byte lane loads, 64 scattered write
+// streams per workgroup; tools/ubench/mixbw.hip, profiles/r03_a_*, r03_d_*), and a bare kernel with ALL of the pass's
+// phases — barriers, LDS round trip, late prefetch, returning LDS atomics — still does (profiles/r03_ph_*): 3.05-3.25 ms
+// for a 5*10^8-sample shard, against 3.26-3.42 measured; reading the records back takes 0.57 ms at best, 0.72-0.76 measured.
 //
 // Packed records.  float64 weights of ONE sign travel as 8-byte records — the weight's upper 48 bits with the bin
 // code in the 16 that go (rounded to nearest: 2^-37 relative per weight, and no cancellation to amplify it): 24 + 8 + 8 = 40 B per sample,
