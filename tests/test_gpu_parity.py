@@ -1096,28 +1096,64 @@ def test_arithmetic_edges_2d_beyond_lds_tables(xh):
     np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges))
 
 
-@pytest.mark.parametrize("block", [512, 1024])
+@pytest.mark.parametrize("block,spl", [(512, 4), (1024, 4), (1024, 8)])
 @pytest.mark.parametrize("lo,hi,nb", [(-4.0, 4.0, 1024), (0.0, 1.0, 1500), (-1e-300, 3e-300, 1100), (-1e300, 1e300, 1200),
                                       (1e6, 1e6 + 1.0, 1030), (-123.456, -123.0, 2000), (0.1, 0.7, 1111)])
-def test_partitioned_mode_arithmetic_digitize_on_and_next_to_every_edge(xh, lo, hi, nb, block):
+def test_partitioned_mode_arithmetic_digitize_on_and_next_to_every_edge(xh, lo, hi, nb, block, spl):
     """The routing pass decides bins of arithmetic edges by arithmetic alone unless a sample is within delta bins of an
     edge (bin_arith_fast, xhist_kernels.hip.h): a sample on every edge and on both floating-point neighbours of it, in
     both dimensions, must land where searchsorted puts it (core.py:163-174) — for several magnitudes of e_0 and step and
-    every workgroup size of the pass."""
-    rng = np.random.default_rng(nb + block)
+    every workgroup size and tile length of the pass."""
+    rng = np.random.default_rng(nb + block + spl)
     edges = [np.linspace(lo, hi, nb + 1), np.linspace(-2.0, 6.0, 1025)]
     x = _edge_torture(edges[0], rng, 20_000)
     y = _edge_torture(edges[1], rng, x.shape[1] - 3 * 1025 - 7)
     assert x.shape == y.shape
     rng.shuffle(y[0])
     want = onp.bincount_rows([x, y], edges)
-    got, desc = _run(xh, [x, y], edges, None, True, partition=1, arith=1, route_block=block)
-    assert "hist=partitioned" in desc and "route=fused" in desc and "scan=5" in desc and "block=%d" % block in desc, desc
+    got, desc = _run(xh, [x, y], edges, None, True, partition=1, arith=1, route_block=block, route_spl=spl)
+    assert "hist=partitioned" in desc and "route=fused" in desc and "scan=5" in desc, desc
+    assert "tile=%d block=%d " % (block * spl, block) in desc, desc
     np.testing.assert_array_equal(got, want, err_msg=desc)
     w = rng.uniform(0.5, 1.5, x.shape)
-    got, desc = _run(xh, [y, x], edges[::-1], w, True, partition=1, arith=1, route_block=block)
-    assert "scan=5" in desc, desc
+    got, desc = _run(xh, [y, x], edges[::-1], w, True, partition=1, arith=1, route_block=block, route_spl=spl)
+    assert "scan=5" in desc and "tile=%d block=%d " % (block * spl, block) in desc, desc
     assert_hist_equal(got, onp.bincount_rows([y, x], edges[::-1], w), True)
+
+
+@pytest.mark.parametrize("geometry", ["auto", (512, 4), (1024, 4), (1024, 8)], ids=str)
+@pytest.mark.parametrize("edges_kind", ["linspace", "uneven"])
+@pytest.mark.parametrize("weights", ["none", "f32", "f64_one_sign", "f64_both_signs"])
+@pytest.mark.parametrize("dims,dtype", [(1, np.float64), (2, np.float64), (3, np.float64), (1, np.float32), (2, np.float32), (3, np.float32)])
+def test_partitioned_mode_routing_geometries(xh, dims, dtype, weights, edges_kind, geometry):
+    """The routing pass exists per workgroup size and tile length (route_geom_for, xhist_exec_device.hip.h: 1024 threads x 8
+    samples where the registers allow, else 1024 x 4; 2 x 512 for A/B runs): every geometry, forced, and the automatic choice
+    give the reference's histogram for every dtype combination — ragged tail, NaNs, right-edge samples and a tile-sized
+    run of one value included."""
+    rng = np.random.default_rng(dims * 7 + len(weights))
+    n = 300_000 + 8191 + 3
+    nb = {1: 200_000, 2: 300, 3: 48}[dims]
+    e = np.linspace(-4, 4, nb + 1)
+    if edges_kind == "uneven":
+        e = np.sort(e + rng.uniform(-0.4, 0.4, e.size) * (e[1] - e[0]))
+        if dims == 1:
+            e = e[:: 20]  # (tables of uneven edges have to fit the LDS for the fast family: 10^4 bins, not partitioned)
+    edges = [e] * dims
+    xs = [rng.standard_normal((1, n)).astype(dtype) * (1.0 + 0.3 * d) for d in range(dims)]
+    xs[0][0, ::499] = np.nan
+    if float(dtype(e[-1])) == e[-1]:
+        xs[-1][0, 7::1013] = e[-1]  # right edge of the last bin
+    for x in xs:
+        x[0, 100_000:100_000 + 9000] = 0.25  # more than a tile of one (bin, partition)
+    w = {"none": None, "f32": rng.uniform(0, 1, (1, n)).astype(np.float32), "f64_one_sign": rng.uniform(0, 1, (1, n)),
+         "f64_both_signs": rng.standard_normal((1, n))}[weights]
+    params = {} if geometry == "auto" else {"route_block": geometry[0], "route_spl": geometry[1]}
+    want = onp.bincount_rows(xs, edges, w)
+    got, desc = _run(xh, xs, edges, w, True, partition=1, **params)
+    assert "hist=partitioned" in desc or (dims == 1 and edges_kind == "uneven"), desc
+    if geometry != "auto" and "route=fused" in desc:
+        assert "tile=%d block=%d " % (geometry[0] * geometry[1], geometry[0]) in desc, desc
+    assert_hist_equal(got, want, w is not None)
 
 
 @pytest.mark.parametrize("weights", ["none", "one_sign", "both_signs", "f32"])

@@ -4,6 +4,7 @@ routing pass + adding-up pass) over `--steps` launches after `--warmup`, and a c
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split (kernel names carry the workgroup size).
 
   python tools/c5_ab.py [--n 500000000] [--dist normal|uniform|const] [--variants "route_block=512;route_block=256"]
+                        [--dtype f64|f32] [--dims 1|2|3] [--rows R] [--bins B] [--unweighted]
 """
 import argparse
 import json
@@ -27,15 +28,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--unweighted", action="store_true")
     ap.add_argument("--signs", default="one", choices=["one", "both"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--wdtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dims", type=int, default=2)
+    ap.add_argument("--edges", default="linspace", choices=["linspace", "jitter"], help="jitter: uneven edges (table lookups)")
+    ap.add_argument("--rows", type=int, default=1, help="n is split into this many rows (one histogram per row)")
     ap.add_argument("--variants", default="route_block=1024;route_block=512;route_block=256")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
-    n = args.n
+    rows = args.rows
+    cols = args.n // rows
+    n = rows * cols
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    tag = _native.F64 if args.dtype == "f64" else _native.F32
 
     def sample():
-        t = torch.empty(n, dtype=torch.float64, device=dev)
+        t = torch.empty(n, dtype=tdt, device=dev)
         if args.dist == "normal":
             t.normal_(generator=g)
         elif args.dist == "uniform":
@@ -44,16 +54,19 @@ def main():
             t.fill_(0.123)
         return t
 
-    x, y = sample(), sample()
+    xs = [sample() for _ in range(args.dims)]
     w = None
     if not args.unweighted:
-        w = torch.empty(n, dtype=torch.float64, device=dev).uniform_(generator=g)
+        w = torch.empty(n, dtype=torch.float64 if args.wdtype == "f64" else torch.float32, device=dev).uniform_(generator=g)
         if args.signs == "both":
             w -= 0.5
-    edges = [np.linspace(-4.0, 4.0, args.bins + 1)] * 2
-    out = torch.zeros((args.bins, args.bins), dtype=torch.float64 if w is not None else torch.int64, device=dev)
-    xv = [_native.make_view(a.data_ptr(), _native.F64, n, 1) for a in (x, y)]
-    wv = _native.make_view(w.data_ptr(), _native.F64, n, 1) if w is not None else None
+    e = np.linspace(-4.0, 4.0, args.bins + 1)
+    if args.edges == "jitter":
+        e = np.sort(e + np.random.default_rng(5).uniform(-0.45, 0.45, e.size) * (e[1] - e[0]))
+    edges = [e] * args.dims
+    out = torch.zeros((rows,) + (args.bins,) * args.dims, dtype=torch.float64 if w is not None else torch.int64, device=dev)
+    xv = [_native.make_view(a.data_ptr(), tag, cols, 1) for a in xs]
+    wv = _native.make_view(w.data_ptr(), _native.F64 if args.wdtype == "f64" else _native.F32, cols, 1) if w is not None else None
     stream = torch.cuda.current_stream(dev).cuda_stream
     ref = None
     for spec in args.variants.split(";"):
@@ -66,7 +79,7 @@ def main():
             k, _, v = item.partition("=")
             plan.set_param(k, int(v))
             kv[k] = int(v)
-        run = plan.bind(xv, wv, 1, n, out.data_ptr(), w is not None, _native.MEM_DEVICE, False, stream)
+        run = plan.bind(xv, wv, rows, cols, out.data_ptr(), w is not None, _native.MEM_DEVICE, False, stream)
         for _ in range(args.warmup):
             run()
         torch.cuda.synchronize(dev)
@@ -84,7 +97,7 @@ def main():
             ok = bool(torch.equal(res, ref))
         else:
             ok = bool(torch.allclose(res, ref, rtol=1e-9, atol=0.0))
-        bps = 16 + (8 if w is not None else 0)
+        bps = args.dims * (8 if args.dtype == "f64" else 4) + ((8 if args.wdtype == "f64" else 4) if w is not None else 0)
         print(json.dumps({"variant": spec, "dist": args.dist, "n": n, "ms_median": ms[len(ms) // 2], "ms_min": ms[0], "ms_max": ms[-1],
                           "frac_of_8TBs": n * bps / (ms[len(ms) // 2] * 1e-3) / 8e12, "matches_first": ok, "sum": float(res.sum()),
                           "desc": plan.describe()}), flush=True)

@@ -255,6 +255,8 @@ int main(int argc, char** argv) {
       V("tile", true, 1, 1, true, true), V("tile", true, 1, 1, true, false),
       V("tile", true, 2, 2, true, true), V("tile", true, 2, 2, true, false),
       V("tile", true, 4, 4, true, true), V("tile", true, 4, 4, true, false),
+      // bigger workgroup tiles: is it the 64 KiB contiguous per stream, workgroup and round that makes (tile, 4, 1024 threads) special?
+      V("tile", true, 8, 8, true, true), V("tile", true, 16, 16, true, true), V("tile", true, 3, 3, true, true), V("tile", true, 6, 6, true, true),
       // direction split between workgroups
       VS(1, 1, true, true), VS(1, 1, true, false), VS(2, 2, true, true), VS(2, 2, true, false),
       // calibration: read only (3 streams), write only, 1:1 copy traffic (3 in, 3 out per lane)
@@ -272,6 +274,7 @@ int main(int argc, char** argv) {
       for (int grid : grids) {
         if ((long)grid * block > 4L * 1024 * 1024) continue;
         if (quick_mix && !(v.L == v.W && v.L > 0 && v.ntl && v.split == 0 && grid <= 2048)) continue;
+        if (argc > 1 && argv[1][0] == 'm' && argv[1][1] == 'b' && !(v.L == v.W && v.L >= 3 && v.nts && v.layout[0] == 't')) continue;
         const long lanes = (long)grid * block;
         const int unit = std::max(v.L, v.W);
         const long rounds = stream_bytes / (16L * unit * lanes);

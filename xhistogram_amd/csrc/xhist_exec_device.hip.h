@@ -183,7 +183,12 @@ static bool exact_records_env() {
   return v;
 }
 
-static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi, int block) {
+static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi, int block, int spl = 4) {
+  if (spl == 8) {
+    if (block != 1024) return nullptr;
+    return sdt == XHIST_F64 ? xhist_pick_route_f64_b1024s8(wdt, D, scan, multi) : sdt == XHIST_F32 ? xhist_pick_route_f32_b1024s8(wdt, D, scan, multi) : nullptr;
+  }
+  if (spl != 4) return nullptr;
   if (sdt == XHIST_F64)
     return block == 1024 ? xhist_pick_route_f64_b1024(wdt, D, scan, multi) : block == 512 ? xhist_pick_route_f64_b512(wdt, D, scan, multi) : nullptr;
   if (sdt == XHIST_F32)
@@ -191,9 +196,38 @@ static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool mult
   return nullptr;
 }
 
-// workgroup size of the routing pass ("route_block" overrides): two 512-thread workgroups per CU where records carry
-// weights, one of 1024 threads for the 2-byte records of counts (see xhist_route.hip.h for the measurements)
-static int route_block_for(const xhist_plan* p, bool weighted) { return p->route_block ? p->route_block : (weighted ? 512 : 1024); }
+// Geometry of the routing pass: workgroup size and samples per lane and tile ("route_block" / "route_spl" override).
+// Long tiles — 1024 threads x 8 samples, 64 KB read per input and tile — are what the mixed read/write traffic of the pass
+// wants (tools/ubench/mixbw `mb`: 24 B read : 8 B written per sample runs at 4.8-5.6 TB/s with 32 KB bursts per workgroup and
+// at 5.7-6.0 with 64 KB and more), as long as the tile's samples and weights fit the 128 registers a lane of a 1024-thread
+// workgroup has: 2 x (bytes of one sample of every input + bytes of its weight) registers hold the tile, and up to 32 of
+// them leave room for the rest (24 with table lookups, which take more registers than the arithmetic digitize).
+// Measured over 5*10^8 samples, ms per call, 1024 x 4 -> 1024 x 8 | 2 x 512 x 4 (profiles/r03_s8_route_geometry.txt):
+//   counts:  f64 pair 2.58 -> 2.40;  f64, 10^6 bins 1.82 -> 1.58;  f32 pair 1.98 -> 1.60 | 1.96;  f32 triple (3*10^8) 1.39 -> 1.20
+//            | 1.57;  f64 triple (48 registers) 2.13 -> 2.19 (stays at 4)
+//   f32 weights:  f32 pair 2.92 -> 2.64 | 3.62;  f32, 10^6 bins 2.47 -> 2.26 | 3.21;  f64, 10^6 bins 2.78 -> 2.55 | 3.33;
+//            f64 pair (40 registers) 3.51 -> 3.49 | 4.12;  32 rows of 3*10^7 f32 pairs, 400 x 400 bins 5.42 -> 4.44 | 5.88
+//   f64 weights, packed records:  f32 pair 3.20 -> 3.03 | 3.32;  f32, 10^6 bins 3.02 -> 2.77 | 3.00;
+//            f32 triple (40 registers) 2.16 -> 2.47 | 2.26
+//   f64 samples AND f64 weights are the exception to the register count: the long tile loses (C5 4.13 -> 4.52, it spills;
+//   10^6 bins 3.36 -> 3.57) and they keep 1024 x 4.
+// Two 512-thread workgroups per CU (VERDICT r2 "next" #1b: one's loads and stores under the other's arithmetic) beat one of
+// 1024 by 2-3 % on C5 while the pass loaded its weights with the samples (3.43-3.48 -> 3.35-3.37 ms,
+// profiles/r03_c5_blocks.txt); with the weights loaded a tile later and the arithmetic digitize they lose everywhere
+// (C5 3.94 | 4.11, uniform 3.93 | 4.12, 10^6 bins 3.28 | 3.32, 8 rows x 512 x 512 bins 3.82 | 3.89; exact float64 records
+// 4.21 | 4.32) and stay behind "route_block" = 512 for A/B runs only.
+struct RouteGeom {
+  int block, spl;
+};
+// Table lookups (edges that are not arithmetic) take more registers than the arithmetic digitize: 24 there.
+static RouteGeom route_geom_for(const xhist_plan* p, int sdt, int wdt /* -1: counts */, int D, int scan) {
+  RouteGeom g;
+  g.block = p->route_block ? p->route_block : 1024;
+  const int bytes = D * (sdt == XHIST_F64 ? 8 : 4) + (wdt == XHIST_F64 ? 8 : wdt == XHIST_F32 ? 4 : 0);
+  g.spl = p->route_spl ? p->route_spl : (g.block == 1024 && 2 * bytes <= (scan == kScanArith ? 32 : 24) && !(sdt == XHIST_F64 && wdt == XHIST_F64) ? 8 : 4);
+  if (g.block != 1024) g.spl = 4;
+  return g;
+}
 
 //
 // Packed records (float64 weights).  A record is normally a 16-bit bin code plus the float64 weight: 10 bytes in two streams.
@@ -211,14 +245,14 @@ static int route_block_for(const xhist_plan* p, bool weighted) { return p->route
 // a few time steps of a big joint histogram cost one launch pair instead of one per row; rows * parts_per_row <= 128.
 static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, const xhist_array* weights, int64_t n_cols, void* out,
                                      hipStream_t stream, int sdt, int wdt, int scan, bool use_f32, const TableSet& tset, int shift,
-                                     int parts_per_row, int profile, LaunchRecord& rec, bool first, bool last, int rows = 1) {
+                                     int parts_per_row, int profile, LaunchRecord& rec, bool first, bool last, RouteGeom geom, int rows = 1) {
   const int D = p->n_dims;
   const bool weighted = weights != nullptr;
   const int n_parts = parts_per_row * rows;
   const int64_t n_total = n_cols * rows;
   if (n_total >= ((int64_t)1 << 40) || n_cols < 4 || n_parts > 128) return XHIST_ERR_UNSUPPORTED;
-  const int block = route_block_for(p, weighted);
-  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan, rows > 1, block);
+  const int block = geom.block, spl = geom.spl;
+  kernel_fn_route k_route = route_kernel(sdt, wdt, D, scan, rows > 1, block, spl);
   if (!k_route) return XHIST_ERR_UNSUPPORTED;
   bool pack = weighted && wdt == XHIST_F64 && p->records48_pref >= 0 && !exact_records_env();
   if (!p->mixed_hint) {  // pinned host words the GPU writes: [0] a call met weights of both signs, [1] a chunk pool ran dry
@@ -230,11 +264,11 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     }
   }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
-  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block) : nullptr;
+  kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
-  const int tile = route_tile(block);
-  const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile);
+  const int tile = route_tile(block, spl);
+  const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile, block);
   const bool rec_f32 = wdt == XHIST_F32;
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
@@ -922,14 +956,33 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       int r_scan = scan;
       const TableSet* r_tset = tset;
       bool r_f32 = use_f32;
-      const int r_tile = route_tile(route_block_for(p, weighted));
-      const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, r_tile), lds_notab = part_route_lds(0, (int)n_parts, weighted, r_tile);
-      if (p->arith && arith_pref >= 0 && scan != kScanArith && n_parts <= 128 &&
-          (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab)) {
-        r_scan = kScanArith;
-        r_tset = &p->ts[0][0];
-        r_f32 = false;
+      const bool can_arith = p->arith && arith_pref >= 0 && n_parts <= 128;
+      const int w_tag = weighted ? wdt : -1;
+      // geometry first: the long tile with the arithmetic digitize where the edges allow it, else with the tables if both
+      // fit the LDS, else the short tile
+      RouteGeom geom = route_geom_for(p, sdt, w_tag, D, can_arith ? kScanArith : scan);
+      if (geom.spl == 8 && (can_arith || scan == kScanArith)) {
+        if (scan != kScanArith) {
+          r_scan = kScanArith;
+          r_tset = &p->ts[0][0];
+          r_f32 = false;
+        }
+      } else {
+        if (geom.spl == 8 && !p->route_spl &&
+            part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, route_tile(geom.block, 8), geom.block) > p->lds_max)
+          geom.spl = 4;
+        if (can_arith && scan != kScanArith) {
+          const int t4 = route_tile(geom.block, geom.spl);
+          const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, t4, geom.block),
+                       lds_notab = part_route_lds(0, (int)n_parts, weighted, t4, geom.block);
+          if (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab) {
+            r_scan = kScanArith;
+            r_tset = &p->ts[0][0];
+            r_f32 = false;
+          }
+        }
       }
+      const int r_block = geom.block, r_tile = route_tile(r_block, geom.spl);
       // rows that follow each other at one stride go through the routing pass several at a time
       // (32 x 3*10^7 float32 pairs + weights, 300 x 300 bins: 8.05 -> 6.02 ms; 8 x 6*10^7 float64, 512 x 512: 5.17 -> 4.18;
       // rows of 5*10^8 samples gain nothing — 8.63 -> 8.95 ms with 128 partitions in flight — and stay one per pass)
@@ -941,7 +994,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       while (uniform_rows && r < n_rows && rc == XHIST_OK) {
         int rows = (int)std::min<int64_t>(n_rows - r, 128 / n_parts);
         const size_t tab_bytes = r_scan == kScanArith ? 0 : (size_t)r_tset->words * 8;
-        while (rows > 1 && part_route_lds(tab_bytes, rows * (int)n_parts, weighted, r_tile) > p->lds_max) --rows;
+        while (rows > 1 && part_route_lds(tab_bytes, rows * (int)n_parts, weighted, r_tile, r_block) > p->lds_max) --rows;
         if (rows < 2) break;  // (one row at a time below)
         xhist_array row_s[XHIST_MAX_DIMS], row_w;
         for (int d = 0; d < D; ++d) {
@@ -954,7 +1007,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         }
         void* row_out = static_cast<char*>(out) + (size_t)r * p->n_bins * 8;
         rc = execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan, r_f32, *r_tset, shift,
-                                       (int)n_parts, profile, rec, r == 0, r + rows == n_rows, rows);
+                                       (int)n_parts, profile, rec, r == 0, r + rows == n_rows, geom, rows);
         if (rc == XHIST_ERR_UNSUPPORTED) {
           if (r > 0) rc = fail(XHIST_ERR_HIP, "internal: partitioned mode refused rows from %lld after accepting row 0", (long long)r);
           else rc = XHIST_OK;  // nothing launched: row by row below
@@ -978,7 +1031,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         // one routing pass (44 B per C5 sample) where it applies, else count + prefix + scatter (52.5 B); the
         // choice depends on the plan and the dtypes only, so every row of a call takes the same route
         rc = fused_pref >= 0 ? execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan,
-                                                         r_f32, *r_tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1)
+                                                         r_f32, *r_tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1, geom)
                              : XHIST_ERR_UNSUPPORTED;
         if (rc == XHIST_ERR_UNSUPPORTED)
           rc = execute_partitioned(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream,

@@ -178,19 +178,19 @@ constexpr int kWdtPacked48 = 0x100 | XHIST_F64;  // float64 weights, packed 8-by
 
 // (several rows per pass: uniform-style edges only — tables with one edge per bucket, or arithmetic — the shapes a census over
 // time steps has; other edges run one row per pass)
-template <typename ST, typename WT, int BLOCK>
+template <typename ST, typename WT, int BLOCK, int SPL = 4>
 static kernel_fn_route route_pick_ds(int D, int scan, bool multi) {
 #define XH_ROUTE_CASE(DD)                                                        \
   case DD:                                                                       \
     if (multi) {                                                                 \
-      if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, true, BLOCK>;    \
-      if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, true, BLOCK>; \
+      if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, true, BLOCK, SPL>;    \
+      if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, true, BLOCK, SPL>; \
       return nullptr;                                                            \
     }                                                                            \
-    if (scan == 0) return (kernel_fn_route)part_route<ST, WT, DD, 0, false, BLOCK>;            \
-    if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, false, BLOCK>;            \
-    if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2, false, BLOCK>;            \
-    if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, false, BLOCK>; \
+    if (scan == 0) return (kernel_fn_route)part_route<ST, WT, DD, 0, false, BLOCK, SPL>;            \
+    if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, false, BLOCK, SPL>;            \
+    if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2, false, BLOCK, SPL>;            \
+    if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, false, BLOCK, SPL>; \
     return nullptr;
   switch (D) {
     XH_ROUTE_CASE(1)
@@ -201,12 +201,12 @@ static kernel_fn_route route_pick_ds(int D, int scan, bool multi) {
 #undef XH_ROUTE_CASE
 }
 
-template <typename ST, int BLOCK>
+template <typename ST, int BLOCK, int SPL = 4>
 static kernel_fn_route route_pick(int wdt, int D, int scan, bool multi) {
-  if (wdt == -1) return route_pick_ds<ST, NoWeight, BLOCK>(D, scan, multi);
-  if (wdt == XHIST_F64) return route_pick_ds<ST, double, BLOCK>(D, scan, multi);
-  if (wdt == XHIST_F32) return route_pick_ds<ST, float, BLOCK>(D, scan, multi);
-  if (wdt == kWdtPacked48) return route_pick_ds<ST, Packed48, BLOCK>(D, scan, multi);
+  if (wdt == -1) return route_pick_ds<ST, NoWeight, BLOCK, SPL>(D, scan, multi);
+  if (wdt == XHIST_F64) return route_pick_ds<ST, double, BLOCK, SPL>(D, scan, multi);
+  if (wdt == XHIST_F32) return route_pick_ds<ST, float, BLOCK, SPL>(D, scan, multi);
+  if (wdt == kWdtPacked48) return route_pick_ds<ST, Packed48, BLOCK, SPL>(D, scan, multi);
   return nullptr;
 }
 
@@ -222,6 +222,6 @@ kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
 // (xhist_route_{f64,f32}_b{1024,512}.hip: one translation unit per sample type and workgroup size)
 #define XH_ROUTE_TU(ST, B) kernel_fn_route xhist_pick_route_##ST##_b##B(int wdt, int D, int scan, bool multi);
-XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 512)
-XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 512)
+XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 512) XH_ROUTE_TU(f64, 1024s8)
+XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 512) XH_ROUTE_TU(f32, 1024s8)
 #undef XH_ROUTE_TU

@@ -47,18 +47,17 @@ constexpr uint32_t kChunkFillMask = 0xfffffu;  // cmeta[id] = partition << 20 | 
 // to a sizing bug or a shrunken pool ("route_pool_pct"), not a mode — but it keeps the library's "never aborts" promise
 // where a trap would poison the HIP context of a long-lived worker (VERDICT r2 "weak" #5).
 constexpr uint64_t kRouteDirect = ~(uint64_t)0;
-// workgroup and tile of the routing pass: 4 samples per lane.  8 per lane — the tile of part_scatter — needs more
-// registers than a 1024-thread workgroup has next to the sort's state for float64 samples (what spills is reloaded inside
-// the loop, and every reload waits for the prefetch in flight, see below), and is no faster for float32 ones, where it
-// fits (5 x 10^8 float32 pairs + weights, 1024 x 1024 bins: 3.39 ms against 3.00)
-// The workgroup size is a template parameter (1024 / 512 threads, tile = 4 samples per lane): ONE 1024-thread
-// workgroup per CU runs its phases — digitize, rank, scan, sort, store — one after the other with the whole CU behind every
-// barrier, so the loads of a tile are in flight only while the tile before it is sorted and the memory pipe idles through
-// the arithmetic; two 512-thread workgroups per CU overlap one's loads and stores with the other's
-// arithmetic (VERDICT r2 "next" #1b).  Measured on C5 shards (profiles/r03_c5_blocks.txt): weighted, packed records
-// 3.43-3.48 ms (1024) -> 3.35-3.37 (2 x 512); three workgroups of 256 threads 3.51-3.55; unweighted 2.57 / 2.59-2.63 / 2.79.
+// Workgroup size and samples per lane and tile are template parameters (1024 / 512 threads; 4 / 8 samples): the host picks
+// them per dtype combination (route_geom_for in xhist_exec_device.hip.h holds the rule and the measurements).  In short:
+// the pass's mixed read/write traffic wants long bursts per workgroup, so 1024 threads x 8 samples wherever the tile's
+// samples and weights fit the registers next to the sort's state (counts; float32 weights; float32 samples), 1024 x 4
+// for float64 samples with float64 weights (8 per lane spill there: what spills is reloaded inside the loop, and every
+// reload waits for the prefetch in flight).  Round 2's 8-per-lane attempt (float32 pairs + weights 3.39 ms against 3.00)
+// predates the split weight loads and the arithmetic digitize; with them the same shape runs 2.64 against 2.92.
+// Two 512-thread workgroups per CU (VERDICT r2 "next" #1b) won 2-3 % while weights were loaded with the samples
+// (profiles/r03_c5_blocks.txt: 3.43-3.48 -> 3.35-3.37 ms; three of 256 threads 3.51-3.55) and lose 2-4 % since.
 constexpr int kRouteBlock = 1024;  // the largest workgroup (sizes the host-side worst cases)
-__host__ __device__ constexpr int route_tile(int block) { return 4 * block; }
+__host__ __device__ constexpr int route_tile(int block, int spl = 4) { return spl * block; }  // spl: samples per lane and tile (4 or 8)
 // chunks one workgroup can file in its LDS list (beyond: filed one by one, slowly)
 // (= the workgroup size.  1024 for every size was tried — shorter lists force bigger chunks, and every workgroup ends with one
 // to two batches of unused chunk ids, so 12 rows x 10^8 samples with 8192-record chunks size their pool at 19 GB for 7 GB of
@@ -125,8 +124,8 @@ __device__ __forceinline__ bool route_gate_closed(const RouteArgs& ra) {
 }
 
 __host__ __device__ constexpr int part_route_slots(int P, int tile) { return tile + 2 * (kRouteGrp - 1) * P + kRouteGrp; }
-__host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted, int tile) {
-  return ((table_bytes + 15) & ~(size_t)15) + (size_t)route_ctl(tile / 4) + (size_t)P * kRouteGrp * (weighted ? 12 : 4) +
+__host__ __device__ constexpr size_t part_route_lds(size_t table_bytes, int P, bool weighted, int tile, int block) {
+  return ((table_bytes + 15) & ~(size_t)15) + (size_t)route_ctl(block) + (size_t)P * kRouteGrp * (weighted ? 12 : 4) +
          (size_t)part_route_slots(P, tile) * (weighted ? 12 : 4) + 64;
 }
 
@@ -161,7 +160,7 @@ __device__ __forceinline__ uint32_t route_take_ids(uint32_t* a, uint32_t need) {
 // into load, wait, sort, store, one after the other (4.2 ms instead of 3.4 for a C5 shard).  Hence: everything
 // the partition owners keep from tile to tile (record cursors, chunk lists) lives in LDS, and chunk ids come
 // from an LDS-resident stock that one lane refills from the global pool a tile before it runs out.
-template <typename ST, typename WT, int D, int SCAN, bool MULTI = false, int BLOCK = kRouteBlock>
+template <typename ST, typename WT, int D, int SCAN, bool MULTI = false, int BLOCK = kRouteBlock, int SPL = 4>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) part_route(const Params p, const RouteArgs ra) {
   constexpr bool kWeighted = !__is_same(WT, NoWeight);
   constexpr bool PACK = __is_same(WT, Packed48);
@@ -171,7 +170,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   using RT = typename std::conditional<__is_same(WT, float), float, double>::type;  // record weights keep the caller's precision
   constexpr int RV = 16 / (int)sizeof(RT);
   typedef RT rvec __attribute__((ext_vector_type(RV)));
-  constexpr int kRouteTile = route_tile(BLOCK), kRouteListCap = route_list_cap(BLOCK), kRouteCtl = route_ctl(BLOCK);
+  constexpr int kRouteTile = route_tile(BLOCK, SPL), kRouteListCap = route_list_cap(BLOCK), kRouteCtl = route_ctl(BLOCK);
   constexpr int GRP = kRouteGrp, U = kRouteTile / (BLOCK * 4);  // 4-sample vectors per lane and tile
   constexpr uint32_t kGm = GRP - 1;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
