@@ -96,11 +96,13 @@ def one(seed):
     plan, override = None, None
     if rng.random() < 0.5:
         override = [("partition", 1), ("slices", 1), ("arith", 1), ("lanes", 1), ("lanes", -1), ("force_generic", 1), ("force_global", 1),
-                    ("lds_copies", 1), ("slices", -1), ("arith", -1), ("fused", -1), ("partition", 1)][int(rng.integers(0, 12))]
+                    ("lds_copies", 1), ("slices", -1), ("arith", -1), ("fused", -1), ("partition", 1),
+                    ("partition", 1, "route_spl", 8), ("partition", 1, "route_spl", 4), ("partition", 1, "route_block", 512)][int(rng.integers(0, 15))]
         try:
             dom, cedges, _ = core._compare_domain([a.dtype for a in args], edges)
             plan = core._get_plan(cedges, dom, 0)
-            plan.set_param(*override)
+            for i in range(0, len(override), 2):
+                plan.set_param(override[i], override[i + 1])
         except (NotImplementedError, TypeError):
             plan = None
     desc["override"] = override
@@ -111,7 +113,8 @@ def one(seed):
         return _compare(args, bins, w, axis, density, resident, two, conv, want, desc, rng)
     finally:
         if plan is not None:
-            plan.set_param(override[0], 0)
+            for i in range(0, len(override), 2):
+                plan.set_param(override[i], 0)
 
 
 def _compare(args, bins, w, axis, density, resident, two, conv, want, desc, rng):
