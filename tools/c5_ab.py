@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--wdtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--dims", type=int, default=2)
-    ap.add_argument("--edges", default="linspace", choices=["linspace", "jitter"], help="jitter: uneven edges (table lookups)")
+    ap.add_argument("--edges", default="linspace", choices=["linspace", "jitter", "random"],
+                    help="jitter: uneven edges (table lookups); random: sorted uniform draws, end points kept (BASELINE C3)")
     ap.add_argument("--rows", type=int, default=1, help="n is split into this many rows (one histogram per row)")
     ap.add_argument("--variants", default="route_block=1024;route_block=512;route_block=256")
     args = ap.parse_args()
@@ -63,6 +64,9 @@ def main():
     e = np.linspace(-4.0, 4.0, args.bins + 1)
     if args.edges == "jitter":
         e = np.sort(e + np.random.default_rng(5).uniform(-0.45, 0.45, e.size) * (e[1] - e[0]))
+    if args.edges == "random":
+        e = np.sort(np.random.default_rng(1).uniform(-4.0, 4.0, args.bins + 1))
+        e[0], e[-1] = -4.0, 4.0
     edges = [e] * args.dims
     out = torch.zeros((rows,) + (args.bins,) * args.dims, dtype=torch.float64 if w is not None else torch.int64, device=dev)
     xv = [_native.make_view(a.data_ptr(), tag, cols, 1) for a in xs]
