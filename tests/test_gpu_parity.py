@@ -1156,6 +1156,34 @@ def test_partitioned_mode_routing_geometries(xh, dims, dtype, weights, edges_kin
     assert_hist_equal(got, want, w is not None)
 
 
+@pytest.mark.parametrize("min_parts", [0, 1, 5, 64, 128])
+@pytest.mark.parametrize("rows", [1, 3, 12])
+@pytest.mark.parametrize("weights", ["none", "f32", "f64"])
+def test_partitioned_mode_finer_partitions(xh, weights, rows, min_parts):
+    """A histogram of a few LDS capacities is cut into 16+ partitions of 2^11 ... 2^15 bins instead of the two or three
+    that its size asks for (part_geometry, xhist_exec_device.hip.h: a handful of partitions serialises the routing pass's
+    rank counters): every partition size gives the reference's result, with one row and with rows sharing a pass."""
+    rng = np.random.default_rng(rows * 10 + len(weights))
+    n = 150_001
+    edges = [np.linspace(-3, 3, 541), np.linspace(-2, 2, 261) ** 3]
+    x, y = rng.standard_normal((rows, n)), rng.standard_normal((rows, n)) * 2.0
+    x[:, ::311] = np.nan
+    w = {"none": None, "f32": rng.uniform(0, 1, (rows, n)).astype(np.float32), "f64": rng.uniform(0, 1, (rows, n))}[weights]
+    want = onp.bincount_rows([x, y], edges, w)
+    got, desc = _run(xh, [x, y], edges, w, True, partition=1, min_parts=min_parts)
+    assert "hist=partitioned" in desc, desc
+    per_part = int(desc.split("bins_per_part=")[1].split()[0])
+    n_bins = 540 * 260
+    if min_parts == 1:
+        assert per_part == (1 << 14 if w is not None else 1 << 15), desc
+    elif min_parts == 128:
+        # never finer than 2^11 bins per partition; rows that fit one pass with 8+ partitions each are left in it
+        assert per_part == 1 << 11 or rows > 1, desc
+    elif min_parts == 0 and weights != "f64":
+        assert -(-n_bins // per_part) >= 8 and (rows > 1 or per_part < (1 << 14 if w is not None else 1 << 15)), desc
+    assert_hist_equal(got, want, w is not None)
+
+
 @pytest.mark.parametrize("weights", ["none", "one_sign", "both_signs", "f32"])
 @pytest.mark.parametrize("pct", [2, 10, 40])
 def test_partitioned_mode_chunk_pool_runs_dry(xh, weights, pct):
@@ -1833,6 +1861,7 @@ def test_one_pass_routing_with_few_partitions_and_many_tiles(xh):
     edges = [np.linspace(-3, 3, 48), np.linspace(-3, 3, 18) ** 3 / 9.0, np.linspace(-3, 3, 101)]
     plan = xh._get_plan(edges, _native.CMP_F64, 0)
     plan.set_param("partition", 1)  # (left alone, 12 B/sample and 2 bin slices would win the cost model)
+    plan.set_param("min_parts", 1)  # (and the bins would be cut into 16+ partitions)
     try:
         h, _ = xh.histogram(*a, bins=edges)
         assert "route=fused" in plan.describe() and "parts=3" in plan.describe(), plan.describe()
@@ -1842,6 +1871,7 @@ def test_one_pass_routing_with_few_partitions_and_many_tiles(xh):
     finally:
         plan.set_param("fused", 0)
         plan.set_param("partition", 0)
+        plan.set_param("min_parts", 0)
     assert torch.equal(h, h3)
     inside = torch.ones(n, dtype=torch.bool, device=dev)
     for x, e in zip(a, edges):

@@ -893,12 +893,39 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   if (!fast) vec = 1;
   const DimTable* dims = tset->dim;
 
+  // ---- partitions of the partitioned mode (below; the slice rule prices it) ---------------------------
+  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS per partition, unless that leaves only a handful:
+  // A handful of partitions is slower than a few dozen: the routing pass ranks a tile's records with ONE returning LDS
+  // counter per partition, and a tile's 8192 adds on two or three addresses serialise (a tile lies in one row, so rows
+  // that share a pass do not help).  5*10^8 samples, ms: float32 pairs + weights 160 x 160 bins, 2 partitions -> 13:
+  // 3.04 -> 2.32; 200 x 200, 3 -> 20: 2.82 -> 2.35; float32 pair counts 300 x 300, 3 -> 22: 2.75 -> 1.58; 400 x 400,
+  // 5 -> 20: 2.33 -> 1.60; float64 pair counts 300 x 300 2.78 -> 2.36; 10^5 bins 1-D, 4 -> 25: 2.65 -> 1.53; 12 rows x
+  // 200 x 200 float32 weighted, 3 -> 10 per row: 2.89 -> 2.43 (profiles/r03_t_few_partitions.txt).  So the bins are cut
+  // finer — down to 2^11 per partition — until a row has 16 partitions ("min_parts" overrides).  float64 samples with
+  // float64 weights, whose tiles are half as long, gain nothing (4.10 -> 4.06, 12 rows 4.09 -> 4.34) and keep the big ones.
+  auto part_geometry = [&](int& shift, int64_t& n_parts) {
+    shift = weighted ? 14 : 15;
+    n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
+    if (weighted && sdt == XHIST_F64 && wdt == XHIST_F64 && !p->min_parts) return;
+    const bool rows_share = n_rows > 1 && n_cols < ((int64_t)1 << 27);  // (uniform_rows below: several rows per pass)
+    const int64_t want_parts = p->min_parts ? p->min_parts : 16;
+    while (shift > 11 && n_parts < want_parts) {
+      const int64_t finer = (p->n_bins + ((int64_t)1 << (shift - 1)) - 1) >> (shift - 1);
+      // rows that fit ONE pass with 8+ partitions each stay in one pass (a pass costs ~0.1 ms beyond its traffic)
+      if (rows_share && n_parts >= 8 && n_rows * n_parts <= 128 && n_rows * finer > 128) break;
+      --shift;
+      n_parts = finer;
+    }
+  };
+
   // ---- a few times the LDS capacity: bin slices ---------------------------------------------------
   // S launches, each streaming all samples and keeping 1/S of the bins in LDS (hist_fast<SLICED>),
-  // cost S x the streaming time at ~6.5 TB/s; the partitioned mode below moves B + 8 + 2 x record
-  // bytes per sample at 3.7 (row by row) to 5 TB/s and needs a few long rows: slices while
-  // 0.65 S B <= B + 8 + 2 x record bytes.  200 x 200 weighted bins of f32 pairs:
-  // 9.3 ms partitioned -> 3 slices; 300 x 300 counts: 8.3 ms -> 2 slices of packed uint16 counters.
+  // cost S x the streaming time; the partitioned mode below moves B + 2 x record bytes per sample once and needs a few
+  // long rows.  Round 3, 5*10^8 samples, slices | partitioned ms (profiles/r03_t_few_partitions.txt): float32 pairs +
+  // float32 weights S = 2: 1.80 | 2.32, S = 3: 2.67 | 2.35, S = 4: 3.53 | 2.21; float64 pairs + float64 weights S = 2:
+  // 3.47 | 4.03, S = 3: 5.21 | 4.06; float32 pair counts (packed uint16 slices) S = 2: 1.73 | 1.58, S = 3: 2.62 | 1.60;
+  // float64 pair counts S = 2: 2.43 | 2.36, S = 3: 3.69 | 2.38.  (Round 1's rule — written when the partitioned mode took
+  // three passes, 9.3 ms for 200 x 200 weighted bins — kept slices up to S = 3-4.)
   int n_slices = 1;
   int64_t slice_bins = p->n_bins;
   if (fast && float_samples && hist == kHistGlobal && !force_global && !two && slices_pref >= 0 && p->n_bins < ((int64_t)1 << 24) &&
@@ -910,10 +937,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     for (int d = 0; d < D; ++d) B += dtype_size(samples[d].dtype);
     if (weighted) B += dtype_size(weights->dtype);
     const int64_t rec = 2 + (weighted ? (wdt == XHIST_F32 ? 4 : 8) : 0);  // a record: uint16 code + the weight in its own precision
-    const int part_shift = weighted ? 14 : 15;
-    const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) &&
-                         ((p->n_bins + ((int64_t)1 << part_shift) - 1) >> part_shift) <= kPartMaxParts;
-    bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? 13 * S * B <= 20 * (B + 8 + 2 * rec) : S <= 16));
+    int part_shift = 0;
+    int64_t parts_per_row = 0;
+    part_geometry(part_shift, parts_per_row);
+    const bool part_ok = partition >= 0 && n_rows <= 64 && n_cols >= ((int64_t)1 << 22) && parts_per_row <= kPartMaxParts;
+    // per sample: a slice pass streams B bytes at ~6.5 TB/s (packed uint16 counters: no faster than 5.7 x 10^11 samples
+    // a second); the partitioned mode moves B + 2 x record bytes at ~4.7 TB/s and no faster than 3.3 x 10^11 samples a second
+    const double per_slice = std::max((double)B / 6.5e12, weighted ? 0.0 : 1.0 / 5.7e11);
+    const double per_part = std::max(((double)B + 2.0 * (double)(weighted ? std::min<int64_t>(rec, 8) : rec)) / 4.7e12, 1.0 / 3.3e11);
+    // (+ ~0.1 ms per routing / adding-up pass: rows share a pass while rows x partitions <= 128)
+    const double n_all = (double)n_rows * (double)n_cols;
+    const int64_t rows_per_pass = (n_rows > 1 && n_cols < ((int64_t)1 << 27) && parts_per_row * 2 <= 128) ? std::max<int64_t>(1, 128 / parts_per_row) : 1;
+    const double t_part = n_all * per_part + (double)((n_rows + rows_per_pass - 1) / rows_per_pass) * 1.0e-4;
+    bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? (double)S * n_all * per_slice <= t_part : S <= 16));
     if (choose && slices_pref == 0) {
       // few samples: S launches cost S x ~13 us before they stream anything, memory-side atomics 2.4-2.7 x 10^10
       // per second (10^5 samples, 256 x 256 weighted bins: 4 slices 54 us, global atomics 13 us)
@@ -942,8 +978,9 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // ---- histograms beyond LDS: partitioned multi-pass instead of memory-side atomics ----------
   // (a few long rows — e.g. one joint histogram per time step — run it row by row)
   if (fast && float_samples && hist == kHistGlobal && !force_global && partition >= 0 && n_rows <= 64 && !two && n_slices == 1) {
-    const int shift = weighted ? 14 : 15;  // 2^14 float64 or 2^15 uint32 bins = 128 KiB of LDS
-    const int64_t n_parts = (p->n_bins + ((int64_t)1 << shift) - 1) >> shift;
+    int shift = 0;
+    int64_t n_parts = 0;
+    part_geometry(shift, n_parts);
     const bool big_enough = n_cols >= ((int64_t)1 << 22) || (partition > 0 && n_cols >= 4);  // part_scatter reads whole weight quads
     if (n_parts <= kPartMaxParts && big_enough && (size_t)(1u << shift) * (weighted ? 8 : 4) + 1024 <= lds_cap) {
       if (!accumulate)

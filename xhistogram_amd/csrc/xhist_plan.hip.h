@@ -379,6 +379,9 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
   } else if (!strcmp(key, "route_spl")) {
     if (value != 0 && value != 4 && value != 8) return fail(XHIST_ERR_INVALID, "route_spl must be 0 (auto), 4 or 8");
     p->route_spl = (int)value;
+  } else if (!strcmp(key, "min_parts")) {
+    if (value < 0 || value > 128) return fail(XHIST_ERR_INVALID, "min_parts must be in [0, 128]");
+    p->min_parts = (int)value;
   } else if (!strcmp(key, "route_pool_pct")) {
     if (value < 0 || value > 100) return fail(XHIST_ERR_INVALID, "route_pool_pct must be in [0, 100]");
     p->route_pool_pct = (int)value;
