@@ -475,6 +475,62 @@ def test_leading_axis_reduction_large_device_view(xh):
 
 
 # ---------------------------------------------------------------------------------------------
+# dense short rows streamed flat (hist_flat_rows)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(5000, 365), (4097, 20), (9000, 1), (4097, 3), (7777, 64), (5001, 255), (5003, 256), (4099, 800),
+                                   (6000, 100), (4096, 127)])
+@pytest.mark.parametrize("edges_kind", ["linspace", "uneven", "many"])
+def test_dense_short_rows_streamed_flat(xh, shape, dtype, edges_kind):
+    """Many dense short rows of one unweighted input (histogram over the last axis of (time x lat, lon), say) are streamed as
+    ONE contiguous array, a sample's row being its position divided by the row length (hist_flat_rows, xhist_lanes.hip.h):
+    row lengths around the vector width and the copy thresholds, a row count that is no multiple of the rows per workgroup,
+    an array whose size is no multiple of the 16-byte vector, NaN / out-of-range / right-edge samples."""
+    rng = np.random.default_rng(shape[1] + len(edges_kind))
+    edges = {"linspace": np.linspace(-3, 3, 51), "uneven": np.sort(rng.uniform(-3, 3, 38)), "many": np.linspace(-4, 4, 401)}[edges_kind]
+    x = rng.standard_normal(shape).astype(dtype)
+    x[::7, ::5] = np.nan
+    x[3, :] = edges[-1] if float(dtype(edges[-1])) == edges[-1] else 0.0
+    x[5, :] = 100.0
+    x[-1, :] = -0.5
+    want = onp.bincount_rows([x], [edges], None)
+    got, desc = _run(xh, [x], [edges], None, True)
+    assert "family=flat_rows" in desc, desc
+    np.testing.assert_array_equal(got, want)
+    got, desc = _run(xh, [x], [edges], None, True, flat_rows=-1)  # (and the kernels it replaced)
+    assert "family=flat_rows" not in desc, desc
+    np.testing.assert_array_equal(got, want)
+
+
+def test_dense_short_rows_flat_needs_alignment_and_falls_back(xh):
+    """the flat kernel reads aligned 16-byte vectors: a view that starts 4 bytes into an allocation takes the older kernels"""
+    rng = np.random.default_rng(8)
+    m, c = 5000, 100
+    edges = np.linspace(-3, 3, 51)
+    flat = torch.as_tensor(rng.standard_normal(m * c + 1).astype(np.float32)).cuda()
+    x = flat[1:].view(m, c)
+    assert x.data_ptr() % 16 == 4
+    got, _ = xh.histogram(x, bins=edges, axis=1)
+    plan = _plan_for(xh, [x], [edges])
+    assert "family=flat_rows" not in plan.describe(), plan.describe()
+    np.testing.assert_array_equal(got.cpu().numpy(), onp.bincount_rows([x.cpu().numpy()], [edges], None))
+    got, _ = xh.histogram(flat[4:4 + (m - 1) * c].view(m - 1, c), bins=edges, axis=1)  # 16 bytes in: aligned again
+    assert "family=flat_rows" in plan.describe(), plan.describe()
+    np.testing.assert_array_equal(got.cpu().numpy(), onp.bincount_rows([flat[4:4 + (m - 1) * c].view(m - 1, c).cpu().numpy()], [edges], None))
+
+
+def test_dense_short_rows_flat_any_length_when_forced(xh):
+    """"flat_rows" = 1: any row length below 65536 (the multiply-high row index, several iterations per row)"""
+    rng = np.random.default_rng(9)
+    edges = np.linspace(-3, 3, 51)
+    for shape in [(4096, 5000), (4100, 1023), (5000, 16385)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        got, desc = _run(xh, [x], [edges], None, True, flat_rows=1)
+        assert "family=flat_rows" in desc, desc
+        np.testing.assert_array_equal(got, onp.bincount_rows([x], [edges], None))
+
+
+# ---------------------------------------------------------------------------------------------
 # partitioned multi-pass mode (histograms beyond LDS, BASELINE C5)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("weighted", [False, True])
@@ -1334,7 +1390,16 @@ def test_lanes_many_short_rows(xh, shape):
     want, _ = onp.histogram(x, bins=edges, axis=1)
     got, _ = xh.histogram(_dev(x), bins=edges, axis=1)
     desc = _describe_last(xh, [_dev(x[:1])], [edges])
-    assert "family=lanes" in desc and "transpose=fused" in desc, desc  # one pass: load, turn in LDS, count
+    assert "family=flat_rows" in desc, desc  # dense rows: streamed as one contiguous array
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    plan = _plan_for(xh, [_dev(x[:1])], [edges])
+    plan.set_param("flat_rows", -1)
+    try:
+        got, _ = xh.histogram(_dev(x), bins=edges, axis=1)
+        desc = plan.describe()
+    finally:
+        plan.set_param("flat_rows", 0)
+    assert "family=lanes" in desc and "transpose=fused" in desc, desc  # (its predecessor) one pass: load, turn in LDS, count
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     xf = x.astype(np.float32)[:, ::-1].copy()
     xf[::7, 0] = np.nan

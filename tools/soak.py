@@ -40,6 +40,9 @@ def one(seed):
     shape = tuple(int(rng.integers(1, 7)) for _ in range(ndim - 1)) + (int(rng.integers(1, big_cols if big else 3000)),)
     if rng.random() < 0.3:
         shape = tuple(rng.permutation(shape))
+    if rng.random() < 0.08:  # many short rows (the flat / row-per-lane kernels)
+        shape = (int(rng.integers(4096, 12000)), int(rng.integers(1, 1200)))
+        ndim = 2
     d = int(rng.choice([1, 1, 1, 2, 2, 3]))
     dtype = rng.choice(["f64", "f32", "i32", "i64", "u8", "f16"])
     # a third of the joint histograms mix dtypes (the mixed-dtype vector kernels / the generic family)

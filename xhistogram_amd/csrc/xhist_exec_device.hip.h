@@ -446,11 +446,25 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const TableSet& tset = *picked;
   const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
-  if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   bool transpose = false;
   if (small && !(all_natural && samples[0].row_stride == 1)) return XHIST_ERR_UNSUPPORTED;
+  // dense short rows of one unweighted float input: streamed flat (hist_flat_rows)
+  // (3.65 x 10^8 float32 samples, 50 bins, ms per call, fused turn-around kernel / row streaming | flat: rows of 20 2.25 | 1.83;
+  // 64 1.00 | 0.72; 100 1.07 | 0.66; 200 0.84 | 0.46; 365 0.79 | 0.41; 512 0.59 | 0.42; 720 0.46 | 0.43; 1024 0.33 | 0.38;
+  // 2048 0.28 | 0.37: profiles/r03_f_flat_rows.txt)
+  constexpr int64_t kFlatMaxCols = 800;
+  const uint32_t flat_nbp = ((uint32_t)p->n_bins + 1u) & ~1u;
+  const int flat_k_log2 = n_cols >= 256 ? 2 : (n_cols >= 128 ? 1 : 0);
+  const bool flat_ok = D == 1 && !weighted && !small && n_cols >= 1 && n_cols < 65536 && samples[0].col_stride == 1 &&
+                       samples[0].row_stride == n_cols && samples[0].inner_rows == 0 && (sdt != XHIST_F32 || use_f32) &&
+                       ((uintptr_t)samples[0].data & 15u) == 0 && ((size_t)flat_nbp << flat_k_log2) * 2 <= 4096;
+  const bool use_flat = flat_ok && !prefer && p->flat_rows >= 0 && n_rows >= 4096 && n_cols <= (p->flat_rows > 0 ? 65535 : kFlatMaxCols) &&
+                        !(all_natural && samples[0].row_stride == 1);
+  if (lds_bytes > p->lds_max && !use_flat) return XHIST_ERR_UNSUPPORTED;  // (the lane-private histograms of hist_lanes)
   if (all_natural && (samples[0].row_stride == 1 || prefer)) {
     // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
+  } else if (use_flat) {
+    transpose = true;  // (dense short rows: hist_flat_rows below)
   } else if (all_rowmajor && (prefer || (n_rows >= 4096 && n_cols <= ((D == 1 && !weighted) ? 400 : 80)))) {
     // many short rows.  Measured crossovers with the row-streaming kernels (64-thread workgroups,
     // few LDS copies, plain-store flush; 3.65 x 10^8 f32 samples): ~400 columns for the fused kernel
@@ -467,6 +481,46 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
 
   const bool fused_ok = D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0;
   if (transpose && grouped_any && !fused_ok) return XHIST_ERR_UNSUPPORTED;  // transpose_2d takes plain row strides only
+  if (use_flat) {
+    kernel_fn_flat ff = flat_rows_kernel(sdt, scan);
+    // R rows per workgroup: ~16 Ki samples, at most 24 KiB of counters, and enough workgroups for every CU
+    int64_t R = std::min<int64_t>(16384 / n_cols, (int64_t)(24576 / (((size_t)flat_nbp << flat_k_log2) * 2)));
+    R = std::min<int64_t>(R, std::max<int64_t>(1, n_rows / ((int64_t)p->cus * 8)));
+    R = std::max<int64_t>(1, std::min<int64_t>(R, 1024));
+    const size_t lds_flat = table_bytes + ((size_t)R * ((size_t)flat_nbp << flat_k_log2) / 2 + 32) * 4;
+    const int64_t row_blocks = (n_rows + R - 1) / R;
+    if (ff && lds_flat <= p->lds_max && row_blocks <= 2147483647LL) {
+      Params kp;
+      memset(&kp, 0, sizeof kp);
+      kp.s_ptr[0] = samples[0].data;
+      kp.s_rs[0] = samples[0].row_stride;
+      kp.s_cs[0] = 1;
+      kp.s_dt[0] = sdt;
+      kp.dim[0] = tset.dim[0];
+      kp.n_dims = 1;
+      kp.tables = tset.blob;
+      kp.table_words = tset.words;
+      kp.tables_in_lds = 1;
+      kp.n_rows = n_rows;
+      kp.n_cols = n_cols;
+      kp.n_bins = p->n_bins;
+      kp.out = out;
+      const int direct = accumulate ? 0 : 1;
+      const uint64_t magic = (((uint64_t)1 << 40) / (uint64_t)n_cols) + 1u;
+      LaunchRecord rec(p, stream);
+      if (int rrc = rec.begin(profile)) return rrc;
+      if (lds_flat > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flat));
+      hipLaunchKernelGGL(ff, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_flat, stream, kp, (int32_t)direct, (int32_t)R, (int32_t)flat_k_log2,
+                         magic, (int64_t)(n_rows * n_cols));
+      HIPC(hipGetLastError());
+      char desc[320];
+      snprintf(desc, sizeof desc,
+               "family=flat_rows hist=lds16 rows_per_wg=%lld copies=%d direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=0 D=1 cmp=%s",
+               (long long)R, 1 << flat_k_log2, direct, kLaneBlock, (long long)row_blocks, lds_flat, scan, use_f32 ? "f32thr" : "f64");
+      return rec.end(desc);
+    }
+  }
+  if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
   if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {
     const int es = dtype_size(sdt);

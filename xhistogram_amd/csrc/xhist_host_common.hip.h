@@ -403,6 +403,7 @@ struct xhist_plan {
   uint32_t* mixed_hint = nullptr;  // pinned host words the GPU sets: [0] a call met weights of both signs, [1] a chunk pool ran dry (see execute_partitioned_fused)
   int route_block = 0;     // routing pass: workgroup size (0 auto; 512 / 1024)
   int route_spl = 0;       // routing pass: samples per lane and tile (0 auto; 4 / 8 — 8 only with 1024-thread workgroups, float64)
+  int flat_rows = 0;       // dense short rows streamed flat (hist_flat_rows): -1 off, 0 auto, 1 for any row length below 65536
   int min_parts = 0;       // partitioned mode: bins are cut finer until a pass has this many partitions (0 auto = 16; 1 = never)
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never

@@ -229,6 +229,85 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
   }
 }
 
+// Flat form for DENSE short rows (one input, unweighted, row stride == columns, fewer than 65536 columns): a workgroup
+// takes R consecutive rows — one contiguous piece of memory — and streams it with aligned 16-byte loads exactly like a long
+// row, whatever the row length; a sample's row is its position divided by the row length (one multiply-high: position *
+// ceil(2^40 / columns) >> 40, exact below 2^22 positions), and its counter lives in an LDS histogram [R rows][K copies][bins]
+// of uint16 counters, two per word (a row has < 65536 samples).  The lanes of a wavefront read neighbouring samples, i.e. one
+// or two rows at a time, so their adds would meet on a row's few bins: lane l uses copy l mod K (K = 4 for rows of 256+
+// samples).  The finished [R x bins] block is written once, with plain coalesced stores.  Against hist_lanes_rows1 (128-byte
+// pieces of 256 rows turned around in LDS, two barriers per piece): 10^6 rows of 365 float32, 50 bins 0.79 -> 0.41 ms per call
+// (1.86 GB in + out at 4.5 TB/s wall, ~5.2 by the kernel); the host keeps it to rows of up to 800 samples.
+template <typename ST, int SCAN>
+__global__ void __launch_bounds__(kLaneBlock) hist_flat_rows(const Params p, int32_t direct_store, int32_t R, int32_t k_log2, uint64_t magic,
+                                                             int64_t n_elems) {
+  constexpr int CMP = __is_same(ST, float) ? 2 : 0;
+  using CT = typename Dom<CMP>::T;
+  constexpr int VEC = 16 / (int)sizeof(ST), UNROLL = 4;
+  using svec = typename VecOf<ST, VEC>::type;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int rows_here = (int)min<int64_t>(R, p.n_rows - r0);
+  const uint64_t* tab = stage_tables(p);
+  const uint32_t nb = (uint32_t)p.n_bins, nbp = (nb + 1u) & ~1u;  // counters per (row, copy): even, so that pairs never straddle
+  uint32_t* hist = reinterpret_cast<uint32_t*>(xhist_smem + (size_t)p.table_words * 8);
+  const uint32_t words = ((uint32_t)R << k_log2) * (nbp >> 1);
+  for (uint32_t i = tid; i < words + 32u; i += kLaneBlock) hist[i] = 0u;  // (+ 32 trash words for dropped samples)
+  __syncthreads();
+  // dense rows: row r of the call starts at element r * n_cols of a 16-byte aligned array of n_elems elements
+  const ST* base = reinterpret_cast<const ST*>(p.s_ptr[0]);
+  const int64_t g0 = (p.row0 + r0) * p.n_cols, g1 = g0 + (int64_t)rows_here * p.n_cols;  // this workgroup's samples
+  const int64_t v_lo = g0 / VEC, v_hi = (g1 + VEC - 1) / VEC;                            // ... and the aligned vectors that hold them
+  const int64_t v_whole = n_elems / VEC;                                                 // vectors that lie wholly inside the array
+  const uint32_t n_here = (uint32_t)(g1 - g0);
+  const uint32_t copy_off = ((uint32_t)tid & ((1u << k_log2) - 1u)) * nbp;
+  const uint32_t trash = words + ((uint32_t)tid & 31u);
+  const int max_steps = max(1, p.dim[0].steps);
+  for (int64_t v0 = v_lo + tid; v0 < v_hi; v0 += kLaneBlock * UNROLL) {
+    svec xv[1][UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t vv = min(v0 + (int64_t)u * kLaneBlock, v_hi - 1);  // (past the workgroup's last vector: that one again, masked below)
+      if (vv < v_whole) {
+        xv[0][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(base) + vv);
+      } else {  // the array's ragged last vector (one lane of one workgroup): element by element
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[0][u][v] = vv * VEC + v < n_elems ? base[vv * VEC + v] : (ST)__builtin_nanf("");
+      }
+    }
+    uint32_t cnt[1][UNROLL][VEC];
+    count_le_tile<CMP, SCAN, 1, UNROLL, VEC>(xv, p, tab, max_steps, cnt);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t vv = v0 + (int64_t)u * kLaneBlock;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int64_t i64 = vv * VEC + v - g0;  // the sample's position among this workgroup's
+        const uint32_t i = (uint32_t)i64;
+        const int b = bin_from_count<CMP>((CT)xv[0][u][v], p.dim[0], cnt[0][u][v]);
+        const bool ok = (b >= 0) & (i64 >= 0) & (i64 < (int64_t)n_here);
+        const uint32_t row = (uint32_t)(((uint64_t)i * magic) >> 40);
+        const uint32_t idx = ((row << k_log2) * nbp) + copy_off + (uint32_t)b;
+        atomicAdd(hist + (ok ? (idx >> 1) : trash), ok ? (1u << ((idx & 1u) << 4)) : 0u);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(p.out) + r0 * nb;
+  const uint32_t total = (uint32_t)rows_here * nb;
+  const uint32_t K = 1u << k_log2;
+  for (uint32_t j = tid; j < total; j += kLaneBlock) {
+    const uint32_t row = j / nb, b = j - row * nb;
+    unsigned long long v = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+      const uint32_t idx = (row * K + k) * nbp + b;
+      v += (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu;
+    }
+    if (direct_store) out[j] = v;
+    else if (v) atomicAdd(out + j, v);
+  }
+}
+
 // [n_rows, n_cols] (row stride `rs` elements, unit column stride) -> dense [n_cols, n_rows].
 // 64 x 64 tiles through LDS (pitch 65): coalesced 256-byte reads along rows, writes along columns.
 template <typename T>

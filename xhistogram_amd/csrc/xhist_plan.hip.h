@@ -379,6 +379,9 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
   } else if (!strcmp(key, "route_spl")) {
     if (value != 0 && value != 4 && value != 8) return fail(XHIST_ERR_INVALID, "route_spl must be 0 (auto), 4 or 8");
     p->route_spl = (int)value;
+  } else if (!strcmp(key, "flat_rows")) {
+    if (value < -1 || value > 1) return fail(XHIST_ERR_INVALID, "flat_rows must be -1 (off), 0 (auto) or 1 (any row length below 65536)");
+    p->flat_rows = (int)value;
   } else if (!strcmp(key, "min_parts")) {
     if (value < 0 || value > 128) return fail(XHIST_ERR_INVALID, "min_parts must be in [0, 128]");
     p->min_parts = (int)value;
