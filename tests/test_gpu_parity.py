@@ -1382,6 +1382,36 @@ def test_lanes_leading_axis_reduction(xh, dt, weighted):
             assert_hist_equal(got.cpu().numpy(), want, True)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("weights", [None, "f32", "f64"])
+@pytest.mark.parametrize("shape,axis", [((300, 40, 50), 0), ((700, 33, 9), 0), ((130, 5000), 0), ((40, 90, 37), 1), ((2000, 3, 5), 0),
+                                        ((64, 20, 1030), (0, 1))])
+def test_lanes_leading_axis_with_more_bins_than_lane_private_columns_hold(xh, shape, axis, weights, dtype):
+    """Reductions over a leading axis give every ROW (a grid point) one LDS counter column; with a column per LANE the
+    histogram is n_bins x 257 words, which a joint histogram (20 x 23 bins) or a few hundred weighted bins do not fit — the
+    generic family took those (7.8 ms for (1825, 360, 720) float32 pairs over `time`).  Now the lane groups of a row share
+    its column and the workgroup takes fewer rows (execute_lanes: "shared")."""
+    rng = np.random.default_rng(len(shape) * 7 + shape[0])
+    xs = [rng.standard_normal(shape).astype(dtype) for _ in range(2)]
+    xs[0][::7] = np.nan
+    xs[1][..., ::5] = 100.0
+    w = None if weights is None else rng.uniform(0, 1, shape).astype(np.float32 if weights == "f32" else np.float64)
+    bins = [np.linspace(-3, 3, 21), np.sort(rng.uniform(-3, 3, 24))]
+    want = onp.histogram(*xs, bins=bins, axis=axis, weights=w)[0]
+    got, _ = xh.histogram(*[_dev(a) for a in xs], bins=bins, axis=axis, weights=None if w is None else _dev(w))
+    desc = _plan_for(xh, [_dev(a) for a in xs], bins).describe()
+    assert "family=lanes" in desc and "(shared)" in desc, desc
+    assert_hist_equal(got.cpu().numpy(), want, w is not None)
+    # one input, 300 weighted bins: 617 KB of lane-private float64 columns
+    e1 = np.linspace(-3, 3, 301)
+    w1 = rng.uniform(0, 1, shape)
+    want = onp.histogram(xs[0], bins=e1, axis=axis, weights=w1)[0]
+    got, _ = xh.histogram(_dev(xs[0]), bins=e1, axis=axis, weights=_dev(w1))
+    desc = _plan_for(xh, [_dev(xs[0])], [e1]).describe()
+    assert "family=lanes" in desc and "(shared)" in desc, desc
+    assert_hist_equal(got.cpu().numpy(), want, True)
+
+
 @pytest.mark.parametrize("shape", [(5000, 20), (4097, 365), (70_000, 7), (4096, 384), (300_001, 33)])
 def test_lanes_many_short_rows(xh, shape):
     rng = np.random.default_rng(52)

@@ -28,22 +28,27 @@ CASES = {
 }
 CASES.update({"rows_%d" % c: ((365_000_000 // c, c), 1) for c in (100, 128, 200, 256, 300, 400, 512, 720, 2048)})
 PARAMS = [kv.split("=") for kv in os.environ.get("XHIST_PROBE_PARAMS", "").split(",") if kv]  # e.g. flat_rows=-1
+WEIGHTED = os.environ.get("XHIST_PROBE_W", "") == "1"   # float32 weights
+NDIM = int(os.environ.get("XHIST_PROBE_D", "1"))       # inputs of the joint histogram (20 bins each when > 1)
 for name in (sys.argv[1:] or list(CASES)):
     shape, axis = CASES[name]
-    x = torch.empty(shape, dtype=torch.float32, device=dev).normal_(generator=g)
-    plan = core._get_plan([np.asarray(edges, dtype=np.float64)], _native.CMP_F64, 0)
+    xs = [torch.empty(shape, dtype=torch.float32, device=dev).normal_(generator=g) for _ in range(NDIM)]
+    w = torch.empty(shape, dtype=torch.float32, device=dev).uniform_(generator=g) if WEIGHTED else None
+    bins = edges if NDIM == 1 else [np.linspace(-4, 4, 21)] * NDIM
+    plan = core._get_plan([np.asarray(b, dtype=np.float64) for b in ([edges] if NDIM == 1 else bins)], _native.CMP_F64, 0)
     for k, v in PARAMS:
         plan.set_param(k, int(v))
-    core.histogram(x, bins=edges, axis=axis)
+    core.histogram(*xs, bins=bins, axis=axis, weights=w)
     torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         t0 = time.perf_counter()
-        h, _ = core.histogram(x, bins=edges, axis=axis)
+        h, _ = core.histogram(*xs, bins=bins, axis=axis, weights=w)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     out_b = h.numel() * 8
-    print("%-14s %8.3f ms  in %.2f GB out %.2f GB  -> %.2f TB/s of in+out   %s" % (name, sorted(ts)[2], x.numel() * 4 / 1e9, out_b / 1e9,
-          (x.numel() * 4 + out_b) / (sorted(ts)[2] * 1e-3) / 1e12, plan.describe()[:230]), flush=True)
-    del x, h
+    in_b = xs[0].numel() * 4 * (NDIM + (1 if WEIGHTED else 0))
+    print("%-14s %8.3f ms  in %.2f GB out %.2f GB  -> %.2f TB/s of in+out   %s" % (name, sorted(ts)[2], in_b / 1e9, out_b / 1e9,
+          (in_b + out_b) / (sorted(ts)[2] * 1e-3) / 1e12, plan.describe()[:230]), flush=True)
+    del xs, w, h
     torch.cuda.empty_cache()

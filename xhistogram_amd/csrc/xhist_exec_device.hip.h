@@ -460,7 +460,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
                        ((uintptr_t)samples[0].data & 15u) == 0 && ((size_t)flat_nbp << flat_k_log2) * 2 <= 4096;
   const bool use_flat = flat_ok && !prefer && p->flat_rows >= 0 && n_rows >= 4096 && n_cols <= (p->flat_rows > 0 ? 65535 : kFlatMaxCols) &&
                         !(all_natural && samples[0].row_stride == 1);
-  if (lds_bytes > p->lds_max && !use_flat) return XHIST_ERR_UNSUPPORTED;  // (the lane-private histograms of hist_lanes)
+  // (hist_lanes: a counter column per lane, or — shared by a row's lane groups — per row, for as few as 16 rows per workgroup)
+  const size_t lds_least = table_bytes + (size_t)p->n_bins * (weighted ? 17 * 8 : 9 * 4);
+  if (lds_least > p->lds_max && !use_flat) return XHIST_ERR_UNSUPPORTED;
   if (all_natural && (samples[0].row_stride == 1 || prefer)) {
     // rows are the contiguous direction: the row-streaming kernels cannot coalesce this at all
   } else if (use_flat) {
@@ -520,7 +522,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       return rec.end(desc);
     }
   }
-  if (lds_bytes > p->lds_max) return XHIST_ERR_UNSUPPORTED;
+  if (lds_least > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
   if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {
     const int es = dtype_size(sdt);
@@ -629,13 +631,29 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   // flight per row (10^5 x 1000 f32 over the leading axis: 0.25 -> 0.14 ms); short reductions pay for the
   // smaller blocks' zeroing and write-out instead (10^6 rows of 100: 0.17 -> 0.19 ms) and keep 256
   if (n_rows > 128 && n_cols >= 512) lane_rows = 64;
+  // Counter columns per lane need n_bins x 257 words.  Where that does not fit (joint histograms over a leading axis:
+  // 20 x 20 bins, (1825, 360, 720) float32 pairs over `time`: the generic family took 7.8 ms, now 1.0) or leaves one
+  // workgroup per CU (float64 sums of 50 bins: 103 KB; the same array with weights 1.49 -> 0.78 ms), the lane groups of a
+  // row share one column per row and the workgroup shrinks to as many rows as fit 40 KiB, 16 at least (joint counts: 64
+  // rows / 54 KB 1.36 ms, 32 rows / 28 KB 1.02, 16 rows 1.80; weighted 50 bins: 128 rows / 53 KB 0.96-1.05, 64 rows 0.78-1.09).
+  int lane_pitch = 0;
+  auto lds_shared = [&](int rows, bool u16) { return table_bytes + (size_t)p->n_bins * (u16 ? (size_t)(rows / 2 + 1) * 4 : (size_t)(rows + 1) * (weighted ? 8 : 4)); };
+  const bool u16_ok = !weighted && n_cols <= 65535;  // (one workgroup per row block then sees every column: see segs16 below)
+  static const size_t share_above = [] { const char* e = getenv("XHIST_AMD_LANES_SHARE_ABOVE_KB"); return (size_t)(e && *e ? atoi(e) : 64) * 1024; }();  // A/B runs
+  static const size_t share_target = [] { const char* e = getenv("XHIST_AMD_LANES_SHARE_TARGET_KB"); return (size_t)(e && *e ? atoi(e) : 40) * 1024; }();
+  if ((u16_ok ? table_bytes + (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4 : lds_bytes) > std::min(p->lds_max, share_above)) {
+    lane_rows = std::min(lane_rows, 128);
+    while (lane_rows > 16 && lds_shared(lane_rows, u16_ok) > share_target) lane_rows /= 2;
+    if (lds_shared(lane_rows, u16_ok) > p->lds_max) return release(XHIST_ERR_UNSUPPORTED);
+    lane_pitch = 1;  // (the number of words is set below, once the counter width is known)
+  }
   kp.lane_rows = lane_rows;
   const int64_t row_blocks = (n_rows + lane_rows - 1) / lane_rows;
   // unweighted and few enough columns per workgroup: uint16 counters, half the LDS
-  size_t lds_use = lds_bytes;
+  size_t lds_use = lane_pitch ? lds_shared(lane_rows, false) : lds_bytes;
   bool packed16 = false;
   if (!weighted) {
-    const size_t lds16 = table_bytes + (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
+    const size_t lds16 = lane_pitch ? lds_shared(lane_rows, true) : table_bytes + (size_t)p->n_bins * (kLaneBlock / 2 + 1) * 4;
     const int bpc16 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds16));
     int64_t segs16 = std::max<int64_t>(1, ((int64_t)p->cus * bpc16 * 2 + row_blocks - 1) / row_blocks);
     segs16 = std::min<int64_t>(std::min<int64_t>(segs16, std::max<int64_t>(1, n_cols / 64)), 65535);
@@ -648,6 +666,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       }
     }
   }
+  if (lane_pitch) lane_pitch = packed16 ? lane_rows / 2 + 1 : lane_rows + 1;
+  kp.lane_pitch = lane_pitch;
+  if (lds_use > p->lds_max) return release(XHIST_ERR_UNSUPPORTED);
   const int bpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds_use));
   int64_t col_segs = std::max<int64_t>(1, ((int64_t)p->cus * bpc * 2 + row_blocks - 1) / row_blocks);
   col_segs = std::min<int64_t>(col_segs, std::max<int64_t>(1, n_cols / 64));
@@ -665,8 +686,8 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   {
     char desc[384];
     snprintf(desc, sizeof desc,
-             "family=lanes hist=%s transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
-             packed16 ? "lds16" : "lds", (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_use, scan,
+             "family=lanes hist=%s%s rows_per_wg=%d transpose=%d direct_store=%d block=%d grid=%lldx%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
+             packed16 ? "lds16" : "lds", lane_pitch ? "(shared)" : "", lane_rows, (int)transpose, direct, kLaneBlock, (long long)row_blocks, (long long)col_segs, lds_use, scan,
              (int)weighted, D,
              use_f32 ? "f32thr" : "f64");
     if (int rrc = rec.end(desc)) return release(rrc);

@@ -84,6 +84,8 @@ struct Params {
   int64_t slice_lo;
   int32_t slice_n;
   int32_t lane_rows;       // hist_lanes: rows per workgroup (64 / 128 / 256; 0 = 256) — fewer rows, more column streams
+  int32_t lane_pitch;      // hist_lanes: 0 = one counter column per LANE (pitch 257 words per bin); else the lane groups of a row
+                           //   share one column per ROW and this is the pitch (rows + 1, or rows / 2 + 1 for uint16 counters)
   int64_t row0;            // first logical row of this launch (inputs only; `out` is pre-advanced)
   int32_t n_dims;
   DimTable dim[kMaxDims];

@@ -50,7 +50,13 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   const uint64_t* tab = stage_tables(p);
   cnt_t* hist = reinterpret_cast<cnt_t*>(xhist_smem + (size_t)p.table_words * 8);
   const uint32_t nb = (uint32_t)p.n_bins;
-  for (uint32_t i = tid; i < nb * kPitch; i += kLaneBlock) hist[i] = (cnt_t)0;
+  // counters: a column per lane (conflict-free, G copies of every row) — or, where nb x 257 words do not fit the LDS (joint
+  // histograms over a leading axis: 20 x 20 bins are 411 KB), a column per ROW that the row's G lane groups share: every
+  // add is an atomic anyway, and nb x (R + 1) words fit for R = 64 ... 16 rows per workgroup
+  const bool shared = p.lane_pitch != 0;
+  const uint32_t pitch = shared ? (uint32_t)p.lane_pitch : (uint32_t)kPitch;
+  const uint32_t my_col = shared ? (uint32_t)lane_row : (uint32_t)tid;
+  for (uint32_t i = tid; i < nb * pitch; i += kLaneBlock) hist[i] = (cnt_t)0;
   __syncthreads();
 
   const ST* sp[D];
@@ -68,8 +74,8 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
 
   const int64_t c_lo = (int64_t)blockIdx.y * cols_per_seg;
   const int64_t c_hi = min(p.n_cols, c_lo + cols_per_seg);
-  cnt_t* mine = hist + (PACKED16 ? tid >> 1 : tid);
-  const uint32_t my_inc = PACKED16 ? 1u << ((tid & 1) << 4) : 1u;
+  cnt_t* mine = hist + (PACKED16 ? my_col >> 1 : my_col);
+  const uint32_t my_inc = PACKED16 ? 1u << ((my_col & 1u) << 4) : 1u;
 
   auto bin_and_add = [&](const ST (&x)[D], wscalar w) {
     bool ok = true;
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
       ok &= (b >= 0);
       flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
     }
-    cnt_t* slot = mine + (ok ? flat : 0u) * kPitch;
+    cnt_t* slot = mine + (ok ? flat : 0u) * pitch;
     if (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(slot), ok ? (double)w : 0.0);
     else atomicAdd(reinterpret_cast<uint32_t*>(slot), ok ? my_inc : 0u);
   };
@@ -123,10 +129,10 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
   for (uint32_t j = tid; j < total; j += kLaneBlock) {
     const uint32_t row = j / nb, b = j - row * nb;
     cnt_t v = (cnt_t)0;
-    for (int gg = 0; gg < G; ++gg) {
+    for (int gg = 0; gg < (shared ? 1 : G); ++gg) {
       const uint32_t lane = (uint32_t)gg * (uint32_t)R + row;
-      if constexpr (PACKED16) v += (hist[b * kPitch + (lane >> 1)] >> ((lane & 1) << 4)) & 0xffffu;
-      else v += hist[b * kPitch + lane];
+      if constexpr (PACKED16) v += (hist[b * pitch + (lane >> 1)] >> ((lane & 1) << 4)) & 0xffffu;
+      else v += hist[b * pitch + lane];
     }
     if (direct_store) {
       out[j] = (out_t)v;
