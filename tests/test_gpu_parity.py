@@ -502,6 +502,33 @@ def test_dense_short_rows_streamed_flat(xh, shape, dtype, edges_kind):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("weights", [None, "f32", "f64", "both_signs_and_nan"])
+@pytest.mark.parametrize("dims", [1, 2])
+@pytest.mark.parametrize("shape", [(5000, 365), (4097, 20), (9000, 1), (4097, 3), (7777, 64), (5001, 255), (4099, 800)])
+def test_dense_short_rows_streamed_flat_weights_and_joint(xh, shape, dims, weights, dtype):
+    """hist_flat_rows with weights (float64 sums in LDS, one copy) and with two inputs (joint bins): the reference's per-row
+    result, NaN weights poisoning only their own bin, NaN weights on dropped samples discarded (core.py:73-83)."""
+    if dims == 1 and weights is None:
+        pytest.skip("covered by test_dense_short_rows_streamed_flat")
+    rng = np.random.default_rng(shape[1] * 3 + dims)
+    xs = [rng.standard_normal(shape).astype(dtype) for _ in range(dims)]
+    xs[0][::7, ::5] = np.nan
+    xs[-1][5, :] = 100.0
+    w = {None: None, "f32": rng.uniform(0, 1, shape).astype(np.float32), "f64": rng.uniform(0, 1, shape),
+         "both_signs_and_nan": rng.standard_normal(shape)}[weights]
+    if weights == "both_signs_and_nan":
+        w[::11, ::3] = np.nan  # some on dropped samples (x is NaN at [::77, ::15]), some on binned ones
+    bins = [np.linspace(-3, 3, 31), np.sort(rng.uniform(-3, 3, 12))][:dims]
+    want = onp.bincount_rows(xs, bins, w)
+    got, desc = _run(xh, xs, bins, w, True)
+    assert "family=flat_rows" in desc and "D=%d" % dims in desc, desc
+    assert_hist_equal(got, want, w is not None)
+    got, desc = _run(xh, xs, bins, w, True, flat_rows=-1)
+    assert "family=flat_rows" not in desc, desc
+    assert_hist_equal(got, want, w is not None)
+
+
 def test_dense_short_rows_flat_needs_alignment_and_falls_back(xh):
     """the flat kernel reads aligned 16-byte vectors: a view that starts 4 bytes into an allocation takes the older kernels"""
     rng = np.random.default_rng(8)
@@ -1440,10 +1467,18 @@ def test_lanes_many_short_rows(xh, shape):
     want, _ = onp.histogram(x, bins=edges, axis=1, weights=w, density=True)
     got, _ = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w), density=True)
     desc = _describe_last(xh, [_dev(x[:1])], [edges])
+    assert "family=flat_rows" in desc and "weighted=1" in desc, desc  # dense rows with weights: streamed flat as well
+    assert_hist_equal(got.cpu().numpy(), want, True)
+    plan.set_param("flat_rows", -1)
+    try:
+        got, _ = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w), density=True)
+        desc = plan.describe()
+    finally:
+        plan.set_param("flat_rows", 0)
     if shape[1] <= 80:
-        assert "family=lanes" in desc and "transpose=1" in desc, desc  # weighted, very short rows: transposed scratch + lanes
+        assert "family=lanes" in desc and "transpose=1" in desc, desc  # (before) weighted, very short rows: transposed scratch + lanes
     else:
-        assert "family=fast" in desc and "direct_store=1" in desc, desc  # one 64-thread workgroup per row, plain-store flush
+        assert "family=fast" in desc and "direct_store=1" in desc, desc  # (before) one 64-thread workgroup per row, plain-store flush
     assert_hist_equal(got.cpu().numpy(), want, True)
     # host route reaches the same kernels through the staged copy
     np.testing.assert_array_equal(xh.histogram(x, bins=edges, axis=1)[0], onp.histogram(x, bins=edges, axis=1)[0])
@@ -1458,6 +1493,15 @@ def test_lanes_2d_joint_nonuniform_and_binary_search_tables(xh):
     want, _ = onp.histogram(a, b, bins=[ea, eb], axis=1)
     got, _ = xh.histogram(_dev(a), _dev(b), bins=[ea, eb], axis=1)
     desc = _describe_last(xh, [_dev(a[:1]), _dev(b[:1])], [ea, eb])
+    assert "family=flat_rows" in desc and "scan=0" in desc, desc
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    plan = _plan_for(xh, [_dev(a[:1]), _dev(b[:1])], [ea, eb])
+    plan.set_param("flat_rows", -1)
+    try:
+        got, _ = xh.histogram(_dev(a), _dev(b), bins=[ea, eb], axis=1)
+        desc = plan.describe()
+    finally:
+        plan.set_param("flat_rows", 0)
     assert "family=lanes" in desc, desc
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 

@@ -448,16 +448,22 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);
   bool transpose = false;
   if (small && !(all_natural && samples[0].row_stride == 1)) return XHIST_ERR_UNSUPPORTED;
-  // dense short rows of one unweighted float input: streamed flat (hist_flat_rows)
+  // dense short rows of one or two float inputs, with or without float weights: streamed flat (hist_flat_rows)
   // (3.65 x 10^8 float32 samples, 50 bins, ms per call, fused turn-around kernel / row streaming | flat: rows of 20 2.25 | 1.83;
   // 64 1.00 | 0.72; 100 1.07 | 0.66; 200 0.84 | 0.46; 365 0.79 | 0.41; 512 0.59 | 0.42; 720 0.46 | 0.43; 1024 0.33 | 0.38;
   // 2048 0.28 | 0.37: profiles/r03_f_flat_rows.txt)
   constexpr int64_t kFlatMaxCols = 800;
-  const uint32_t flat_nbp = ((uint32_t)p->n_bins + 1u) & ~1u;
-  const int flat_k_log2 = n_cols >= 256 ? 2 : (n_cols >= 128 ? 1 : 0);
-  const bool flat_ok = D == 1 && !weighted && !small && n_cols >= 1 && n_cols < 65536 && samples[0].col_stride == 1 &&
-                       samples[0].row_stride == n_cols && samples[0].inner_rows == 0 && (sdt != XHIST_F32 || use_f32) &&
-                       ((uintptr_t)samples[0].data & 15u) == 0 && ((size_t)flat_nbp << flat_k_log2) * 2 <= 4096;
+  const uint32_t flat_nbp = weighted ? (uint32_t)p->n_bins : (((uint32_t)p->n_bins + 1u) & ~1u);
+  const int flat_k_log2 = (weighted || p->n_bins > 128) ? 0 : (n_cols >= 256 ? 2 : (n_cols >= 128 ? 1 : 0));  // (copies: few bins, long rows)
+  const size_t flat_row_bytes = ((size_t)flat_nbp << flat_k_log2) * (weighted ? 8 : 2);  // LDS per row of a workgroup
+  bool flat_ok = (D == 1 || D == 2) && !small && n_cols >= 1 && n_cols < 65536 && (sdt != XHIST_F32 || use_f32) && flat_row_bytes <= 4096 &&
+                 (!weighted || wdt == XHIST_F32 || wdt == XHIST_F64);
+  for (int d = 0; d <= D && flat_ok; ++d) {
+    if (d == D && !weighted) break;
+    const xhist_array& a = d < D ? samples[d] : *weights;
+    const size_t vec_bytes = (size_t)(16 / dtype_size(sdt)) * (size_t)dtype_size(a.dtype);  // one load: as many elements as a 16-byte sample vector
+    flat_ok = a.col_stride == 1 && a.row_stride == n_cols && a.inner_rows == 0 && ((uintptr_t)a.data & (vec_bytes - 1)) == 0;
+  }
   const bool use_flat = flat_ok && !prefer && p->flat_rows >= 0 && n_rows >= 4096 && n_cols <= (p->flat_rows > 0 ? 65535 : kFlatMaxCols) &&
                         !(all_natural && samples[0].row_stride == 1);
   // (hist_lanes: a counter column per lane, or — shared by a row's lane groups — per row, for as few as 16 rows per workgroup)
@@ -484,22 +490,30 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   const bool fused_ok = D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0;
   if (transpose && grouped_any && !fused_ok) return XHIST_ERR_UNSUPPORTED;  // transpose_2d takes plain row strides only
   if (use_flat) {
-    kernel_fn_flat ff = flat_rows_kernel(sdt, scan);
+    kernel_fn_flat ff = xhist_pick_flat_rows(sdt, weighted ? wdt : -1, D, scan);
     // R rows per workgroup: ~16 Ki samples, at most 24 KiB of counters, and enough workgroups for every CU
-    int64_t R = std::min<int64_t>(16384 / n_cols, (int64_t)(24576 / (((size_t)flat_nbp << flat_k_log2) * 2)));
-    R = std::min<int64_t>(R, std::max<int64_t>(1, n_rows / ((int64_t)p->cus * 8)));
+    int64_t R = std::min<int64_t>(16384 / n_cols, (int64_t)(24576 / flat_row_bytes));
+    R = std::min<int64_t>(R, std::max<int64_t>((2048 + n_cols - 1) / n_cols, n_rows / ((int64_t)p->cus * 8)));  // (2048+ samples a workgroup)
     R = std::max<int64_t>(1, std::min<int64_t>(R, 1024));
-    const size_t lds_flat = table_bytes + ((size_t)R * ((size_t)flat_nbp << flat_k_log2) / 2 + 32) * 4;
+    const size_t lds_flat = ((table_bytes + 15) & ~(size_t)15) + (size_t)R * flat_row_bytes + 32 * (weighted ? 8 : 4);
     const int64_t row_blocks = (n_rows + R - 1) / R;
     if (ff && lds_flat <= p->lds_max && row_blocks <= 2147483647LL) {
       Params kp;
       memset(&kp, 0, sizeof kp);
-      kp.s_ptr[0] = samples[0].data;
-      kp.s_rs[0] = samples[0].row_stride;
-      kp.s_cs[0] = 1;
-      kp.s_dt[0] = sdt;
-      kp.dim[0] = tset.dim[0];
-      kp.n_dims = 1;
+      for (int d = 0; d < D; ++d) {
+        kp.s_ptr[d] = samples[d].data;
+        kp.s_rs[d] = samples[d].row_stride;
+        kp.s_cs[d] = 1;
+        kp.s_dt[d] = sdt;
+        kp.dim[d] = tset.dim[d];
+      }
+      if (weighted) {
+        kp.w_ptr = weights->data;
+        kp.w_rs = weights->row_stride;
+        kp.w_cs = 1;
+        kp.w_dt = weights->dtype;
+      }
+      kp.n_dims = D;
       kp.tables = tset.blob;
       kp.table_words = tset.words;
       kp.tables_in_lds = 1;
@@ -517,8 +531,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       HIPC(hipGetLastError());
       char desc[320];
       snprintf(desc, sizeof desc,
-               "family=flat_rows hist=lds16 rows_per_wg=%lld copies=%d direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=0 D=1 cmp=%s",
-               (long long)R, 1 << flat_k_log2, direct, kLaneBlock, (long long)row_blocks, lds_flat, scan, use_f32 ? "f32thr" : "f64");
+               "family=flat_rows hist=%s rows_per_wg=%lld copies=%d direct_store=%d block=%d grid=%lld lds_bytes=%zu scan=%d weighted=%d D=%d cmp=%s",
+               weighted ? "lds" : "lds16", (long long)R, 1 << flat_k_log2, direct, kLaneBlock, (long long)row_blocks, lds_flat, scan, (int)weighted, D,
+               use_f32 ? "f32thr" : "f64");
       return rec.end(desc);
     }
   }

@@ -235,54 +235,74 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
   }
 }
 
-// Flat form for DENSE short rows (one input, unweighted, row stride == columns, fewer than 65536 columns): a workgroup
-// takes R consecutive rows — one contiguous piece of memory — and streams it with aligned 16-byte loads exactly like a long
-// row, whatever the row length; a sample's row is its position divided by the row length (one multiply-high: position *
-// ceil(2^40 / columns) >> 40, exact below 2^22 positions), and its counter lives in an LDS histogram [R rows][K copies][bins]
-// of uint16 counters, two per word (a row has < 65536 samples).  The lanes of a wavefront read neighbouring samples, i.e. one
-// or two rows at a time, so their adds would meet on a row's few bins: lane l uses copy l mod K (K = 4 for rows of 256+
-// samples).  The finished [R x bins] block is written once, with plain coalesced stores.  Against hist_lanes_rows1 (128-byte
-// pieces of 256 rows turned around in LDS, two barriers per piece): 10^6 rows of 365 float32, 50 bins 0.79 -> 0.41 ms per call
-// (1.86 GB in + out at 4.5 TB/s wall, ~5.2 by the kernel); the host keeps it to rows of up to 800 samples.
-template <typename ST, int SCAN>
+// Flat form for DENSE short rows (every input — and the weights — with row stride == columns, fewer than 65536 columns,
+// 16-byte aligned): a workgroup takes R consecutive rows — one contiguous piece of memory per array — and streams it with
+// aligned vector loads exactly like a long row, whatever the row length; a sample's row is its position divided by the row
+// length (one multiply-high: position * ceil(2^40 / columns) >> 40, exact below 2^22 positions), and its counter lives in an
+// LDS histogram [R rows][K copies][bins].  Counts are uint16, two per word (a row has < 65536 samples); the lanes of a
+// wavefront read neighbouring samples, i.e. one or two rows at a time, so their adds would meet on a row's few bins: lane l
+// uses copy l mod K (K = 4 for rows of 256+ samples).  Weighted sums are float64, one copy (same-address float64 adds are not
+// slower than scattered ones: tools/ubench/ldsatomic).  The finished [R x bins] block is written once, with plain coalesced
+// stores.  Against hist_lanes_rows1 (128-byte pieces of 256 rows turned around in LDS, two barriers per piece): 10^6 rows of
+// 365 float32, 50 bins 0.79 -> 0.40 ms per call (1.86 GB in + out at 4.6 TB/s wall, ~5.3 by the kernel); against one
+// 64-thread workgroup per row (weights, joint histograms) see DESIGN.  The host keeps it to rows of up to 800 samples.
+template <typename ST, typename WT, int D, int SCAN>
 __global__ void __launch_bounds__(kLaneBlock) hist_flat_rows(const Params p, int32_t direct_store, int32_t R, int32_t k_log2, uint64_t magic,
                                                              int64_t n_elems) {
   constexpr int CMP = __is_same(ST, float) ? 2 : 0;
   using CT = typename Dom<CMP>::T;
-  constexpr int VEC = 16 / (int)sizeof(ST), UNROLL = 4;
+  constexpr bool kWeighted = !__is_same(WT, NoWeight);
+  using wscalar = typename std::conditional<kWeighted, WT, float>::type;
+  using cnt_t = typename std::conditional<kWeighted, double, uint32_t>::type;
+  using out_t = typename std::conditional<kWeighted, double, unsigned long long>::type;
+  constexpr int VEC = 16 / (int)sizeof(ST), UNROLL = (D == 1 && !kWeighted) ? 4 : 2;
   using svec = typename VecOf<ST, VEC>::type;
+  using wvec = typename VecOf<wscalar, VEC>::type;
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * R;
   const int rows_here = (int)min<int64_t>(R, p.n_rows - r0);
   const uint64_t* tab = stage_tables(p);
-  const uint32_t nb = (uint32_t)p.n_bins, nbp = (nb + 1u) & ~1u;  // counters per (row, copy): even, so that pairs never straddle
-  uint32_t* hist = reinterpret_cast<uint32_t*>(xhist_smem + (size_t)p.table_words * 8);
-  const uint32_t words = ((uint32_t)R << k_log2) * (nbp >> 1);
-  for (uint32_t i = tid; i < words + 32u; i += kLaneBlock) hist[i] = 0u;  // (+ 32 trash words for dropped samples)
+  const uint32_t nb = (uint32_t)p.n_bins, nbp = kWeighted ? nb : ((nb + 1u) & ~1u);  // uint16 counters pair up: an even number per (row, copy)
+  cnt_t* hist = reinterpret_cast<cnt_t*>(xhist_smem + (((size_t)p.table_words * 8 + 15) & ~(size_t)15));
+  const uint32_t slots = ((uint32_t)R << k_log2) * (kWeighted ? nbp : (nbp >> 1));  // LDS elements of the histogram
+  for (uint32_t i = tid; i < slots + 32u; i += kLaneBlock) hist[i] = (cnt_t)0;     // (+ 32 trash slots for dropped samples)
   __syncthreads();
-  // dense rows: row r of the call starts at element r * n_cols of a 16-byte aligned array of n_elems elements
-  const ST* base = reinterpret_cast<const ST*>(p.s_ptr[0]);
+  // dense rows: row r of the call starts at element r * n_cols of aligned arrays of n_elems elements
+  const ST* base[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) base[d] = reinterpret_cast<const ST*>(p.s_ptr[d]);
+  const wscalar* wbase = reinterpret_cast<const wscalar*>(p.w_ptr);
   const int64_t g0 = (p.row0 + r0) * p.n_cols, g1 = g0 + (int64_t)rows_here * p.n_cols;  // this workgroup's samples
   const int64_t v_lo = g0 / VEC, v_hi = (g1 + VEC - 1) / VEC;                            // ... and the aligned vectors that hold them
-  const int64_t v_whole = n_elems / VEC;                                                 // vectors that lie wholly inside the array
+  const int64_t v_whole = n_elems / VEC;                                                 // vectors that lie wholly inside the arrays
   const uint32_t n_here = (uint32_t)(g1 - g0);
   const uint32_t copy_off = ((uint32_t)tid & ((1u << k_log2) - 1u)) * nbp;
-  const uint32_t trash = words + ((uint32_t)tid & 31u);
-  const int max_steps = max(1, p.dim[0].steps);
+  const uint32_t trash = slots + ((uint32_t)tid & 31u);
+  int max_steps = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) max_steps = max(max_steps, p.dim[d].steps);
   for (int64_t v0 = v_lo + tid; v0 < v_hi; v0 += kLaneBlock * UNROLL) {
-    svec xv[1][UNROLL];
+    svec xv[D][UNROLL];
+    wvec wv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t vv = min(v0 + (int64_t)u * kLaneBlock, v_hi - 1);  // (past the workgroup's last vector: that one again, masked below)
       if (vv < v_whole) {
-        xv[0][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(base) + vv);
-      } else {  // the array's ragged last vector (one lane of one workgroup): element by element
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) xv[0][u][v] = vv * VEC + v < n_elems ? base[vv * VEC + v] : (ST)__builtin_nanf("");
+        for (int d = 0; d < D; ++d) xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const svec*>(base[d]) + vv);
+        if (kWeighted) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wbase) + vv);
+      } else {  // the arrays' ragged last vector (one lane of one workgroup): element by element
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const bool in = vv * VEC + v < n_elems;
+#pragma unroll
+          for (int d = 0; d < D; ++d) xv[d][u][v] = in ? base[d][vv * VEC + v] : (ST)__builtin_nanf("");
+          if (kWeighted) wv[u][v] = in ? wbase[vv * VEC + v] : (wscalar)0;
+        }
       }
     }
-    uint32_t cnt[1][UNROLL][VEC];
-    count_le_tile<CMP, SCAN, 1, UNROLL, VEC>(xv, p, tab, max_steps, cnt);
+    uint32_t cnt[D][UNROLL][VEC];
+    count_le_tile<CMP, SCAN, D, UNROLL, VEC>(xv, p, tab, max_steps, cnt);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t vv = v0 + (int64_t)u * kLaneBlock;
@@ -290,27 +310,39 @@ __global__ void __launch_bounds__(kLaneBlock) hist_flat_rows(const Params p, int
       for (int v = 0; v < VEC; ++v) {
         const int64_t i64 = vv * VEC + v - g0;  // the sample's position among this workgroup's
         const uint32_t i = (uint32_t)i64;
-        const int b = bin_from_count<CMP>((CT)xv[0][u][v], p.dim[0], cnt[0][u][v]);
-        const bool ok = (b >= 0) & (i64 >= 0) & (i64 < (int64_t)n_here);
+        bool ok = (i64 >= 0) & (i64 < (int64_t)n_here);
+        uint32_t flat = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int b = bin_from_count<CMP>((CT)xv[d][u][v], p.dim[d], cnt[d][u][v]);
+          ok &= (b >= 0);
+          flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
+        }
         const uint32_t row = (uint32_t)(((uint64_t)i * magic) >> 40);
-        const uint32_t idx = ((row << k_log2) * nbp) + copy_off + (uint32_t)b;
-        atomicAdd(hist + (ok ? (idx >> 1) : trash), ok ? (1u << ((idx & 1u) << 4)) : 0u);
+        const uint32_t idx = ((row << k_log2) * nbp) + copy_off + flat;
+        if constexpr (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + (ok ? idx : trash), ok ? (double)wv[u][v] : 0.0);
+        else atomicAdd(reinterpret_cast<uint32_t*>(hist) + (ok ? (idx >> 1) : trash), ok ? (1u << ((idx & 1u) << 4)) : 0u);
       }
     }
   }
   __syncthreads();
-  unsigned long long* out = reinterpret_cast<unsigned long long*>(p.out) + r0 * nb;
+  out_t* out = reinterpret_cast<out_t*>(p.out) + r0 * nb;
   const uint32_t total = (uint32_t)rows_here * nb;
   const uint32_t K = 1u << k_log2;
   for (uint32_t j = tid; j < total; j += kLaneBlock) {
     const uint32_t row = j / nb, b = j - row * nb;
-    unsigned long long v = 0;
+    cnt_t v = (cnt_t)0;
     for (uint32_t k = 0; k < K; ++k) {
       const uint32_t idx = (row * K + k) * nbp + b;
-      v += (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu;
+      if constexpr (kWeighted) v += hist[idx];
+      else v += (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu;
     }
-    if (direct_store) out[j] = v;
-    else if (v) atomicAdd(out + j, v);
+    if (direct_store) {
+      out[j] = (out_t)v;
+    } else if (v != (cnt_t)0) {
+      if constexpr (kWeighted) unsafeAtomicAdd(reinterpret_cast<double*>(out) + j, (double)v);
+      else atomicAdd(reinterpret_cast<unsigned long long*>(out) + j, (unsigned long long)v);
+    }
   }
 }
 

@@ -220,6 +220,8 @@ kernel_fn xhist_pick_f32_long(int scan);  // hist_fast<float, NoWeight, 1, 4, 8,
 kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
+typedef void (*kernel_fn_flat)(const Params, int32_t, int32_t, int32_t, uint64_t, int64_t);
+kernel_fn_flat xhist_pick_flat_rows(int sdt, int wdt, int D, int scan);  // hist_flat_rows (xhist_pick_flat.hip); nullptr: no such variant
 // (xhist_route_{f64,f32}_b{1024,512}.hip: one translation unit per sample type and workgroup size)
 #define XH_ROUTE_TU(ST, B) kernel_fn_route xhist_pick_route_##ST##_b##B(int wdt, int D, int scan, bool multi);
 XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 512) XH_ROUTE_TU(f64, 1024s8)

@@ -166,26 +166,6 @@ static kernel_fn_rows1 rows1_kernel(int sdt, int scan) {
   return nullptr;
 }
 
-typedef void (*kernel_fn_flat)(const Params, int32_t, int32_t, int32_t, uint64_t, int64_t);
-
-template <typename ST>
-static kernel_fn_flat flat_rows_pick(int scan) {
-  switch (scan) {
-    case 1: return (kernel_fn_flat)hist_flat_rows<ST, 1>;
-    case 2: return (kernel_fn_flat)hist_flat_rows<ST, 2>;
-    case 3: return (kernel_fn_flat)hist_flat_rows<ST, 3>;
-    case 4: return (kernel_fn_flat)hist_flat_rows<ST, 4>;
-    case kScanArith: return (kernel_fn_flat)hist_flat_rows<ST, kScanArith>;
-    default: return (kernel_fn_flat)hist_flat_rows<ST, 0>;
-  }
-}
-
-static kernel_fn_flat flat_rows_kernel(int sdt, int scan) {
-  if (sdt == XHIST_F64) return flat_rows_pick<double>(scan);
-  if (sdt == XHIST_F32) return flat_rows_pick<float>(scan);
-  return nullptr;
-}
-
 template <bool TLDS>
 static kernel_fn generic_kernel_t(int cmp, bool weighted, bool lds) {
   if (cmp == XHIST_CMP_F64) {
