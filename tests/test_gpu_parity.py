@@ -546,6 +546,22 @@ def test_dense_short_rows_flat_needs_alignment_and_falls_back(xh):
     np.testing.assert_array_equal(got.cpu().numpy(), onp.bincount_rows([flat[4:4 + (m - 1) * c].view(m - 1, c).cpu().numpy()], [edges], None))
 
 
+def test_dense_short_rows_flat_in_row_blocks(xh):
+    """block_size cuts the rows into separate launches on one output (core.py:86-134): blocks that start on a 16-byte
+    boundary stream flat, the others take the older kernels — same result either way"""
+    rng = np.random.default_rng(10)
+    edges = np.linspace(-3, 3, 41)
+    for shape, dtype, bs in [((20000, 40), np.float64, 5000), ((20004, 33), np.float32, 5001), ((16384, 100), np.float32, 4096)]:
+        x = rng.standard_normal(shape).astype(dtype)
+        w = rng.uniform(0, 1, shape)
+        want = onp.histogram(x, bins=edges, axis=1)[0]
+        got = xh.histogram(_dev(x), bins=edges, axis=1, block_size=bs)[0]
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        wantw = onp.histogram(x, bins=edges, axis=1, weights=w)[0]
+        gotw = xh.histogram(_dev(x), bins=edges, axis=1, weights=_dev(w), block_size=bs)[0]
+        assert_hist_equal(gotw.cpu().numpy(), wantw, True)
+
+
 def test_dense_short_rows_flat_any_length_when_forced(xh):
     """"flat_rows" = 1: any row length below 65536 (the multiply-high row index, several iterations per row)"""
     rng = np.random.default_rng(9)
