@@ -970,6 +970,40 @@ def test_device_min_max_feeding_integer_bins(xh, dt):
         assert lo == float(s2.min()) and hi == float(s2.max())
 
 
+def test_weights_that_span_a_small_slab_of_device_data(xh):
+    """cos(lat) / cell-area weights against (time, lat, lon) on the GPU: only the (lat, lon) slab they span is
+    written out and the weighted kernels read it with stride 0 along every other axis (core._weights_slab);
+    reduced axes outside the slab are summed afterwards.  Must equal the reference's materialised-weights result."""
+    rng = np.random.default_rng(154)
+    t = rng.standard_normal((48, 36, 72)).astype(np.float32)
+    t[0, 3, :5] = np.nan
+    u = rng.standard_normal(t.shape).astype(np.float32)
+    e = np.linspace(-3, 3, 31)
+    w_lat = np.cos(np.linspace(-1.4, 1.4, 36)).reshape(1, 36, 1)
+    w_area = rng.uniform(0, 2, (36, 72))
+    w_lon = rng.uniform(0, 2, (72,)).astype(np.float32)
+    w_time = rng.uniform(0, 2, (48, 1, 1))
+    w_bad = w_lat.copy()
+    w_bad[0, 5, 0] = np.nan
+    w_bad[0, 9, 0] = np.inf
+    cases = [(w_lat, (1, 2), True), (w_lat, None, True), (w_lat, (0, 1), True), (w_lat, 1, True), (w_lat, (0, 1, 2), True),
+             (w_area, (1, 2), True), (w_area, None, True), (w_lon, (1, 2), True), (w_lon, 2, True), (w_lon, (0, 2), False),
+             (w_bad, (1, 2), True), (w_time, (1, 2), False), (w_lat, 2, False), (w_lat, (0, 2), False),
+             (rng.uniform(0, 1, t.shape), (1, 2), False), (np.float64(0.5) * np.ones((1, 1, 1)), None, False)]
+    for w, axis, applies in cases:
+        for args, bins in (([t], e), ([t, u], [np.linspace(-3, 3, 9), np.linspace(-3, 3, 7)])):
+            want, _ = onp.histogram(*args, bins=bins, weights=w, axis=axis)
+            got, _ = xh.histogram(*[_dev(a) for a in args], bins=bins, weights=_dev(w), axis=axis)
+            assert got.shape == want.shape and got.dtype == torch.float64
+            assert_hist_equal(got.cpu().numpy(), want, True)
+        drop = list(range(3)) if axis is None else [axis] if isinstance(axis, int) else list(axis)
+        part = xh._weights_slab([_dev(t)], _dev(w), drop, [e], None, "torch")
+        assert (part is not None) == applies, (w.shape, axis)
+    # weights that arrive broadcast already (a stride-0 view of full shape: what the xarray wrapper hands over)
+    got, _ = xh.histogram(_dev(t), bins=e, weights=_dev(w_lat).expand(t.shape), axis=(1, 2), density=True)
+    assert_hist_equal(got.cpu().numpy(), onp.histogram(t, bins=e, weights=w_lat, axis=(1, 2), density=True)[0], True)
+
+
 @pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
 def test_weights_broadcast_along_reduced_axes(xh, resident):
     """cos(lat)-style weights: constant along some reduced axes -> counted unweighted over those axes,

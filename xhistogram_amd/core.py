@@ -965,6 +965,68 @@ def _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, b
     return part.sum(axis=tuple(rest), keepdims=True)
 
 
+def _weights_slab(args_b, w_raw, drop_axes, bins, block_size, backend):
+    """Device-resident data with weights that vary only along reduced axes and are small next to the data —
+    ``cos(lat)`` of shape (1, lat, 1) or cell areas (1, lat, lon) against (time, lat, lon): the reference
+    materialises them at full size (``broadcast_arrays`` + reshape, core.py:366 / 211-229), a second array
+    as big as the data.  Here only the SLAB they really span — the run of adjacent reduced axes from the
+    first axis they vary along to the innermost reduced axis next to it — is written out ((lat, lon): 4 MB
+    against 1.5 GB) and handed to the weighted kernels with stride 0 along every other axis; reduced axes
+    outside the slab are summed afterwards (histograms add up).  (365, 720, 1440) float32, cos(lat), over
+    (lat, lon): 0.54 -> 0.30 ms; over everything: 0.61 -> 0.31.  None when it does not apply."""
+    if backend != "torch" or w_raw is None:
+        return None
+    shape = tuple(int(n) for n in args_b[0].shape)
+    nd = len(shape)
+    if w_raw.ndim > nd or nd < 2:
+        return None
+    wstrides = tuple(w_raw.stride())
+    for ax in _range(w_raw.ndim):
+        if wstrides[ax] == 0 and w_raw.shape[ax] > 1:
+            w_raw = w_raw[tuple(slice(0, 1) if k == ax else slice(None) for k in _range(w_raw.ndim))]
+    wshape = (1,) * (nd - w_raw.ndim) + tuple(int(n) for n in w_raw.shape)
+    if any(wshape[ax] not in (1, shape[ax]) for ax in _range(nd)):
+        return None  # (not broadcastable: the regular path raises)
+    drop = sorted(int(ax) for ax in drop_axes)
+    vary = [ax for ax in _range(nd) if wshape[ax] > 1]
+    if not vary or len(vary) == nd or any(ax not in drop for ax in vary):
+        return None  # scalar weights, full-size weights, or weights that differ from row to row
+    lo, hi = vary[0], vary[-1]
+    if any(ax not in drop for ax in _range(lo, hi + 1)):
+        return None
+    while hi + 1 in drop:
+        hi += 1
+    lo_far = lo
+    while lo_far - 1 in drop:
+        lo_far -= 1
+    total = 1
+    for n in shape:
+        total *= n
+    itemsize = sum(_np_dtype_of(a).itemsize for a in args_b)
+    n_bins = 1
+    for b in bins:
+        n_bins *= max(len(b) - 1, 0)
+    blk = None
+    for first in ([lo_far, lo] if lo_far != lo else [lo]):  # the whole run of adjacent reduced axes if its slab is still small
+        slab_elems = 1
+        for ax in _range(first, hi + 1):
+            slab_elems *= shape[ax]
+        left_over = any(ax < first or ax > hi for ax in drop)
+        if slab_elems * 8 * 8 > total * itemsize or slab_elems == total:
+            continue  # the slab is not small next to the data
+        if left_over and n_bins * 8 * 4 > slab_elems * itemsize:
+            continue  # (as in _reduce_in_two_steps: the intermediate must stay small)
+        blk = list(_range(first, hi + 1))
+        break
+    if blk is None:
+        return None
+    lo = blk[0]
+    rest = [ax for ax in drop if ax not in blk]
+    slab = w_raw.reshape(wshape).expand(tuple(shape[ax] if lo <= ax <= hi else 1 for ax in _range(nd))).contiguous()
+    part = _bincount(*args_b, slab.expand(shape), weights=True, axis=blk, bins=bins, density=False, block_size=block_size)
+    return part.sum(dim=rest, keepdim=True) if rest else part
+
+
 def _weights_constant_along_reduced(args_b, w_raw, drop_axes, bins, block_size, backend):
     """Weights that do not vary along some of the reduced axes (``cos(lat)`` of shape (1, lat, 1) under a
     reduction over lat and lon; one weight per time step; ...): the reference materialises them at
@@ -1161,7 +1223,9 @@ def _counts_one_device(all_arrays, w_raw, n_inputs, has_weights, two, drop_axes,
     block_size = bincount_kwargs["block_size"]
     counts = None
     if not two and has_weights:
-        counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
+        counts = _weights_slab(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
+        if counts is None:
+            counts = _weights_constant_along_reduced(all_arrays[:n_inputs], w_raw, drop_axes, bins, block_size, backend)
     if counts is None and not two:
         counts = _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend)
     if counts is None:
