@@ -212,6 +212,10 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
+ *       "route_block" (0 auto / 512 / 1024 threads), "route_spl" (0 auto / 4 / 8 samples per lane and tile) and "min_parts"
+ *       (0 auto = 16 / 1 = as few as the histogram's size asks for / up to 128: partitions per row) shape the routing pass of
+ *       the multi-pass mode; "route_pool_pct" (tests: its chunk pool cut to this percentage),
+ *       "flat_rows" (0 auto / 1 for any row length below 65536 / -1 never: many dense short rows streamed as one array),
  *       "lds_copies" (0 = auto), "profile" (0 = off, R = keep the last R kernel timings),
  *       "profile_stride" (S >= 1: time every S-th execute only — for microsecond kernels, where the two event records of
  *       the profile mode cost as much as the launch itself) */
