@@ -1317,6 +1317,21 @@ def test_partitioned_mode_finer_partitions(xh, weights, rows, min_parts):
     assert_hist_equal(got, want, w is not None)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_partitioned_mode_finer_partitions_three_pass_route(xh, weighted):
+    """the count + prefix + scatter form of the partitioned mode ("fused" = -1) takes the finer partitions as well"""
+    rng = np.random.default_rng(71)
+    n = 400_003
+    edges = [np.linspace(-3, 3, 541), np.linspace(-2, 2, 261)]
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    w = rng.uniform(0, 1, (1, n)) if weighted else None
+    want = onp.bincount_rows([x, y], edges, w)
+    for mp in (1, 0, 64):
+        got, desc = _run(xh, [x, y], edges, w, True, partition=1, fused=-1, min_parts=mp)
+        assert "hist=partitioned" in desc and "route=fused" not in desc, desc
+        assert_hist_equal(got, want, weighted)
+
+
 @pytest.mark.parametrize("weights", ["none", "one_sign", "both_signs", "f32"])
 @pytest.mark.parametrize("pct", [2, 10, 40])
 def test_partitioned_mode_chunk_pool_runs_dry(xh, weights, pct):
