@@ -687,42 +687,68 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
         tbl[j] = (uint64_t)id | ((uint64_t)(ra.cmeta[id] & kChunkFillMask) << 32);
       }
       __syncthreads();
-      const uint32_t totalq = nb << qlg;
-      // (the loads of a group sit under `if (live)`, so the compiler waits for group g's before it issues group g + 1's; a
-      // branch-free form that issues all of them first — dead quads re-read the head of their chunk — was measured and is no
-      // faster, 0.767 against 0.745-0.757 ms: sixteen wavefronts per CU overlap each other's round trips, and what the pass
-      // is sensitive to is LDS atomic contention — uniform samples 0.693 ms, N(0,1) 0.767, one bin for all 2.5 ms)
-      for (uint32_t Q = tid; Q < totalq; Q += 1024 * kGroups) {
-        c4 cv[kGroups];
-        w4 wq[kGroups];
-        bool live[kGroups];
+      // Loads free of control flow, several per lane in flight; the adds of a load under `if (live)`.  A record is a 2-byte
+      // code for counts, so a lane takes eight (one 16-byte load) and four such loads; weighted records come four to a lane
+      // and load (quads: 32 bytes of float64 / packed records).  Pieces past a chunk's fill or past the batch re-read the
+      // head of a chunk and are dropped.  (Round 2's form had the loads under the `if` as well — the compiler then waits for
+      // one group's loads before it issues the next — and 8-byte loads of codes: 16 KB per CU in flight for counts, 5*10^8
+      // float32 samples into 10^5 bins 0.31 ms -> 0.17.  Sending the dropped pieces' adds to a trash slot instead of
+      // branching around them took 1.2 ms: lanes that meet on one LDS address inside otherwise scattered adds are slow.)
+      // Fills are multiples of 8: records leave the routing pass in whole groups.
+      if constexpr (!WEIGHTED) {
+        typedef uint16_t c8 __attribute__((ext_vector_type(8)));
+        constexpr int kOct = 4;
+        const int olg = lg - 3;
+        const uint32_t totalo = nb << olg;
+        for (uint32_t O = tid; O < totalo; O += 1024 * kOct) {
+          c8 cv[kOct];
+          bool live[kOct];
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-          const uint32_t Qg = Q + (uint32_t)g * 1024u;
-          live[g] = false;
-          if (Qg < totalq) {
+          for (int g = 0; g < kOct; ++g) {
+            const uint32_t Og = min(O + (uint32_t)g * 1024u, totalo - 1u);
+            const uint64_t e = tbl[Og >> olg];
+            const uint32_t within = (Og & ((1u << olg) - 1u)) << 3;
+            live[g] = (O + (uint32_t)g * 1024u < totalo) & (within < (uint32_t)(e >> 32));
+            const uint64_t at = ((uint64_t)(uint32_t)e << lg) + (live[g] ? within : 0u);
+            cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c8*>(codes + at));
+          }
+#pragma unroll
+          for (int g = 0; g < kOct; ++g)
+            if (live[g]) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<uint32_t*>(hist) + (uint32_t)cv[g][k], 1u);
+            }
+        }
+      } else {
+        const uint32_t totalq = nb << qlg;
+        for (uint32_t Q = tid; Q < totalq; Q += 1024 * kGroups) {
+          c4 cv[kGroups];
+          w4 wq[kGroups];
+          bool live[kGroups];
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g) {
+            const uint32_t Qg = min(Q + (uint32_t)g * 1024u, totalq - 1u);
             const uint64_t e = tbl[Qg >> qlg];
             const uint32_t within = (Qg & ((1u << qlg) - 1u)) << 2;
-            if (within < (uint32_t)(e >> 32)) {
-              const uint64_t at = ((uint64_t)(uint32_t)e << lg) + within;
-              if constexpr (!PACK) cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
-              if (WEIGHTED) wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
-              live[g] = true;
-            }
+            live[g] = (Q + (uint32_t)g * 1024u < totalq) & (within < (uint32_t)(e >> 32));
+            const uint64_t at = ((uint64_t)(uint32_t)e << lg) + (live[g] ? within : 0u);
+            if constexpr (!PACK) cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
+            wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
           }
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g)
+            if (live[g]) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if constexpr (PACK) {
+                  const uint64_t r = (uint64_t)__double_as_longlong((double)wq[g][k]);
+                  unsafeAtomicAdd(reinterpret_cast<double*>(hist) + (uint32_t)(r & 0xffffull), __longlong_as_double((long long)(r & ~0xffffull)));
+                } else {
+                  unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
+                }
+              }
+            }
         }
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g)
-          if (live[g]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if constexpr (PACK) {
-                const uint64_t r = (uint64_t)__double_as_longlong((double)wq[g][k]);
-                unsafeAtomicAdd(reinterpret_cast<double*>(hist) + (uint32_t)(r & 0xffffull), __longlong_as_double((long long)(r & ~0xffffull)));
-              } else if (WEIGHTED) unsafeAtomicAdd(reinterpret_cast<double*>(hist) + cv[g][k], (double)wq[g][k]);
-              else atomicAdd(reinterpret_cast<uint32_t*>(hist) + cv[g][k], 1u);
-            }
-          }
       }
       __syncthreads();
     }
