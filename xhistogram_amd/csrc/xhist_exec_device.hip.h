@@ -454,7 +454,11 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   // 2048 0.28 | 0.37: profiles/r03_f_flat_rows.txt)
   constexpr int64_t kFlatMaxCols = 800;
   const uint32_t flat_nbp = weighted ? (uint32_t)p->n_bins : (((uint32_t)p->n_bins + 1u) & ~1u);
-  const int flat_k_log2 = (weighted || p->n_bins > 128) ? 0 : (n_cols >= 256 ? 2 : (n_cols >= 128 ? 1 : 0));  // (copies: few bins, long rows)
+  // (copies of a row's counters for the lanes of a wavefront to spread over — they read neighbouring samples, one or two
+  // rows at a time — were measured and bought nothing: 10^6 rows of 365 float32, 1 / 2 / 4 / 8 copies 0.403 / 0.411 / 0.422 /
+  // 0.497 ms; rows of 200: 0.463 / 0.468 / 0.520 / 0.684; the kernel keeps the parameter, XHIST_AMD_FLAT_K_LOG2 sets it)
+  static const int flat_k_env = [] { const char* e = getenv("XHIST_AMD_FLAT_K_LOG2"); return e && *e ? atoi(e) : 0; }();
+  const int flat_k_log2 = std::max(0, std::min(3, flat_k_env));
   const size_t flat_row_bytes = ((size_t)flat_nbp << flat_k_log2) * (weighted ? 8 : 2);  // LDS per row of a workgroup
   bool flat_ok = (D == 1 || D == 2) && !small && n_cols >= 1 && n_cols < 65536 && (sdt != XHIST_F32 || use_f32) && flat_row_bytes <= 4096 &&
                  (!weighted || wdt == XHIST_F32 || wdt == XHIST_F64);

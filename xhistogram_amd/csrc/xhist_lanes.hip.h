@@ -239,11 +239,10 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
 // 16-byte aligned): a workgroup takes R consecutive rows — one contiguous piece of memory per array — and streams it with
 // aligned vector loads exactly like a long row, whatever the row length; a sample's row is its position divided by the row
 // length (one multiply-high: position * ceil(2^40 / columns) >> 40, exact below 2^22 positions), and its counter lives in an
-// LDS histogram [R rows][K copies][bins].  Counts are uint16, two per word (a row has < 65536 samples); the lanes of a
-// wavefront read neighbouring samples, i.e. one or two rows at a time, so their adds would meet on a row's few bins: lane l
-// uses copy l mod K (K = 4 for rows of 256+ samples).  Weighted sums are float64, one copy (same-address float64 adds are not
-// slower than scattered ones: tools/ubench/ldsatomic).  The finished [R x bins] block is written once, with plain coalesced
-// stores.  Against hist_lanes_rows1 (128-byte pieces of 256 rows turned around in LDS, two barriers per piece): 10^6 rows of
+// LDS histogram [R rows][K copies][bins].  Counts are uint16, two per word (a row has < 65536 samples), weighted sums
+// float64.  The lanes of a wavefront read neighbouring samples, i.e. one or two rows at a time, and meet on a row's few bins;
+// K copies (lane l on copy l mod K) were built against that and measured useless (K = 1 is as fast or faster: see the host
+// side), so K = 1.  The finished [R x bins] block is written once, with plain coalesced stores.  Against hist_lanes_rows1 (128-byte pieces of 256 rows turned around in LDS, two barriers per piece): 10^6 rows of
 // 365 float32, 50 bins 0.79 -> 0.40 ms per call (1.86 GB in + out at 4.6 TB/s wall, ~5.3 by the kernel); against one
 // 64-thread workgroup per row (weights, joint histograms) see DESIGN.  The host keeps it to rows of up to 800 samples.
 template <typename ST, typename WT, int D, int SCAN>
