@@ -5,7 +5,8 @@
 //   random        uniform over the 16 Ki bins (C5's adding-up pass with uniform samples)
 //   normal        a sum of four uniforms, sigma ~ 1/14 of the range (bins of a Gaussian sample, C3 / C5 as benched)
 //   lane_private  bin % 32 == lane % 32: conflict-free for 8-byte slots (what the lane-bank copies of hist_fast give C2)
-//   one           every lane the same bin
+//   one           every lane the same bin;  few4 / few16 / few64: that many bins (the rank counters of a routing pass with as
+//                 many partitions);  random_but_1pct_on_one_address: the adding-up pass with a trash slot
 // Output: one JSON line per variant with atomics per clock and CU (clock from s_memtime) and the wall rate in G/s.
 // Build: hipcc --offload-arch=gfx950 -O3 -o ldsatomic ldsatomic.hip
 #include <hip/hip_runtime.h>
@@ -18,7 +19,7 @@
 constexpr int kBins = 16384;
 extern __shared__ unsigned char smem[];
 
-enum { RANDOM = 0, NORMAL = 1, LANE_PRIVATE = 2, ONE = 3 };
+enum { RANDOM = 0, NORMAL = 1, LANE_PRIVATE = 2, ONE = 3, FEW4 = 4, FEW16 = 5, FEW64 = 6, MOSTLY_RANDOM = 7 };
 
 __device__ __forceinline__ uint32_t lcg(uint32_t& s) {
   s = s * 1664525u + 1013904223u;
@@ -49,6 +50,10 @@ __global__ void __launch_bounds__(1024) lds_adds(int iters, double* sink, unsign
         const uint32_t r2 = lcg(s);
         bin[k] = (((r >> 20) + ((r >> 8) & 0xfffu) + (r2 >> 20) + ((r2 >> 8) & 0xfffu)) >> 4) + 6144u;  // 4 x U[0, 4096) / 16: sigma ~ 148 bins
       } else if (PATTERN == LANE_PRIVATE) bin[k] = ((r >> 18) & ~31u) | lane;
+      else if (PATTERN == FEW4) bin[k] = 777u + (r >> 30) * 33u;         // 4 addresses (a routing pass with 4 partitions)
+      else if (PATTERN == FEW16) bin[k] = 777u + (r >> 28) * 33u;        // 16 addresses
+      else if (PATTERN == FEW64) bin[k] = 777u + (r >> 26) * 33u;        // 64 addresses
+      else if (PATTERN == MOSTLY_RANDOM) bin[k] = (r & 0xffu) < 3u ? 16000u : (r >> 18);  // ~1 % of the adds on ONE address
       else bin[k] = 777u;
     }
 #pragma unroll
@@ -110,6 +115,17 @@ int main() {
     run<1, LANE_PRIVATE>("u32", "lane_private", block, cus, sink, stamps);
     run<2, RANDOM>("u32_returning", "random", block, cus, sink, stamps);
     run<2, NORMAL>("u32_returning", "normal", block, cus, sink, stamps);
+    if (block == 1024) {
+      run<1, ONE>("u32", "one", block, cus, sink, stamps);
+      run<2, ONE>("u32_returning", "one", block, cus, sink, stamps);
+      run<1, FEW4>("u32", "few4", block, cus, sink, stamps);
+      run<2, FEW4>("u32_returning", "few4", block, cus, sink, stamps);
+      run<2, FEW16>("u32_returning", "few16", block, cus, sink, stamps);
+      run<2, FEW64>("u32_returning", "few64", block, cus, sink, stamps);
+      run<1, MOSTLY_RANDOM>("u32", "random_but_1pct_on_one_address", block, cus, sink, stamps);
+      run<0, MOSTLY_RANDOM>("f64", "random_but_1pct_on_one_address", block, cus, sink, stamps);
+      run<0, FEW16>("f64", "few16", block, cus, sink, stamps);
+    }
   }
   return 0;
 }
