@@ -274,7 +274,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
   if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   const int64_t n_tiles = ((n_cols + tile - 1) / tile) * rows;
-  const int per_cu = std::max<int>(1, std::min<int>(4, (int)((size_t)160 * 1024 / lds_route)));
+  // workgroups resident per CU: by LDS — and by registers: the routing pass is held to 128 per lane (waves_per_eu 4), so a
+  // CU holds 1024 of its threads.  (Sized by LDS alone, a 77 KB workgroup of 1024 threads got a grid of 2 per CU, ran it
+  // in two rounds, and 10^7 float64 pairs + weights into 512 x 512 bins took 0.233 ms against 0.170 for the three-pass route.)
+  const int per_cu = std::max<int>(1, std::min<int>(std::min<int>(4, 1024 / block), (int)((size_t)160 * 1024 / lds_route)));
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
   const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_total + 65535) / 65536));
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
@@ -1043,7 +1046,12 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     const double n_all = (double)n_rows * (double)n_cols;
     const int64_t rows_per_pass = (n_rows > 1 && n_cols < ((int64_t)1 << 27) && parts_per_row * 2 <= 128) ? std::max<int64_t>(1, 128 / parts_per_row) : 1;
     const double t_part = n_all * per_part + (double)((n_rows + rows_per_pass - 1) / rows_per_pass) * 1.0e-4;
-    bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? (double)S * n_all * per_slice <= t_part : S <= 16));
+    // every slice pass ends with one global atomic per non-empty bin and workgroup (~2 x 10^11 a second for the chip) and costs
+    // ~13 us to launch: 10^7 float64 pairs into 512 x 512 counts, 5 slices 0.377 ms against 0.112 partitioned
+    const double slice_wgs = (double)std::max<int64_t>(p->cus, n_rows);
+    const double slice_bins_each = (double)((p->n_bins + S - 1) / S);
+    const double t_slice_fixed = 13e-6 + slice_wgs * std::min(slice_bins_each, n_all / slice_wgs) / 2.0e11;
+    bool choose = slices_pref > 0 ? S <= 64 : (partition > 0 ? false : (part_ok ? (double)S * (n_all * per_slice + t_slice_fixed) <= t_part : S <= 16));
     if (choose && slices_pref == 0) {
       // few samples: S launches cost S x ~13 us before they stream anything, memory-side atomics 2.4-2.7 x 10^10
       // per second (10^5 samples, 256 x 256 weighted bins: 4 slices 54 us, global atomics 13 us)
