@@ -562,6 +562,37 @@ def test_dense_short_rows_flat_in_row_blocks(xh):
         assert_hist_equal(gotw.cpu().numpy(), wantw, True)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_accumulate_into_an_existing_output_short_rows_and_leading_axis(xh, weighted):
+    """xhist_plan_execute(accumulate=1) adds to what the output holds (the C ABI's contract for callers that bin a stream in
+    pieces): through the flat short-row kernel and through the row-per-lane kernels, whose plain-store flush must turn into
+    adds — twice the same call gives twice the histogram."""
+    from xhistogram_amd import _native
+
+    rng = np.random.default_rng(12)
+    edges = np.linspace(-3, 3, 41)
+    plan = xh._get_plan([edges], _native.CMP_F64, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for shape, lead in [((5000, 100), False), ((300, 6000), True)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        w = rng.uniform(0, 1, shape).astype(np.float32) if weighted else None
+        xt, wt = _dev(x), (None if w is None else _dev(w))
+        if lead:  # rows are the contiguous direction: reduce over the leading axis
+            rows, cols, rs, cs = shape[1], shape[0], 1, shape[1]
+            want = onp.histogram(x, bins=edges, axis=0, weights=w)[0]
+        else:
+            rows, cols, rs, cs = shape[0], shape[1], shape[1], 1
+            want = onp.histogram(x, bins=edges, axis=1, weights=w)[0]
+        out = torch.zeros((rows, 40), dtype=torch.float64 if weighted else torch.int64, device="cuda")
+        xv = [_native.make_view(xt.data_ptr(), _native.F32, rs, cs)]
+        wv = _native.make_view(wt.data_ptr(), _native.F32, rs, cs) if weighted else None
+        for k in (1, 2, 3):
+            plan.execute(xv, wv, rows, cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=True, stream=stream)
+            torch.cuda.synchronize()
+            assert ("family=lanes" if lead else "family=flat_rows") in plan.describe(), plan.describe()
+            assert_hist_equal(out.cpu().numpy(), k * want, weighted)
+
+
 def test_dense_short_rows_flat_any_length_when_forced(xh):
     """"flat_rows" = 1: any row length below 65536 (the multiply-high row index, several iterations per row)"""
     rng = np.random.default_rng(9)
