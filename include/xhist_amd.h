@@ -205,7 +205,7 @@ int xhist_pointer_device(const void* ptr, int* device);
 /* ---- diagnostics / tuning (not part of the reference contract) ----------------------------- */
 /* keys: "block_threads", "grid_blocks" (0 = auto), "force_global" (0/1), "force_generic" (0/1),
  *       "partition" (0 auto / 1 prefer / -1 never: multi-pass mode for histograms beyond LDS),
- *       "fused" (0 auto / -1 never: that mode in one routing pass instead of count + prefix + scatter),
+ *       "fused" (0 auto / 1 always / -1 never: that mode in one routing pass instead of count + prefix + scatter),
  *       "records48" (0 auto / -1 never: that pass moves float64 weights as 8-byte records — 36 mantissa bits next to the bin code,
  *       2^-37 relative per weight — while a call's weights have one sign, decided on the GPU; both signs fall back to full
  *       float64 records in the same call; XHIST_AMD_EXACT_RECORDS=1 is the process-wide "never"),

@@ -1348,6 +1348,27 @@ def test_partitioned_mode_finer_partitions(xh, weights, rows, min_parts):
     assert_hist_equal(got, want, w is not None)
 
 
+def test_partitioned_mode_small_float64_weighted_calls_take_three_passes(xh):
+    """left to itself, a single row of fewer than 1.5 x 10^7 float64 samples with float64 weights goes through count + prefix +
+    scatter (9-15 % faster there than the routing pass, whose fixed costs show); more samples, other dtypes, or "fused" = 1
+    take the one-pass route.  Same histogram either way."""
+    rng = np.random.default_rng(72)
+    n = 4_500_000
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    w = rng.uniform(0, 1, (1, n))
+    want = onp.bincount_rows([x, y], edges, w)
+    got, desc = _run(xh, [x, y], edges, w, True)
+    assert "hist=partitioned" in desc and "route=fused" not in desc, desc
+    assert_hist_equal(got, want, True)
+    got, desc = _run(xh, [x, y], edges, w, True, fused=1)
+    assert "hist=partitioned" in desc and "route=fused" in desc, desc
+    assert_hist_equal(got, want, True)
+    got, desc = _run(xh, [x.astype(np.float32), y.astype(np.float32)], edges, w.astype(np.float32), True)
+    assert "route=fused" in desc, desc
+    assert_hist_equal(got, onp.bincount_rows([x.astype(np.float32), y.astype(np.float32)], edges, w.astype(np.float32)), True)
+
+
 @pytest.mark.parametrize("weighted", [False, True])
 def test_partitioned_mode_finer_partitions_three_pass_route(xh, weighted):
     """the count + prefix + scatter form of the partitioned mode ("fused" = -1) takes the finer partitions as well"""

@@ -1125,7 +1125,13 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       // rows that follow each other at one stride go through the routing pass several at a time
       // (32 x 3*10^7 float32 pairs + weights, 300 x 300 bins: 8.05 -> 6.02 ms; 8 x 6*10^7 float64, 512 x 512: 5.17 -> 4.18;
       // rows of 5*10^8 samples gain nothing — 8.63 -> 8.95 ms with 128 partitions in flight — and stay one per pass)
-      bool uniform_rows = fused_pref >= 0 && n_rows > 1 && n_parts * 2 <= 128 && n_cols < ((int64_t)1 << 27) && (!weighted || weights->inner_rows == 0);
+      // a single row of float64 samples with float64 weights below ~1.5 x 10^7 samples: the routing pass's fixed costs (chunk
+      // pool, lists, one partial chunk per workgroup and partition) show, and count + prefix + scatter is 9-15 % faster
+      // (5*10^6: 0.155 | 0.132 ms, 10^7: 0.191 | 0.174, 2*10^7: 0.273 | 0.269: profiles/r03_h_fused_vs_three_pass_mid_sizes.txt);
+      // every other dtype combination is ahead with one pass from 5*10^6 samples on
+      const bool three_pass = fused_pref == 0 && partition == 0 && n_rows == 1 && weighted && sdt == XHIST_F64 && wdt == XHIST_F64 && n_cols < 15000000;
+      const int fused_use = three_pass ? -1 : fused_pref;
+      bool uniform_rows = fused_use >= 0 && n_rows > 1 && n_parts * 2 <= 128 && n_cols < ((int64_t)1 << 27) && (!weighted || weights->inner_rows == 0);
       for (int d = 0; d < D; ++d) uniform_rows &= samples[d].inner_rows == 0;
       static const bool batch_off = [] { const char* e = getenv("XHIST_AMD_ROW_BATCH"); return e && *e == '0'; }();
       if (batch_off) uniform_rows = false;
@@ -1169,7 +1175,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         void* row_out = static_cast<char*>(out) + (size_t)r * p->n_bins * 8;
         // one routing pass (44 B per C5 sample) where it applies, else count + prefix + scatter (52.5 B); the
         // choice depends on the plan and the dtypes only, so every row of a call takes the same route
-        rc = fused_pref >= 0 ? execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan,
+        rc = fused_use >= 0 ? execute_partitioned_fused(p, row_s, weighted ? &row_w : nullptr, n_cols, row_out, stream, sdt, wdt, r_scan,
                                                          r_f32, *r_tset, shift, (int)n_parts, profile, rec, r == 0, r == n_rows - 1, geom)
                              : XHIST_ERR_UNSUPPORTED;
         if (rc == XHIST_ERR_UNSUPPORTED)

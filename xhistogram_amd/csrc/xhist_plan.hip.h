@@ -369,7 +369,7 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->profile_stride = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20));
     p->n_seen = 0;
   } else if (!strcmp(key, "fused")) {
-    p->fused_pref = value < 0 ? -1 : 0;
+    p->fused_pref = value < 0 ? -1 : (value > 0 ? 1 : 0);
   } else if (!strcmp(key, "records48")) {
     p->records48_pref = value < 0 ? -1 : 0;
     if (p->mixed_hint) *p->mixed_hint = 0u;  // (setting the knob also forgets what earlier calls saw)
