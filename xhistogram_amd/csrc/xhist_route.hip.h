@@ -732,8 +732,12 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
             const uint32_t within = (Qg & ((1u << qlg) - 1u)) << 2;
             live[g] = (Q + (uint32_t)g * 1024u < totalq) & (within < (uint32_t)(e >> 32));
             const uint64_t at = ((uint64_t)(uint32_t)e << lg) + (live[g] ? within : 0u);
-            if constexpr (!PACK) cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
-            wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
+            // (8-byte weights — 32 bytes a lane and load — are 3 % faster with their loads under the `if` after all: packed
+            // C5 records 0.704-0.712 ms against 0.728-0.735; 4-byte weights the other way round, 0.489 against 0.502)
+            if (sizeof(RT) < 8 || live[g]) {
+              if constexpr (!PACK) cv[g] = __builtin_nontemporal_load(reinterpret_cast<const c4*>(codes + at));
+              wq[g] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(wrec + at));
+            }
           }
 #pragma unroll
           for (int g = 0; g < kGroups; ++g)
