@@ -1995,6 +1995,9 @@ def test_resident_short_cut_equals_the_general_path(xh, dtype):
         ((xt, yt), dict(bins=[e1, e2], axis=(1, 2), weights=wt, density=True)),
         ((xt, yt), dict(bins=[e1, e2], density=True)),
         ((xt,), dict(bins=e1.astype(np.float32), axis=-1)),
+        ((xt,), dict(bins=e1, axis=0)),                                     # leading axes: rows are the contiguous direction
+        ((xt,), dict(bins=e1, axis=(0, 1), weights=wt)),
+        ((xt, yt), dict(bins=[e1, e2], axis=(1, 0), weights=wt, density=True)),
     ]
     for args, kw in cases:
         assert xh._resident_fast_path(args, kw["bins"], None, xh._normalise_axis(kw.get("axis"), 3), kw.get("weights"), kw.get("density", False), "auto") is not None
@@ -2011,7 +2014,8 @@ def test_resident_short_cut_equals_the_general_path(xh, dtype):
     # what the short cut must leave alone
     assert xh._resident_fast_path((xt[:, :, ::2],), e1, None, None, None, False, "auto") is None      # not contiguous
     assert xh._resident_fast_path((xt,), 10, None, None, None, False, "auto") is None                 # integer bins
-    assert xh._resident_fast_path((xt,), e1, None, [0], None, False, "auto") is None                  # leading axis
+    assert xh._resident_fast_path((xt,), e1, None, [1], None, False, "auto") is None                  # an axis in the middle
+    assert xh._resident_fast_path((xt,), e1, None, [0, 2], None, False, "auto") is None               # axes apart
     assert xh._resident_fast_path((xt,), e1, None, None, wt[0], False, "auto") is None                # broadcast weights
     assert xh._resident_fast_path((xt.to(torch.float16),), e1, None, None, None, False, "auto") is None
     with pytest.raises(ValueError):

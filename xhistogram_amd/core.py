@@ -1155,13 +1155,21 @@ def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
         if wtag is None:
             return None
     ndim = a0.ndim
+    leading = False
     if axis is None:
         kept = 0
     else:
         k = len(axis)
-        if k == 0 or sorted(axis) != list(_range(ndim - k, ndim)):
-            return None  # (non-trailing reductions have their own view logic)
-        kept = ndim - k
+        if k == 0:
+            return None
+        order = sorted(axis)
+        if order == list(_range(ndim - k, ndim)):
+            kept = ndim - k
+        elif order == list(_range(k)):  # the LEADING axes (dim="time" of (time, lat, lon)): rows are the contiguous direction
+            leading = True
+            kept = k
+        else:
+            return None  # (reduced axes in the middle or apart have their own view logic)
     sig, per_input = _fast_signature(bins, len(args))
     if sig is None:
         return None
@@ -1171,6 +1179,14 @@ def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
         hit = _FAST.get(key)
         if hit is not None:
             _FAST.move_to_end(key)
+            cur = _plans.get(hit[2])
+            if cur is None:  # the plan cache dropped these edges since: back in, so that both caches hold ONE object
+                _plans[hit[2]] = hit[0]
+                while len(_plans) > _PLAN_CACHE:
+                    _plans.popitem(last=False)
+            elif cur is not hit[0]:  # ... and rebuilt them
+                hit = (cur, hit[1], hit[2])
+                _FAST[key] = hit
     if hit is None:
         # first call with these edges: numpy validates them exactly as in the general path
         edges = [np.histogram_bin_edges(np.zeros(0, np.float64), bins=b, range=None) for b in per_input]
@@ -1178,24 +1194,33 @@ def _resident_fast_path(args, bins, range_, axis, weights, density, block_size):
         if cmp_domain != _native.CMP_F64:
             return None
         _native.require_device(dev_index)
-        hit = (_get_plan(conv, cmp_domain, dev_index), edges)
+        plan_key = (dev_index, cmp_domain) + tuple((e.dtype.str, e.tobytes()) for e in conv)  # (_get_plan's key)
+        hit = (_get_plan(conv, cmp_domain, dev_index), edges, plan_key)
         with _plans_lock:
             _FAST[key] = hit
             while len(_FAST) > _PLAN_CACHE:
                 _FAST.popitem(last=False)
-    plan, edges = hit
+    plan, edges = hit[0], hit[1]
     weighted = weights is not None
-    rows = 1
-    for n in shape[:kept]:
-        rows *= int(n)
-    cols = a0.numel() // rows
+    if leading:
+        cols = 1
+        for n in shape[:kept]:
+            cols *= int(n)
+        rows = a0.numel() // cols
+        rs, cs, kept_shape = 1, rows, tuple(shape[kept:])
+    else:
+        rows = 1
+        for n in shape[:kept]:
+            rows *= int(n)
+        cols = a0.numel() // rows
+        rs, cs, kept_shape = cols, 1, tuple(shape[:kept])
     out = torch.empty((rows,) + plan.bins_shape, dtype=torch.float64 if weighted else torch.int64, device=device)
     if out.numel():
-        views = [_native.make_view(a.data_ptr(), tag, cols, 1) for a in args]
-        wview = _native.make_view(weights.data_ptr(), wtag, cols, 1) if weighted else None
+        views = [_native.make_view(a.data_ptr(), tag, rs, cs) for a in args]
+        wview = _native.make_view(weights.data_ptr(), wtag, rs, cs) if weighted else None
         plan.execute(views, wview, rows, cols, out.data_ptr(), weighted, _native.MEM_DEVICE, accumulate=False,
                      stream=torch.cuda.current_stream(device).cuda_stream)
-    h = out.reshape(tuple(shape[:kept]) + plan.bins_shape)
+    h = out.reshape(kept_shape + plan.bins_shape)
     if density:
         h = _density(h, edges, len(args))
     return h, list(edges)
