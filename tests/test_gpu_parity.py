@@ -1455,10 +1455,74 @@ def test_bin_estimators_on_device_resident_data_without_a_host_copy(xh, name, dt
     np.testing.assert_array_equal(h.cpu().numpy(), want_h)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["fd", "auto"])
+def test_quartile_estimators_on_device_without_a_host_copy(xh, name, dt):
+    """"fd" and "auto" need the data only through n, min, max and the quartiles (numpy/lib/_histograms_impl.py): four order
+    statistics, found exactly on the GPU by narrowing histograms (core._device_order_statistics), and np.percentile's own
+    interpolation — edges bit-identical to numpy's for sizes from 1 element up, ties, constant data, heavy tails, values
+    packed into a few ulps; the tensor itself never goes to the host (only counts and the last interval's few values do)."""
+    rng = np.random.default_rng(17)
+    cases = {
+        "one": np.array([2.5]), "two": np.array([1.0, 4.0]), "three": np.array([3.0, -1.0, 8.0]), "ten": rng.standard_normal(10),
+        "normal": rng.standard_normal(100_001) * 3 + 1, "uniform": rng.uniform(-5, 9, 250_000),
+        "ties": np.round(rng.standard_normal(300_000) * 4), "constant": np.full(5000, 1.25),
+        "mostly_constant": np.where(rng.random(200_000) < 0.9, 2.0, rng.standard_normal(200_000)),
+        "lognormal": rng.lognormal(0, 3, 400_000), "near_1e6": 1e6 + rng.standard_normal(150_000) * 1e-3,
+        "few_ulps": 1.0 + rng.integers(0, 7, 100_000) * np.finfo(dt).eps, "big": rng.standard_normal(3_000_000),
+        "two_d": rng.standard_normal((300, 1001)),
+    }
+    for label, a in cases.items():
+        a = a.astype(dt)
+        t = _dev(a)
+        try:
+            want = np.histogram_bin_edges(a, bins=name)
+        except ValueError as err:  # ("Too many bins for data range": values a few ulps apart) — the same error, then
+            with pytest.raises(ValueError, match=str(err)[:20]):
+                xh._device_quartile_edges(t, name, None, np.dtype(dt), False)
+            continue
+        n_before = t.numel()
+        got = xh._device_quartile_edges(t, name, None, np.dtype(dt), False)
+        assert got is not None, label
+        assert got.dtype == want.dtype, label
+        np.testing.assert_array_equal(got, want, err_msg=label)
+        assert t.numel() == n_before
+    # the public entry point takes it; ranges, integer data and DeviceArrays still go through numpy on a host copy
+    a = cases["normal"].astype(dt)
+    h, edges = xh.histogram(_dev(a), bins=name)
+    want_h, want_e = np.histogram(a, bins=name)
+    np.testing.assert_array_equal(edges[0] if isinstance(edges, (list, tuple)) else edges, want_e)
+    np.testing.assert_array_equal(h.cpu().numpy(), want_h)
+    assert xh._device_quartile_edges(_dev(a), name, (-1.0, 1.0), np.dtype(dt), False) is None
+    np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, (-1.0, 1.0), False), np.histogram_bin_edges(a, bins=name, range=(-1.0, 1.0)))
+    with pytest.raises(ValueError):
+        xh._device_bin_edges(_dev(np.array([1.0, np.nan, 2.0], dtype=dt)), name, None, False)  # numpy's own error for non-finite data
+
+
+def test_order_statistics_on_device(xh):
+    """every rank of small arrays and scattered ranks of big ones, against np.sort"""
+    rng = np.random.default_rng(18)
+    for dt in (np.float64, np.float32):
+        for a in (rng.standard_normal(1000), np.round(rng.standard_normal(5000) * 2), rng.lognormal(0, 5, 200_000), rng.standard_normal(2_000_000)):
+            a = a.astype(dt)
+            srt = np.sort(a)
+            ranks = list(range(len(a))) if len(a) <= 5000 else [0, 1, 17, len(a) // 4, len(a) // 2, len(a) - 2, len(a) - 1] + list(rng.integers(0, len(a), 20))
+            if len(ranks) > 60:
+                ranks = ranks[::len(ranks) // 60]
+            got = xh._device_order_statistics(_dev(a).reshape(-1), ranks, float(srt[0]), float(srt[-1]), len(a))
+            assert got is not None
+            for r in ranks:
+                assert got[int(r)] == float(srt[int(r)]), (dt, len(a), r)
+
+
 def test_bin_estimators_that_need_the_data_still_work(xh):
-    """"fd" / "auto" / "doane" / "stone" (percentiles, third moments): numpy's implementation on a host copy, same edges"""
+    """"doane" / "stone" (third moments, a search over bin counts) — and "fd" / "auto" of integer data: numpy's implementation on a
+    host copy, same edges"""
     rng = np.random.default_rng(8)
     a = rng.standard_normal(20_000)
+    ai = rng.integers(-50, 90, 20_000)
+    for name in ("fd", "auto"):
+        np.testing.assert_array_equal(xh._device_bin_edges(_dev(ai), name, None, False), np.histogram_bin_edges(ai, bins=name))
     for name in ("fd", "auto", "doane", "stone"):
         np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), np.histogram_bin_edges(a, bins=name))
     with pytest.raises(TypeError):
