@@ -1499,6 +1499,38 @@ def test_quartile_estimators_on_device_without_a_host_copy(xh, name, dt):
         xh._device_bin_edges(_dev(np.array([1.0, np.nan, 2.0], dtype=dt)), name, None, False)  # numpy's own error for non-finite data
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_doane_and_stone_estimators_on_device(xh, dt):
+    """"doane" from float64 reductions on the device (declining when the bin count hangs on numpy's own summation order),
+    "stone" from this library's histograms of 1 ... max(100, sqrt(n)) uniform bins (exact counts: numpy's very numbers)."""
+    import warnings
+
+    rng = np.random.default_rng(19)
+    cases = {"one": np.array([2.5]), "two": np.array([1.0, 4.0]), "three": np.array([3.0, -1.0, 8.0]), "normal": rng.standard_normal(60_001) * 3 + 1,
+             "skewed": rng.lognormal(0, 1, 80_000), "uniform": rng.uniform(-5, 9, 50_000), "ties": np.round(rng.standard_normal(40_000) * 4),
+             "constant": np.full(3000, 1.25), "bimodal": np.concatenate([rng.normal(-3, 0.5, 30_000), rng.normal(4, 1.5, 20_000)])}
+    declined = 0
+    for label, a in cases.items():
+        a = a.astype(dt)
+        for name in ("doane", "stone"):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = np.histogram_bin_edges(a, bins=name)
+                got = xh._device_doane_stone_edges(_dev(a), name, None, np.dtype(dt), False)
+            if got is None:  # (allowed for "doane" only: a tie, or nearly constant data)
+                assert name == "doane", label
+                declined += 1
+                continue
+            assert got.dtype == want.dtype, (label, name)
+            np.testing.assert_array_equal(got, want, err_msg="%s %s" % (label, name))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), want)
+    assert declined <= 2
+    big = _dev(rng.standard_normal(20_000_000).astype(dt))
+    assert xh._device_doane_stone_edges(big, "stone", None, np.dtype(dt), False) is None  # 4472 candidates: left to numpy
+
+
 def test_order_statistics_on_device(xh):
     """every rank of small arrays and scattered ranks of big ones, against np.sort"""
     rng = np.random.default_rng(18)
