@@ -1493,8 +1493,13 @@ def test_quartile_estimators_on_device_without_a_host_copy(xh, name, dt):
     want_h, want_e = np.histogram(a, bins=name)
     np.testing.assert_array_equal(edges[0] if isinstance(edges, (list, tuple)) else edges, want_e)
     np.testing.assert_array_equal(h.cpu().numpy(), want_h)
-    assert xh._device_quartile_edges(_dev(a), name, (-1.0, 1.0), np.dtype(dt), False) is None
+    for r in ((-1.0, 1.0), (0, 30), (2.0, 2.0), (50.0, 60.0), (-100, 100)):  # a range: the selector sees the data cut to it (possibly none of it)
+        got = xh._device_quartile_edges(_dev(a), name, r, np.dtype(dt), False)
+        assert got is not None, r
+        np.testing.assert_array_equal(got, np.histogram_bin_edges(a, bins=name, range=r), err_msg=str(r))
     np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, (-1.0, 1.0), False), np.histogram_bin_edges(a, bins=name, range=(-1.0, 1.0)))
+    with pytest.raises(ValueError):
+        xh._device_quartile_edges(_dev(a), name, (3.0, 1.0), np.dtype(dt), False)  # numpy's "max must be larger than min"
     with pytest.raises(ValueError):
         xh._device_bin_edges(_dev(np.array([1.0, np.nan, 2.0], dtype=dt)), name, None, False)  # numpy's own error for non-finite data
 

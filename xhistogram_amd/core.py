@@ -759,9 +759,8 @@ def _device_bin_edges(a, b, r, has_weights):
             edges = _device_doane_stone_edges(a, b, r, proto_dtype, resident)
         if edges is not None:
             return edges
-        # "doane" and "stone" need third moments / a search over bin counts of the DATA ("fd" and "auto" of integer data or
-        # with a range: percentiles of the cut data): they take numpy's own implementation on a host copy (so does a
-        # float64-boundary tie of "scott", see _device_estimator_edges)
+        # what is left — "doane" / "stone" with a range, quartiles or skewness of integer data, a DeviceArray, a bin count
+        # that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
         if (a.size if resident else a.numel()) == 0:
@@ -780,7 +779,7 @@ def _device_bin_edges(a, b, r, has_weights):
 
 
 ESTIMATORS_FROM_MOMENTS = ("sqrt", "sturges", "rice", "scott")
-ESTIMATORS_FROM_QUARTILES = ("fd", "auto")  # float32 / float64 torch tensors, range=None: _device_quartile_edges
+ESTIMATORS_FROM_QUARTILES = ("fd", "auto")  # float32 / float64 torch tensors: _device_quartile_edges
 
 
 def _estimator_cut(name, r, proto_dtype):
@@ -963,19 +962,30 @@ def _device_order_statistics(flat, ranks, mn, mx, n):
 
 
 def _device_quartile_edges(a, name, r, proto_dtype, resident):
-    """np.histogram_bin_edges(a, bins="fd" | "auto", range=None) for a float32 / float64 GPU tensor without a host copy:
+    """np.histogram_bin_edges(a, bins="fd" | "auto", range=r) for a float32 / float64 GPU tensor without a host copy:
     numpy's selectors (numpy/lib/_histograms_impl.py: _hist_bin_fd, _hist_bin_auto) need the data only through its size,
     min, max and the two quartiles, and np.percentile's default method needs four order statistics for those — found
     exactly by _device_order_statistics — and its own interpolation (numpy/lib/_function_base_impl.py: _lerp), restated here
-    with numpy's dtypes.  None: not that case (other estimator, dtype, a range, a DeviceArray)."""
-    if name not in ESTIMATORS_FROM_QUARTILES or resident or r is not None or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+    with numpy's dtypes.  With a range the selector sees the data cut to it.  None: not that case (other estimator, dtype,
+    a DeviceArray)."""
+    if name not in ESTIMATORS_FROM_QUARTILES or resident or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
         return None
-    n = a.numel()
+    size = a.numel()
+    if size == 0:
+        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=r)
+    lo_hi = None
+    if r is not None:  # the selector sees the data cut to the range (numpy validates it: its own errors)
+        if np.ndim(r[0]) or np.ndim(r[1]):
+            return None
+        np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
+        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+    n, mn, mx, _, _ = _device_moments(a, lo_hi, False)
+    n = int(n)
     if n == 0:
-        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=None)
-    _, mn, mx, _, _ = _device_moments(a, None, False)
+        return _edges_from_moments(name, r, proto_dtype, size, (0, mn, mx, np.nan, np.nan), iqr=0.0)
     if not (np.isfinite(mn) and np.isfinite(mx)):
-        np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
+        if r is None:
+            np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
         return None
     q = np.true_divide([75, 25], 100)
     virtual = (n - 1) * q
@@ -994,7 +1004,7 @@ def _device_quartile_edges(a, name, r, proto_dtype, resident):
     lerp = np.asanyarray(np.add(lower, diff * gamma))
     np.subtract(upper, diff * (1 - gamma), out=lerp, where=gamma >= 0.5, casting="unsafe", dtype=type(lerp.dtype))
     iqr = np.subtract(*lerp)
-    return _edges_from_moments(name, None, proto_dtype, n, (n, mn, mx, np.nan, np.nan), iqr=iqr)
+    return _edges_from_moments(name, r, proto_dtype, size, (n, mn, mx, np.nan, np.nan), iqr=iqr)
 
 
 def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
