@@ -1532,6 +1532,17 @@ def test_doane_and_stone_estimators_on_device(xh, dt):
                 warnings.simplefilter("ignore")
                 np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), want)
     assert declined <= 2
+    a = cases["skewed"].astype(dt)
+    for r in ((0.5, 3.0), (0, 30), (2.0, 2.0), (500.0, 600.0)):  # a range: the selector sees the data cut to it (possibly none of it)
+        for name in ("doane", "stone"):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = np.histogram_bin_edges(a, bins=name, range=r)
+                got = xh._device_doane_stone_edges(_dev(a), name, r, np.dtype(dt), False)
+            if got is None:
+                assert name == "doane", r
+                continue
+            np.testing.assert_array_equal(got, want, err_msg="%s %s" % (r, name))
     big = _dev(rng.standard_normal(20_000_000).astype(dt))
     assert xh._device_doane_stone_edges(big, "stone", None, np.dtype(dt), False) is None  # 4472 candidates: left to numpy
 

@@ -759,8 +759,8 @@ def _device_bin_edges(a, b, r, has_weights):
             edges = _device_doane_stone_edges(a, b, r, proto_dtype, resident)
         if edges is not None:
             return edges
-        # what is left — "doane" / "stone" with a range, quartiles or skewness of integer data, a DeviceArray, a bin count
-        # that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
+        # what is left — quartiles or skewness of integer data, a DeviceArray, "stone" of more than 1.6 x 10^7 elements, a bin
+        # count that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
         if (a.size if resident else a.numel()) == 0:
@@ -1008,7 +1008,7 @@ def _device_quartile_edges(a, name, r, proto_dtype, resident):
 
 
 def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
-    """np.histogram_bin_edges(a, bins="doane" | "stone", range=None) for a float32 / float64 GPU tensor without a host copy
+    """np.histogram_bin_edges(a, bins="doane" | "stone", range=r) for a float32 / float64 GPU tensor without a host copy
     (numpy/lib/_histograms_impl.py: _hist_bin_doane, _hist_bin_stone).
     "doane" needs the skewness: mean, standard deviation and third moment are reduced on the device in float64; numpy sums
     them in the data's own precision and order, so a bin count that hangs on the last digits (or nearly constant data) is
@@ -1016,14 +1016,24 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
     "stone" minimises a loss over 1 ... max(100, sqrt(n)) bin counts, each needing the histogram of that many uniform bins:
     those are this library's own kernels — exact counts, hence numpy's very numbers — for up to 4000 candidates
     (n <= 1.6 x 10^7; numpy itself needs n / 4 seconds there)."""
-    if name not in ("doane", "stone") or resident or r is not None or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+    if name not in ("doane", "stone") or resident or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
         return None
-    n = a.numel()
+    size = a.numel()
+    if size == 0:
+        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=r)
+    lo_hi = None
+    if r is not None:  # the selector sees the data cut to the range (numpy validates it: its own errors)
+        if np.ndim(r[0]) or np.ndim(r[1]):
+            return None
+        np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
+        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+    n, mn, mx, _, _ = _device_moments(a, lo_hi, False)
+    n = int(n)
     if n == 0:
-        return np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=name, range=None)
-    _, mn, mx, _, _ = _device_moments(a, None, False)
+        return _edges_from_moments(name, r, proto_dtype, size, (0, mn, mx, np.nan, np.nan), width_of=lambda ptp: 0.0)
     if not (np.isfinite(mn) and np.isfinite(mx)):
-        np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
+        if r is None:
+            np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
         return None
     torch = _torch()
     flat = a.reshape(-1)
@@ -1033,6 +1043,8 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
                 return 0.0
             sg1 = np.sqrt(6.0 * (n - 2) / ((n + 1.0) * (n + 3)))
             xd = flat.to(torch.float64)
+            if lo_hi is not None:
+                xd = xd[(xd >= lo_hi[0]) & (xd <= lo_hi[1])]
             mean = xd.mean()
             sigma = float(torch.sqrt(((xd - mean) ** 2).mean()))
             if not sigma > 1e-5 * max(abs(mx), abs(mn)):
@@ -1044,7 +1056,7 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
         if upper > 4000:
             return None
         as_scalar = proto_dtype.type
-        first, last = as_scalar(mn), as_scalar(mx)
+        first, last = (as_scalar(mn), as_scalar(mx)) if r is None else (r[0], r[1])  # (numpy hands the selector the OUTER edges)
         if first == last:
             first, last = first - 0.5, last + 0.5
 
@@ -1062,7 +1074,7 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
             if nbins == upper:
                 warnings.warn("The number of bins estimated may be suboptimal.", RuntimeWarning, stacklevel=3)
             return ptp / nbins
-    return _edges_from_moments(name, None, proto_dtype, n, (n, mn, mx, np.nan, np.nan), width_of=width_of)
+    return _edges_from_moments(name, r, proto_dtype, size, (n, mn, mx, np.nan, np.nan), width_of=width_of)
 
 
 def _device_estimator_edges(a, name, r, proto_dtype, resident):
