@@ -1547,6 +1547,22 @@ def test_doane_and_stone_estimators_on_device(xh, dt):
     assert xh._device_doane_stone_edges(big, "stone", None, np.dtype(dt), False) is None  # 4472 candidates: left to numpy
 
 
+@pytest.mark.parametrize("dt", [np.int32, np.int64, np.uint8, np.int16])
+@pytest.mark.parametrize("name", ["fd", "auto"])
+def test_quartile_estimators_of_integer_data_on_device(xh, name, dt):
+    """integer data: order statistics by the same search (float64 edges tell integers below 2^53 apart), np.percentile's
+    interpolation in float64, numpy's width >= 1 rule for integer data"""
+    rng = np.random.default_rng(21)
+    lo, hi = (0, 250) if dt == np.uint8 else (-3000, 9000)
+    for a in (rng.integers(lo, hi, 100_003), rng.integers(lo, lo + 3, 5000), np.array([7, 7, 7, 7]), rng.integers(lo, hi, 11), np.array([5])):
+        a = a.astype(dt)
+        for r in (None, (lo + 10, hi - 20)):
+            want = np.histogram_bin_edges(a, bins=name, range=r)
+            got = xh._device_quartile_edges(_dev(a), name, r, np.dtype(dt), False)
+            assert got is not None and got.dtype == want.dtype, (len(a), r)
+            np.testing.assert_array_equal(got, want, err_msg=str((len(a), r)))
+
+
 def test_order_statistics_on_device(xh):
     """every rank of small arrays and scattered ranks of big ones, against np.sort"""
     rng = np.random.default_rng(18)
@@ -1569,7 +1585,7 @@ def test_bin_estimators_that_need_the_data_still_work(xh):
     rng = np.random.default_rng(8)
     a = rng.standard_normal(20_000)
     ai = rng.integers(-50, 90, 20_000)
-    for name in ("fd", "auto"):
+    for name in ("doane", "stone"):
         np.testing.assert_array_equal(xh._device_bin_edges(_dev(ai), name, None, False), np.histogram_bin_edges(ai, bins=name))
     for name in ("fd", "auto", "doane", "stone"):
         np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), np.histogram_bin_edges(a, bins=name))

@@ -759,7 +759,7 @@ def _device_bin_edges(a, b, r, has_weights):
             edges = _device_doane_stone_edges(a, b, r, proto_dtype, resident)
         if edges is not None:
             return edges
-        # what is left — quartiles or skewness of integer data, a DeviceArray, "stone" of more than 1.6 x 10^7 elements, a bin
+        # what is left — "doane" / "stone" of integer data, a DeviceArray, "stone" of more than 1.6 x 10^7 elements, a bin
         # count that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
@@ -913,6 +913,7 @@ def _device_order_statistics(flat, ranks, mn, mx, n):
     torch = _torch()
     B, small = 1 << 15, 1 << 16
     is32 = flat.dtype == torch.float32
+    is_int = not flat.dtype.is_floating_point
 
     def bounds32(lo, top):  # lo <= x <= top for float32 x, decided exactly by float32 scalars
         lo32, top32 = np.float32(lo), np.float32(top)
@@ -949,7 +950,7 @@ def _device_order_statistics(flat, ranks, mn, mx, n):
             lo = float(edges[j])
             top = float(edges[j + 1]) if j + 1 == len(edges) - 1 else float(np.nextafter(edges[j + 1], -np.inf))  # bins are [e_j, e_j+1), the last one closed
             if int(counts[j]) <= small:
-                l, t = bounds32(lo, top) if is32 else (lo, top)
+                l, t = bounds32(lo, top) if is32 else ((int(np.ceil(lo)), int(np.floor(top))) if is_int else (lo, top))
                 vals = np.sort(flat[(flat >= l) & (flat <= t)].cpu().numpy())
                 if len(vals) != int(counts[j]):
                     return None
@@ -962,13 +963,13 @@ def _device_order_statistics(flat, ranks, mn, mx, n):
 
 
 def _device_quartile_edges(a, name, r, proto_dtype, resident):
-    """np.histogram_bin_edges(a, bins="fd" | "auto", range=r) for a float32 / float64 GPU tensor without a host copy:
+    """np.histogram_bin_edges(a, bins="fd" | "auto", range=r) for a float or integer GPU tensor without a host copy:
     numpy's selectors (numpy/lib/_histograms_impl.py: _hist_bin_fd, _hist_bin_auto) need the data only through its size,
     min, max and the two quartiles, and np.percentile's default method needs four order statistics for those — found
     exactly by _device_order_statistics — and its own interpolation (numpy/lib/_function_base_impl.py: _lerp), restated here
     with numpy's dtypes.  With a range the selector sees the data cut to it.  None: not that case (other estimator, dtype,
     a DeviceArray)."""
-    if name not in ESTIMATORS_FROM_QUARTILES or resident or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+    if name not in ESTIMATORS_FROM_QUARTILES or resident or proto_dtype.kind not in "fiu" or proto_dtype == np.float16:
         return None
     size = a.numel()
     if size == 0:
@@ -987,6 +988,8 @@ def _device_quartile_edges(a, name, r, proto_dtype, resident):
         if r is None:
             np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
         return None
+    if proto_dtype.kind in "iu" and max(abs(mn), abs(mx)) >= 2.0 ** 53:
+        return None  # (integers the float64 edges of the search cannot tell apart)
     q = np.true_divide([75, 25], 100)
     virtual = (n - 1) * q
     previous = np.floor(virtual).astype(np.intp)
