@@ -1304,7 +1304,7 @@ def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None,
 # dtype promotion rules, stride analysis, plan lookup.  None of that can change between two calls with the same
 # edges and the same kind of input, so the outcome is cached per signature and the call goes straight to the
 # plan.  Everything this path does not recognise falls through to the general code below it.
-_FAST = OrderedDict()  # (device, bins signature) -> (plan, validated edge arrays)
+_FAST = OrderedDict()  # (device, bins signature) -> (plan, validated edge arrays, the plan cache's key of that plan)
 _FAST_TAGS = None
 
 
