@@ -1550,6 +1550,16 @@ def test_doane_and_stone_estimators_on_device(xh, dt):
 @pytest.mark.parametrize("dt", [np.int32, np.int64, np.uint8, np.int16])
 @pytest.mark.parametrize("name", ["fd", "auto"])
 def test_quartile_estimators_of_integer_data_on_device(xh, name, dt):
+    _integer_estimators(xh, name, dt, xh._device_quartile_edges)
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int64, np.uint8])
+@pytest.mark.parametrize("name", ["doane", "stone"])
+def test_doane_and_stone_of_integer_data_on_device(xh, name, dt):
+    _integer_estimators(xh, name, dt, xh._device_doane_stone_edges)
+
+
+def _integer_estimators(xh, name, dt, fn):
     """integer data: order statistics by the same search (float64 edges tell integers below 2^53 apart), np.percentile's
     interpolation in float64, numpy's width >= 1 rule for integer data"""
     rng = np.random.default_rng(21)
@@ -1557,8 +1567,13 @@ def test_quartile_estimators_of_integer_data_on_device(xh, name, dt):
     for a in (rng.integers(lo, hi, 100_003), rng.integers(lo, lo + 3, 5000), np.array([7, 7, 7, 7]), rng.integers(lo, hi, 11), np.array([5])):
         a = a.astype(dt)
         for r in (None, (lo + 10, hi - 20)):
-            want = np.histogram_bin_edges(a, bins=name, range=r)
-            got = xh._device_quartile_edges(_dev(a), name, r, np.dtype(dt), False)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = np.histogram_bin_edges(a, bins=name, range=r)
+                got = fn(_dev(a), name, r, np.dtype(dt), False)
+            if got is None and name == "doane":
+                continue  # (a tie at the ceil, or nearly constant data: numpy decides)
             assert got is not None and got.dtype == want.dtype, (len(a), r)
             np.testing.assert_array_equal(got, want, err_msg=str((len(a), r)))
 
@@ -1584,9 +1599,9 @@ def test_bin_estimators_that_need_the_data_still_work(xh):
     host copy, same edges"""
     rng = np.random.default_rng(8)
     a = rng.standard_normal(20_000)
-    ai = rng.integers(-50, 90, 20_000)
-    for name in ("doane", "stone"):
-        np.testing.assert_array_equal(xh._device_bin_edges(_dev(ai), name, None, False), np.histogram_bin_edges(ai, bins=name))
+    ah = rng.standard_normal(5000).astype(np.float16)
+    for name in ("fd", "doane"):  # float16: numpy on a host copy
+        np.testing.assert_array_equal(xh._device_bin_edges(_dev(ah), name, None, False), np.histogram_bin_edges(ah, bins=name))
     for name in ("fd", "auto", "doane", "stone"):
         np.testing.assert_array_equal(xh._device_bin_edges(_dev(a), name, None, False), np.histogram_bin_edges(a, bins=name))
     with pytest.raises(TypeError):

@@ -759,7 +759,7 @@ def _device_bin_edges(a, b, r, has_weights):
             edges = _device_doane_stone_edges(a, b, r, proto_dtype, resident)
         if edges is not None:
             return edges
-        # what is left — "doane" / "stone" of integer data, a DeviceArray, "stone" of more than 1.6 x 10^7 elements, a bin
+        # what is left — a DeviceArray, float16 data, "stone" of more than 1.6 x 10^7 elements, a bin
         # count that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
@@ -1011,7 +1011,7 @@ def _device_quartile_edges(a, name, r, proto_dtype, resident):
 
 
 def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
-    """np.histogram_bin_edges(a, bins="doane" | "stone", range=r) for a float32 / float64 GPU tensor without a host copy
+    """np.histogram_bin_edges(a, bins="doane" | "stone", range=r) for a float or integer GPU tensor without a host copy
     (numpy/lib/_histograms_impl.py: _hist_bin_doane, _hist_bin_stone).
     "doane" needs the skewness: mean, standard deviation and third moment are reduced on the device in float64; numpy sums
     them in the data's own precision and order, so a bin count that hangs on the last digits (or nearly constant data) is
@@ -1019,7 +1019,7 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
     "stone" minimises a loss over 1 ... max(100, sqrt(n)) bin counts, each needing the histogram of that many uniform bins:
     those are this library's own kernels — exact counts, hence numpy's very numbers — for up to 4000 candidates
     (n <= 1.6 x 10^7; numpy itself needs n / 4 seconds there)."""
-    if name not in ("doane", "stone") or resident or proto_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+    if name not in ("doane", "stone") or resident or proto_dtype.kind not in "fiu" or proto_dtype == np.float16:
         return None
     size = a.numel()
     if size == 0:
@@ -1037,6 +1037,8 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
     if not (np.isfinite(mn) and np.isfinite(mx)):
         if r is None:
             np.histogram_bin_edges(np.array([mn, mx]).astype(proto_dtype), bins=1, range=None)  # numpy's ValueError
+        return None
+    if proto_dtype.kind in "iu" and max(abs(mn), abs(mx)) >= 2.0 ** 53:
         return None
     torch = _torch()
     flat = a.reshape(-1)
