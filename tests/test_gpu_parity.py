@@ -2283,3 +2283,108 @@ def test_one_pass_routing_with_few_partitions_and_many_tiles(xh):
     m = 1_000_000
     hp, _ = xh.histogram(*[x[:m] for x in a], bins=edges)
     np.testing.assert_array_equal(hp.cpu().numpy(), onp.histogram(*[x[:m].cpu().numpy() for x in a], bins=edges)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# packed bucket entries (count_le_pack): float64 samples on non-uniform edges, float32 pre-compare + exact redo
+def _pack_torture(edges, rng, n_random):
+    """what the float32 pre-compare cannot decide, and everything around it: every edge, its float64 neighbours, the float32
+    image of every edge and ITS float64 and float32 neighbours, the rounding boundaries between float32 values next to an
+    edge, samples scattered within one float32 ulp of every edge, plus randoms and the usual specials"""
+    e = np.asarray(edges, dtype=np.float64)
+    with np.errstate(over="ignore"):
+        f32 = e.astype(np.float32)
+    f = f32.astype(np.float64)
+    fu = np.nextafter(f32, np.float32(np.inf)).astype(np.float64)
+    fd = np.nextafter(f32, np.float32(-np.inf)).astype(np.float64)
+    ulp = np.where(np.isfinite(fu - fd), (fu - fd) / 2, 0.0)
+    mids = [(f + fu) / 2, (f + fd) / 2]
+    parts = [e, np.nextafter(e, -np.inf), np.nextafter(e, np.inf), f, np.nextafter(f, -np.inf), np.nextafter(f, np.inf), fu, fd]
+    for m in mids:
+        parts += [m, np.nextafter(m, -np.inf), np.nextafter(m, np.inf)]
+    parts += [np.repeat(e, 8) + rng.uniform(-1.5, 1.5, e.size * 8) * np.repeat(ulp, 8),
+              rng.uniform(e[0] - 0.1 * (e[-1] - e[0]), e[-1] + 0.1 * (e[-1] - e[0]), n_random),
+              np.array([np.nan, np.inf, -np.inf, e[0], e[-1], 0.0, -0.0])]
+    x = np.concatenate(parts)
+    rng.shuffle(x)
+    return x.reshape(1, -1)
+
+
+def _sorted_uniform(rng, n, lo, hi):
+    e = np.sort(rng.uniform(lo, hi, n))
+    e[0], e[-1] = lo, hi
+    return e
+
+
+_PACK_EDGES = {
+    "c3_like_257": lambda rng: _sorted_uniform(rng, 257, -4.0, 4.0),
+    "geometric_300": lambda rng: np.geomspace(1e-3, 50.0, 300),
+    "negative_129": lambda rng: _sorted_uniform(rng, 129, -1000.0, -999.0),
+    "few_5": lambda rng: np.array([-1.0, -0.25, 0.1, 0.7, 3.0]),
+    "two_edges": lambda rng: np.array([0.3, 0.7]),
+    "big_magnitude": lambda rng: _sorted_uniform(rng, 65, 1.0e30, 3.0e30),
+    "small_magnitude": lambda rng: _sorted_uniform(rng, 65, 1.0e-30, 3.0e-30),
+    # float32 cannot tell these edges apart / hold them at all: the packed set must not be offered, results stay exact
+    "beyond_float32": lambda rng: _sorted_uniform(rng, 33, 1.0e300, 3.0e300),
+    "below_float32": lambda rng: _sorted_uniform(rng, 33, 1.0e-300, 3.0e-300),
+    "one_float32_ulp": lambda rng: 1.0 + np.sort(rng.uniform(0, 1e-8, 40)),
+    "duplicates": lambda rng: np.sort(np.concatenate([rng.uniform(-2, 2, 50), [0.5] * 4, [-1.0] * 2])),
+    "cluster_of_five": lambda rng: np.sort(np.concatenate([rng.uniform(-2, 2, 60), 0.123 + np.arange(5) * 1e-9])),
+}
+_PACK_NOT_OFFERED = {"beyond_float32", "below_float32", "one_float32_ulp", "duplicates", "cluster_of_five"}
+_PACK_EITHER = {"two_edges", "geometric_300"}  # (a linear bucket grid may or may not separate these)
+
+
+@pytest.mark.parametrize("weights", [None, "f64", "f32"])
+@pytest.mark.parametrize("kind", sorted(_PACK_EDGES))
+def test_packed_bucket_entries_1d_on_and_around_every_edge(xh, kind, weights):
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    edges = [_PACK_EDGES[kind](rng)]
+    x = _pack_torture(edges[0], rng, 100_000)
+    w = None if weights is None else rng.uniform(-1, 2, x.shape).astype(np.float64 if weights == "f64" else np.float32)
+    want = onp.bincount_rows([x], edges, w)
+    got, desc = _run(xh, [x], edges, w, True, pack=1)
+    assert_hist_equal(got, want, w is not None)
+    offered = "scan=6" in desc or "scan=7" in desc
+    if kind in _PACK_NOT_OFFERED:
+        assert not offered, desc
+    elif kind not in _PACK_EITHER:
+        assert offered and "family=fast" in desc, desc
+    got, _ = _run(xh, [x], edges, w, True, pack=-1)
+    assert_hist_equal(got, want, w is not None)
+
+
+@pytest.mark.parametrize("weights", [None, "f64"])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_packed_bucket_entries_joint(xh, dims, weights):
+    """the automatic choice for joint histograms of float64 samples on non-uniform edges (BASELINE C3's shape)"""
+    rng = np.random.default_rng(400 + dims)
+    nb = ([257, 257] if weights is None else [65, 90]) if dims == 2 else ([33, 17, 41] if weights is None else [17, 9, 21])  # (weighted: float64 sums that still fit LDS)
+    edges = [_sorted_uniform(rng, k, -4.0, 4.0) for k in nb]
+    cols = [_pack_torture(e, rng, 60_000) for e in edges]
+    n = min(c.shape[1] for c in cols)
+    samples = [c[:, :n].copy() for c in cols]
+    for d in range(1, dims):  # every edge-adjacent sample of one input meets ordinary samples of the others
+        samples[d] = np.roll(samples[d], 7919 * d, axis=1)
+    w = None if weights is None else rng.uniform(0, 1, samples[0].shape)
+    want = onp.bincount_rows(samples, edges, w)
+    got, desc = _run(xh, samples, edges, w, True)
+    assert ("scan=6" in desc or "scan=7" in desc) and "family=fast" in desc, desc
+    if dims == 2 and weights is None:
+        assert "hist=packed16" in desc, desc
+    assert_hist_equal(got, want, w is not None)
+    got, desc = _run(xh, samples, edges, w, True, pack=-1)
+    assert "scan=6" not in desc and "scan=7" not in desc, desc
+    assert_hist_equal(got, want, w is not None)
+    got, _ = _run(xh, samples, edges, w, False)  # host route
+    assert_hist_equal(got, want, w is not None)
+
+
+def test_packed_bucket_entries_many_rows_and_ragged_tiles(xh):
+    rng = np.random.default_rng(431)
+    edges = [_sorted_uniform(rng, 40, -3.0, 3.0), _sorted_uniform(rng, 23, -3.0, 3.0)]
+    for shape in [(7, 10_001), (300, 777), (1, 3), (2, 4097)]:
+        x, y = rng.standard_normal(shape), rng.standard_normal(shape)
+        x[:, ::5] = rng.choice(edges[0], size=x[:, ::5].shape)  # plenty of samples ON an edge: the exact redo runs in most wavefronts
+        got, desc = _run(xh, [x, y], edges, None, True)
+        np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges), err_msg=desc)

@@ -738,12 +738,13 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     return XHIST_OK;
   }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref, fused_pref;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref, fused_pref, pack_pref;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
     lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref; fused_pref = p->fused_pref;
+    pack_pref = p->pack_pref;
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
@@ -941,6 +942,24 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         tables_fit = true;
       } else {
         hist = h0; cl2 = c0; hist_bytes = b0;
+      }
+    }
+    // Non-uniform edges, float64 samples: packed 16-byte bucket entries (count_le_pack) — one LDS read per sample and
+    // dimension instead of two dependent ones — where the histogram stays in LDS with them.  Measured for joint histograms
+    // (C3: see DESIGN 4); 1-D histograms keep the two-level tables unless "pack" = 1.
+    if (fast && !mixed && !two && !i64dom && sdt == XHIST_F64 && p->pk_np && pack_pref >= 0 && scan != kScanArith && tables_fit &&
+        (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || pack_pref > 0)) {
+      const int h0 = hist, c0 = cl2;
+      const size_t b0 = hist_bytes, tb = (size_t)p->ts_pk.words * 8;
+      if (tb + 1024 <= lds_cap) {
+        place(tb, true);
+        if ((hist == kHistLds || hist == kHistPacked) && (hist == h0 || pack_pref > 0)) {
+          scan = p->pk_np == 2 ? kScanPack2 : kScanPack3;
+          tset = &p->ts_pk;
+          table_bytes = tb;
+        } else {
+          hist = h0; cl2 = c0; hist_bytes = b0;
+        }
       }
     }
     if (fast && !tables_fit) continue;  // the vector family keeps its tables in LDS

@@ -386,6 +386,11 @@ struct xhist_plan {
   //             [0: (start | cnt << 16) uint32 buckets, 1: uint16 start-only buckets on a 2x finer
   //                 grid for the linear-scan kernels (float domains only)]
   TableSet ts[2][2];
+  // packed 16-byte bucket entries for float64 samples on NON-uniform edges (count_le_pack): float64 edges + entries;
+  // pk_np = 0 (not offered: some bucket would hold more than three edges, or the edges leave float32's range), 2 or 3
+  TableSet ts_pk;
+  int pk_np = 0;
+  int pack_pref = 0;   // 0 auto, 1 packed entries whenever the plan has them, -1 never
   bool uns = false;    // the int64-domain inputs hold unsigned 64-bit values (XHIST_CMP_UNSIGNED)
   bool huge = false;   // some dimension has more than 65535 edges: no bucket tables (lut_k = 0)
   bool arith = false;  // every dimension has arithmetic (numpy.linspace) edges: table-free digitize available

@@ -280,6 +280,59 @@ __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool&
   return inside ? g : -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed bucket entries (SCAN = kScanPack2 / kScanPack3; float64 samples, NON-uniform edges — BASELINE C3).
+// The table digitize above costs a dimension two DEPENDENT LDS reads (uint16 `start`, then 1-4 float64 edges at
+// start) and the address arithmetic between them; C3's kernel keeps its LDS busy 74 % of the time and its VALU 57 %
+// (profiles/r03_s_c3_sq_counters.txt).  Here a bucket is ONE aligned 16-byte entry
+//     { thr_a, thr_b, thr_c : float32,  start : uint32 }        (one ds_read_b128 per sample and dimension)
+// with thr = m(e_j) for the (at most three) edges of the bucket, m(x) = (float)x, NaN where the bucket has fewer.
+// m is monotone non-decreasing, so with xf = m(x):   xf > m(e)  =>  x > e   and   xf < m(e)  =>  x < e;
+// only xf == m(e) decides nothing (one sample in ~10^5 for C3's edges).  Those samples — which include every x == e_j,
+// in particular the right edge x == e_last, and every x that is NaN-adjacent in float32 — set `near`; a wavefront in
+// which any lane is near redoes that lane with an exact binary search over the float64 edges (count_le_exact).
+// The bucket map runs on xf in float32 (bucket_of<2>), applied by the table builder to m(e_j) with the same code:
+// the composition is monotone in x, hence edges of lower buckets are < x and edges of higher buckets > x, as ever.
+// Without `near`:  count == 0  <=>  x < e_0,  count == E  <=>  x > e_last (x == e_last is near), NaN counts 0 —
+// and the entries hold start - 1, so what comes out is the bin itself and the range test is `bin < nb` (unsigned):
+// no float64 compare, no subtraction.
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanPack2 = 6, kScanPack3 = 7;
+constexpr bool scan_is_pack(int scan) { return scan == kScanPack2 || scan == kScanPack3; }
+typedef uint32_t pack_entry_t __attribute__((ext_vector_type(4), aligned(16)));
+
+// returns the real-bin index, or a value >= nb (as unsigned) for a sample the reference drops — valid unless `near`
+template <int NP, typename TabPtr>
+__device__ __forceinline__ uint32_t count_le_pack(double x, const DimTable& t, TabPtr tab, bool& near) {
+  const float xf = (float)x;
+  const pack_entry_t e = reinterpret_cast<const pack_entry_t*>(tab)[t.lut_off + bucket_of<2>(xf, t)];
+  const float ta = __uint_as_float(e[0]), tb = __uint_as_float(e[1]), tc = __uint_as_float(e[2]);
+  uint32_t c = e[3];  // start - 1: the sum below is the BIN, -1 (as 2^32 - 1) below e_0, nb above e_last
+  c += (xf > ta) ? 1u : 0u;
+  c += (xf > tb) ? 1u : 0u;
+  near = (xf == ta) | (xf == tb);
+  if (NP == 3) {
+    c += (xf > tc) ? 1u : 0u;
+    near |= (xf == tc);
+  }
+  return c;
+}
+
+// exact bin over ALL float64 edges of a dimension, in the packed counts' convention: 2^32 - 1 for dropped samples
+// (x < e_0, x > e_last, NaN), else min(#{e_j <= x}, nb) - 1 so that x == e_last lands in the last bin
+template <typename TabPtr>
+__device__ __forceinline__ uint32_t count_le_exact(double x, const DimTable& t, TabPtr tab) {
+  const double* e = reinterpret_cast<const double*>(tab + t.edge_off);
+  uint32_t lo = 0u, len = (uint32_t)t.n_edges;
+  while (len) {
+    const uint32_t half = len >> 1, mid = lo + half;
+    const bool le = e[mid] <= x;
+    lo = le ? mid + 1u : lo;
+    len = le ? len - half - 1u : half;
+  }
+  return Dom<0>::in_range(x, t) ? min(lo, (uint32_t)t.nb) - 1u : 0xffffffffu;
+}
+
 template <int CMP, int SCAN, typename TabPtr>
 __device__ __forceinline__ uint32_t count_le_scan(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
   using T = typename Dom<CMP>::T;
@@ -486,6 +539,34 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
             for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_arith((double)xv[d][u][v], p.dim[d]);
       }
     }
+  } else if constexpr (scan_is_pack(SCAN)) {
+    static_assert(CMP == 0, "packed entries: float64 samples");
+    constexpr int NP = SCAN == kScanPack3 ? 3 : 2;
+    bool near_any = false;  // (a lane mask in SGPRs: OR-ing the samples' flags costs the vector ALU nothing)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          bool near;
+          cnt[d][u][v] = count_le_pack<NP>((double)xv[d][u][v], p.dim[d], tab, near);
+          near_any |= near;
+        }
+    if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {  // rare: a sample whose float32 image equals an edge's
+      if (near_any) {  // which of this lane's samples it was is found again here, not carried through the fast path
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              bool near;
+              (void)count_le_pack<NP>((double)xv[d][u][v], p.dim[d], tab, near);
+              if (near) cnt[d][u][v] = count_le_exact((double)xv[d][u][v], p.dim[d], tab);
+            }
+      }
+    }
   } else if constexpr (SCAN > 0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
@@ -554,6 +635,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
   constexpr int CMP = I64DOM ? 1 : ((__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0);
   static_assert(!I64DOM || (__is_same(ST, int64_t) && SCAN == 0), "int64 domain: int64 samples, (start, cnt) tables");
+  static_assert(!scan_is_pack(SCAN) || (__is_same(ST, double) && !MIXED && !I64DOM), "packed bucket entries: float64 samples");
   using CT = typename Dom<CMP>::T;
   // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
   // integer samples: zero, masked by the past_end bit
@@ -759,9 +841,11 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
             // one input, LDS histogram: the slot address comes straight from the edge count
             //   bin = min(cnt, nb) - 1  ->  byte offset (min(cnt, nb) << sh) from a base moved back
             //   by one bin; out-of-range / NaN / past-the-end samples go to the lane's trash slot
-            const bool ok1 = Dom<CMP>::in_range((CT)xv[0][u][v], p.dim[0]) &
-                             (kFloatSamples || !((past_end >> (u * VEC + v)) & 1u));
-            const uint32_t off = min(cnt[0][u][v], (uint32_t)p.dim[0].nb) << slot_shift;
+            // (packed entries: what count_le_tile returns is the bin, >= nb for dropped samples; slot_base sits one bin back)
+            const bool ok1 = scan_is_pack(SCAN) ? (cnt[0][u][v] < (uint32_t)p.dim[0].nb)
+                                                : (Dom<CMP>::in_range((CT)xv[0][u][v], p.dim[0]) &
+                                                   (kFloatSamples || !((past_end >> (u * VEC + v)) & 1u)));
+            const uint32_t off = (scan_is_pack(SCAN) ? cnt[0][u][v] + 1u : min(cnt[0][u][v], (uint32_t)p.dim[0].nb)) << slot_shift;
             lds_t* slot = ok1 ? reinterpret_cast<lds_t*>(slot_base + off) : trash_slot;
             if (kWeighted) {
               unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
@@ -771,16 +855,24 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
             }
             continue;
           }
+          // a sample counts when EVERY dimension has it in range; `flat` of a dropped sample is garbage and never used
+          // (the range predicates are lane masks: AND-ing them is scalar work, and no bin is ever patched to -1)
           bool ok = kFloatSamples || !((past_end >> (u * VEC + v)) & 1u);
           uint32_t flat = 0;
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            const int b = bin_from_count<CMP>((CT)xv[d][u][v], p.dim[d], cnt[d][u][v]);
-            ok &= (b >= 0);
+            uint32_t b;
+            if constexpr (scan_is_pack(SCAN)) {
+              b = cnt[d][u][v];  // the bin itself, >= nb (unsigned) when dropped
+              ok &= b < (uint32_t)p.dim[d].nb;
+            } else {
+              b = min(cnt[d][u][v], (uint32_t)p.dim[d].nb) - 1u;  // x == e_last counts E edges -> last bin
+              ok &= Dom<CMP>::in_range((CT)xv[d][u][v], p.dim[d]);
+            }
             // the last dimension has stride 1; n_bins < 2^24 in every LDS mode and < 2^31 always
-            if (d == 0) flat = (uint32_t)b;
-            else if (HIST != kHistGlobal) flat = __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;  // full-rate mad_u24
-            else flat = flat * (uint32_t)p.dim[d].nb + (uint32_t)b;
+            if (d == 0) flat = b;
+            else if (HIST != kHistGlobal) flat = __umul24(flat, (uint32_t)p.dim[d].nb) + b;  // full-rate mad_u24
+            else flat = flat * (uint32_t)p.dim[d].nb + b;
           }
           if constexpr (SLICED) {  // keep only this launch's bins; from here on `flat` is relative to the slice
             flat -= (uint32_t)p.slice_lo;
@@ -986,6 +1078,29 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
     while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b + 1) lo = m + 1; else hi = m; }
     if (LUT16) lut16[b] = (uint16_t)start;
     else lut[b] = (uint32_t)start | ((uint32_t)(lo - start) << 16);
+  }
+}
+
+// packed-entry tables (count_le_pack): one workgroup per dimension.  thr_j = (float)e_j is computed HERE, with the
+// conversion the kernels apply to the samples; entry b = { thr of the first three edges of bucket b (NaN beyond the
+// bucket's own), start }.  The host reads the table back and offers it only if no bucket holds more than three edges.
+static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t, uint64_t* blob, int32_t* scratch) {
+  const double* edges = reinterpret_cast<const double*>(blob + t.edge_off);
+  pack_entry_t* ent = reinterpret_cast<pack_entry_t*>(blob) + t.lut_off;
+  for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x) scratch[j] = bucket_of<2>((float)edges[j], t);
+  __syncthreads();
+  for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
+    int lo = 0, hi = t.n_edges;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b) lo = m + 1; else hi = m; }
+    const int start = lo;
+    hi = t.n_edges;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (scratch[m] < b + 1) lo = m + 1; else hi = m; }
+    const int cnt = lo - start;
+    pack_entry_t e;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e[k] = k < cnt ? __float_as_uint((float)edges[start + k]) : 0x7fc00000u;
+    e[3] = (uint32_t)start - 1u;  // (count_le_pack's sum is then the bin itself)
+    ent[b] = e;
   }
 }
 

@@ -27,6 +27,7 @@ typedef void (*kernel_fn_acc_chunks)(const RouteArgs, void*, int64_t, int, int, 
 // sample and dimension the batch keeps the value, its running count and (linear scan) up to
 // SCAN edge values in VGPRs, and 1024-thread workgroups leave 128 VGPRs per lane.
 constexpr int unroll_for(int D, int vec, int scan) {
+  if (scan_is_pack(scan)) scan = 2;  // packed bucket entries: one 16-byte entry per sample and dimension, as the two-edge scan
   int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
   if (D >= 2 && scan >= 3) cap /= 2;
   if (D == 1 && scan >= 3 && vec == 4) cap = 8;
@@ -80,10 +81,28 @@ static kernel_fn fast_pick_arith(int hist) {
   return nullptr;
 }
 
+// packed bucket entries (count_le_pack): float64 samples, histograms in LDS (replicated or packed uint16 counters)
+template <typename ST, typename WT, int D, int SCAN>
+static kernel_fn fast_pick_pack(int hist) {
+  if constexpr (std::is_same<ST, double>::value) {
+    constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+    constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+    constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+    constexpr int U = unroll_for(D, VEC, SCAN);
+    if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
+    if (hist == kHistPacked) {
+      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+    }
+  }
+  return nullptr;
+}
+
 template <typename ST, typename WT, int D>
 static kernel_fn fast_pick_s(int scan, int hist) {
   switch (scan) {
     case kScanArith: return fast_pick_arith<ST, WT, D>(hist);
+    case kScanPack2: return fast_pick_pack<ST, WT, D, kScanPack2>(hist);
+    case kScanPack3: return fast_pick_pack<ST, WT, D, kScanPack3>(hist);
     case 1: return fast_pick<ST, WT, D, 1>(hist);
     case 2: return fast_pick<ST, WT, D, 2>(hist);
     case 3: return fast_pick<ST, WT, D, 3>(hist);

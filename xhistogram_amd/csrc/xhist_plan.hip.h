@@ -143,6 +143,115 @@ static int build_domain(xhist_plan* p, int dom_all, bool lut16, int n_inputs, co
   return cleanup(XHIST_OK);
 }
 
+// Packed-entry table set (count_le_pack; kernels header): per dimension K 16-byte entries behind the float64 edges.
+// K is searched per dimension, downwards from what the LDS budget allows, for a bucket grid on which no bucket holds more
+// than three edges (C3: 257 random edges, K ~ 850: most grids qualify, a few put four edges of a tight cluster into one
+// bucket); the search runs on the host with the float32 arithmetic of bucket_of<2>, the table is BUILT on the device and
+// read back, and only what the device built decides whether the set is offered.
+static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges, const std::vector<std::vector<uint64_t>>& words,
+                             const void* const* edges, size_t entry_budget_bytes) {
+  TableSet* ts = &p->ts_pk;
+  p->pk_np = 0;
+  int32_t edge_off = 0;
+  int64_t max_e = 0;
+  const int k_cap = (int)std::min<size_t>(entry_budget_bytes / (16 * (size_t)n_inputs), 2048);
+  for (int d = 0; d < n_inputs; ++d) {
+    DimTable& t = ts->dim[d];
+    memset(&t, 0, sizeof t);
+    const int E = (int)n_edges[d];
+    const double* e = static_cast<const double*>(edges[d]);
+    max_e = std::max<int64_t>(max_e, E);
+    t.n_edges = E;
+    t.nb = E - 1;
+    t.e0_f = e[0];
+    t.eL_f = e[E - 1];
+    t.edge_off = edge_off;
+    edge_off += (int32_t)words[d].size();
+    if (E < 2 || E > 65535) return XHIST_OK;
+    std::vector<float> thr((size_t)E);
+    for (int j = 0; j < E; ++j) {
+      if (!std::isfinite(e[j]) || std::fabs(e[j]) > 3.0e38) return XHIST_OK;
+      thr[(size_t)j] = (float)e[j];
+    }
+    const float range = thr[(size_t)E - 1] - thr[0];
+    if (!(range > 0.0f) || !std::isfinite(range)) return XHIST_OK;
+    int best_k = 0, best_cnt = 4;
+    for (int K = k_cap; K >= std::max(8, k_cap - 96) && best_cnt > 2; --K) {
+      const float scale = (float)((double)K / (double)range), bias = -thr[0] * scale;
+      if (!std::isfinite(scale) || !(scale > 0.0f) || !std::isfinite(bias)) continue;
+      int run = 0, prev = -1, mx = 0;
+      for (int j = 0; j < E; ++j) {
+        float tt = std::fmaf(thr[(size_t)j], scale, bias);
+        tt = std::fmax(std::fmin(tt, (float)(K - 1)), 0.0f);
+        const int b = (int)tt;
+        run = b == prev ? run + 1 : 1;
+        prev = b;
+        mx = std::max(mx, run);
+      }
+      if (mx < best_cnt) { best_cnt = mx; best_k = K; }
+    }
+    if (!best_k || best_cnt > 3) return XHIST_OK;
+    const float scale = (float)((double)best_k / (double)range);
+    t.lut_k = best_k;
+    t.scale = (double)scale;
+    t.bias = (double)(-thr[0] * scale);
+    t.steps = 1;
+  }
+  int64_t stride = 1;
+  for (int d = n_inputs - 1; d >= 0; --d) {
+    ts->dim[d].out_stride = stride;
+    stride *= ts->dim[d].nb;
+  }
+  int32_t off = (edge_off + 1) / 2;  // entries: 16-byte units, behind the edges
+  for (int d = 0; d < n_inputs; ++d) {
+    ts->dim[d].lut_off = off;
+    off += ts->dim[d].lut_k;
+  }
+  const int32_t table_words = off * 2;
+  std::vector<uint64_t> blob((size_t)table_words, 0);
+  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + ts->dim[d].edge_off, words[d].data(), words[d].size() * 8);
+  uint64_t* d_blob = nullptr;
+  int32_t* d_scratch = nullptr;
+  auto cleanup = [&](int rc, bool keep) {
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (!keep && d_blob) (void)hipFree(d_blob);
+    return rc;
+  };
+#define HIPP(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)), false); \
+  } while (0)
+  HIPP(hipMalloc(&d_blob, blob.size() * 8));
+  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
+  HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+  for (int d = 0; d < n_inputs; ++d) {
+    hipLaunchKernelGGL(build_pack_tables, dim3(1), dim3(256), 0, 0, ts->dim[d], d_blob, d_scratch);
+    HIPP(hipGetLastError());
+    HIPP(hipDeviceSynchronize());
+  }
+  HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));
+#undef HIPP
+  int np = 1;
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(blob.data());
+  for (int d = 0; d < n_inputs; ++d) {
+    const DimTable& t = ts->dim[d];
+    uint32_t prev = 0;
+    for (int b = 0; b <= t.lut_k; ++b) {
+      const uint32_t start = b < t.lut_k ? w32[((size_t)t.lut_off + (size_t)b) * 4 + 3] + 1u : (uint32_t)t.n_edges;  // (entries hold start - 1)
+      if (start < prev || start > (uint32_t)t.n_edges || (b == 0 && start != 0)) return cleanup(XHIST_OK, false);  // (not offered)
+      if (b) np = std::max<int>(np, (int)(start - prev));
+      prev = start;
+    }
+  }
+  if (np > 3) return cleanup(XHIST_OK, false);
+  ts->blob = d_blob;
+  ts->words = table_words;
+  ts->max_cnt = np;
+  p->pk_np = np <= 2 ? 2 : 3;
+  return cleanup(XHIST_OK, true);
+}
+
 extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* edges, const int64_t* n_edges,
                                  int cmp_domain, xhist_plan** out_plan) {
   Range range_("xhist_plan_create[edge tables]");
@@ -258,6 +367,17 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0],
                         mixed ? dim_dom : nullptr);
   if (rc == XHIST_OK && vector_sets) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
+  if (rc == XHIST_OK && vector_sets && !mixed) {
+    // packed entries share the LDS with the histogram they serve: whatever the smallest form of this plan's histogram
+    // (packed uint16 counters) leaves, at most 32 KiB
+    size_t edge_bytes = 0;
+    for (int d = 0; d < n_inputs; ++d) edge_bytes += words[d].size() * 8;
+    const size_t hist_min = (((size_t)std::min<int64_t>(n_bins, (int64_t)1 << 24) + 1) / 2 + 32) * 4;
+    const size_t fixed = edge_bytes + 16 + 1024 + hist_min;
+    size_t budget = p->lds_max > fixed ? p->lds_max - fixed : 0;
+    budget = std::min<size_t>(budget, 32 * 1024);  // (C3: 27 KiB are left)
+    if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, n_inputs, n_edges, words, edges, budget);
+  }
   if (rc == XHIST_OK && vector_sets) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
     for (int d = 0; d < n_inputs; ++d) {
@@ -279,6 +399,7 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     for (auto& dom : p->ts)
       for (auto& t : dom)
         if (t.blob) (void)hipFree(t.blob);
+    if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
     delete p;
     return rc;
   }
@@ -345,6 +466,7 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
     for (auto& dom : p->ts)
       for (auto& t : dom)
         if (t.blob) (void)hipFree(t.blob);
+    if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (p->mixed_hint) (void)hipHostFree(p->mixed_hint);
   }
@@ -395,6 +517,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "slices")) {
     p->slices_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "pack")) {
+    p->pack_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "arith")) {
     p->arith_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {
