@@ -226,7 +226,10 @@ def main():
     use_dist = world > 1 or launched
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # a rank that never shows up must end the run with a message, not with PyTorch's default ten-minute wait
+        import datetime
+        limit = float(os.environ.get("XHIST_AMD_COMM_TIMEOUT_S", "120"))
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=limit if limit > 0 else 1800))
     _native.require_device(local)
 
     wl = build_workload(args.config, args, torch, dev, rank)

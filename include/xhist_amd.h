@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 7
+#define XHIST_ABI_VERSION 8
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -176,6 +176,14 @@ int xhist_comm_info(const xhist_comm* comm, int* rank, int* world_size, int* dev
 int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, int op, void* stream);
 /* recv holds world_size * count elements, rank r's block at offset r * count */
 int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
+/* Deadlines: xhist_comm_create (the rendezvous) and xhist_comm_wait (the completion of collectives) do not wait for a
+ * peer for ever: XHIST_AMD_COMM_TIMEOUT_S seconds (environment, default 60; <= 0: no deadline).  On expiry, or on an
+ * asynchronous RCCL error, the communicator is aborted (ncclCommAbort: kernels of a collective in flight return), the call
+ * returns XHIST_ERR_COMM with a message naming rank, world size and what was waited for, and every later call on the
+ * communicator returns XHIST_ERR_COMM at once; xhist_comm_destroy is still due.
+ * xhist_comm_wait: block until everything enqueued on `stream` has completed — the host-side synchronisation point of
+ * an exchange, in place of a bare hipStreamSynchronize that a dead peer would hang. */
+int xhist_comm_wait(xhist_comm* comm, void* stream);
 int xhist_comm_destroy(xhist_comm* comm);
 
 /* ---- device buffers ------------------------------------------------------------------------ */

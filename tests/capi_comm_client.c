@@ -5,7 +5,10 @@
  * makes the full histogram appear on every GPU (the reference's bin_counts.sum(drop_axes), core.py:439).
  * Build:  gcc -O2 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/capi_comm_client.c -o capi_comm_client \
  *             -L xhistogram_amd -lxhist_amd -Wl,-rpath,xhistogram_amd -L /opt/rocm/lib -lamdhip64 -lm
- * Run:    ./capi_comm_client [world_size]      (default: the number of GPUs; exit 77 without a GPU) */
+ * Run:    ./capi_comm_client [world_size]      (default: the number of GPUs; exit 77 without a GPU)
+ *         ./capi_comm_client lonely            rank 0 of a world of 2 whose peer never joins: xhist_comm_create must come
+ *                                              back with XHIST_ERR_COMM inside the deadline (XHIST_AMD_COMM_TIMEOUT_S), not hang */
+#include <time.h>
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdint.h>
@@ -69,6 +72,7 @@ static int rank_main(int rank, int world, const char* id_path) {
   xhist_array xa = {dx, XHIST_F64, 0, n, 1, 0, 0};
   if (xhist_plan_execute(plan, &xa, NULL, 1, n, dcounts, XHIST_I64, XHIST_MEM_DEVICE, 0, NULL)) { printf("execute: %s\n", xhist_last_error()); return 7; }
   if (xhist_comm_allreduce(comm, dcounts, NB, XHIST_I64, XHIST_REDUCE_SUM, NULL)) { printf("allreduce: %s\n", xhist_last_error()); return 8; }
+  if (xhist_comm_wait(comm, NULL)) { printf("wait: %s\n", xhist_last_error()); return 8; }  /* completion with a deadline, not a bare sync */
   int64_t counts[NB];
   if (hipMemcpy(counts, dcounts, sizeof counts, hipMemcpyDeviceToHost) != hipSuccess) return 6;
 
@@ -114,8 +118,29 @@ static int rank_main(int rank, int world, const char* id_path) {
   return bad ? 1 : 0;
 }
 
+/* rank 0 of a world of two, alone: the rendezvous must end in a status code */
+static int lonely_main(void) {
+  char id[XHIST_COMM_ID_BYTES];
+  if (xhist_comm_unique_id(id, sizeof id)) { printf("id: %s\n", xhist_last_error()); return 3; }
+  xhist_comm* comm = NULL;
+  const time_t t0 = time(NULL);
+  const int rc = xhist_comm_create(0, 0, 2, id, sizeof id, &comm);
+  const long took = (long)(time(NULL) - t0);
+  printf("xhist_comm_create alone in a world of 2: rc %d after %ld s: %s\n", rc, took, rc ? xhist_last_error() : "(no error)");
+  if (rc != XHIST_ERR_COMM || comm != NULL) return 1;
+  xhist_shutdown();
+  printf("OK: lonely rank got XHIST_ERR_COMM\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (xhist_abi_version() != XHIST_ABI_VERSION) return 2;
+  if (argc > 1 && !strcmp(argv[1], "lonely")) {
+    int n = 0;
+    xhist_device_count(&n);
+    if (n <= 0) { printf("no GPU: this library has no CPU path\n"); return 77; }
+    return lonely_main();
+  }
   /* the device count comes from a child: the parent must not initialise HIP before it forks */
   int fds[2];
   if (pipe(fds)) return 2;

@@ -68,3 +68,20 @@ def test_c_comm_client_one_process_per_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().splitlines()[-1].startswith("OK")
+
+
+@pytest.mark.gpu
+def test_c_comm_client_peer_that_never_joins_is_a_status_code_not_a_hang(tmp_path):
+    """ONE GPU is enough: rank 0 of a world of two whose peer never shows up.  xhist_comm_create must return
+    XHIST_ERR_COMM with a readable message inside the deadline ($XHIST_AMD_COMM_TIMEOUT_S) — the first-contact failure
+    of a multi-GPU node (VERDICT r3 "missing" #1)"""
+    import time
+
+    exe = _build_comm(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XHIST_AMD_COMM_TIMEOUT_S="4")
+    t0 = time.time()
+    r = subprocess.run([exe, "lonely"], capture_output=True, text=True, timeout=120, env=env)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rc -7" in r.stdout and "rendezvous of 2 ranks" in r.stdout and "aborted" in r.stdout, r.stdout
+    assert took < 60, took

@@ -244,3 +244,35 @@ def test_native_comm_fails_loudly_without_a_gpu():
         _native.Comm(0, 0, 1, b"short")
     with pytest.raises(ValueError):
         _native.Comm(0, 3, 2, b"\0" * _native.COMM_ID_BYTES)
+
+
+@pytest.mark.gpu
+def test_native_comm_deadline_through_the_python_shim():
+    """the same from Python, in a process of its own: Comm(world_size=2) with one rank raises RuntimeError inside the
+    deadline, and the communicator-less process goes on to run a single-rank exchange"""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, time, torch\n"
+        "from xhistogram_amd import _native\n"
+        "_native.load()\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    _native.Comm(0, 0, 2, _native.comm_unique_id())\n"
+        "    print('NO ERROR')\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED after %.1f s: %s' % (time.time() - t0, e))\n"
+        "c = _native.Comm(0, 0, 1, _native.comm_unique_id())\n"
+        "t = torch.arange(8, dtype=torch.int64, device='cuda')\n"
+        "c.allreduce(t.data_ptr(), 8, _native.I64, _native.REDUCE_SUM, torch.cuda.current_stream().cuda_stream)\n"
+        "c.wait(torch.cuda.current_stream().cuda_stream)\n"
+        "print('SUM', int(t.sum()))\n"
+        "c.close()\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XHIST_AMD_COMM_TIMEOUT_S="4", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RAISED after" in r.stdout and "rendezvous of 2 ranks" in r.stdout, r.stdout + r.stderr
+    assert "SUM 28" in r.stdout, r.stdout + r.stderr

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -71,7 +71,7 @@ EXPORTS = (
     "xhist_plan_create", "xhist_plan_destroy", "xhist_plan_execute", "xhist_plan_execute_two_weights", "xhist_bincount_rows",
     "xhist_minmax", "xhist_moments", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
-    "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
+    "xhist_comm_wait", "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
     "xhist_pointer_device", "xhist_scratch_stats", "xhist_shutdown",
 )
 
@@ -146,6 +146,7 @@ def load():
         lib.xhist_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.xhist_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         lib.xhist_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        lib.xhist_comm_wait.argtypes = [C.c_void_p, C.c_void_p]
         lib.xhist_comm_destroy.argtypes = [C.c_void_p]
         lib.xhist_buffer_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.xhist_buffer_free.argtypes = [C.c_int, C.c_void_p]
@@ -361,7 +362,7 @@ def comm_unique_id():
 class Comm:
     """One RCCL communicator bound to one GPU (xhist_comm): the exchange step of sharded inputs for
     hosts without torch.distributed.  ``Comm(device, rank, world_size, unique_id)`` is collective —
-    it returns once every rank has joined.  Buffers are device pointers; calls are asynchronous on
+    it returns once every rank has joined, or raises after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 60) when one never does.  Buffers are device pointers; calls are asynchronous on
     ``stream`` and must be issued in the same order on every rank."""
 
     def __init__(self, device, rank, world_size, unique_id):
@@ -382,6 +383,12 @@ class Comm:
 
     def allgather(self, send_ptr, recv_ptr, count, tag, stream=0):
         check(load().xhist_comm_allgather(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count), int(tag), C.c_void_p(stream)))
+
+    def wait(self, stream=0):
+        """block until everything enqueued on ``stream`` has completed — the host-side end of an exchange.  Unlike a bare
+        stream synchronisation it watches the communicator: a peer that never entered the collective, or died in it, ends
+        in a RuntimeError after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 60) and an aborted communicator, not in a hang"""
+        check(load().xhist_comm_wait(self._h, C.c_void_p(stream)))
 
     def close(self):
         if getattr(self, "_h", None):

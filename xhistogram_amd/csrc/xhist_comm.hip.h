@@ -8,15 +8,34 @@
 // dlopen on the first call — a process that never exchanges anything (single GPU, or a host that
 // brings its own collective, like the Python package with torch.distributed) never loads it, and
 // one that already has an RCCL mapped (torch's) shares that copy instead of loading a second.
+//
+// Deadlines (round 4).  A peer that never joins, or dies inside a collective, must not hang a long-lived worker: the header
+// promises status codes.  What can wait for a peer:
+//   the rendezvous (xhist_comm_create) — ncclCommInitRankConfig runs on a helper thread while the caller waits for it with
+//     a deadline; on expiry the caller calls ncclCommAbort on the half-built communicator (RCCL publishes the handle before
+//     it starts to wait for its peers), which makes the rendezvous return with an error within a second.  RCCL's own
+//     non-blocking mode does not do this job here: with config.blocking = 0 the init call of RCCL 2.27.7 (ROCm 7.2) itself
+//     never returns while a peer is missing (tools/ubench/rccl_lonely.cpp, profiles/r04_c_rccl_lonely_rank.txt);
+//   the completion of a collective (xhist_comm_wait) — polls the stream and ncclCommGetAsyncError against the deadline.
+// The deadline is $XHIST_AMD_COMM_TIMEOUT_S seconds (default 60; <= 0 = wait for ever).  On expiry, or on an asynchronous
+// RCCL error, the communicator is torn down with ncclCommAbort (kernels of a collective in flight return), the call reports
+// XHIST_ERR_COMM with what it was waiting for, and every later call on that communicator fails at once with the same code.
 #pragma once
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
+
 struct RcclApi {
   void* handle = nullptr;
   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommInitRankConfig) comm_init_rank_config = nullptr;
+  decltype(&ncclCommGetAsyncError) get_async_error = nullptr;
+  decltype(&ncclCommAbort) comm_abort = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
@@ -49,7 +68,9 @@ static int rccl_api(const RcclApi** out) {
     bool ok = true;
     auto sym = [&](const char* name) { void* s = dlsym(g_rccl.handle, name); if (!s) ok = false; return s; };
     g_rccl.get_unique_id = (decltype(g_rccl.get_unique_id))sym("ncclGetUniqueId");
-    g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))sym("ncclCommInitRank");
+    g_rccl.comm_init_rank_config = (decltype(g_rccl.comm_init_rank_config))sym("ncclCommInitRankConfig");
+    g_rccl.get_async_error = (decltype(g_rccl.get_async_error))sym("ncclCommGetAsyncError");
+    g_rccl.comm_abort = (decltype(g_rccl.comm_abort))sym("ncclCommAbort");
     g_rccl.all_reduce = (decltype(g_rccl.all_reduce))sym("ncclAllReduce");
     g_rccl.all_gather = (decltype(g_rccl.all_gather))sym("ncclAllGather");
     g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))sym("ncclCommDestroy");
@@ -74,7 +95,51 @@ static int rccl_api(const RcclApi** out) {
 struct xhist_comm {
   ncclComm_t comm = nullptr;
   int device = 0, rank = 0, world = 1;
+  bool aborted = false;     // torn down after a deadline or an asynchronous error: every later call reports XHIST_ERR_COMM
+  std::string why;          // what the communicator was waiting for when it was aborted
+  std::mutex mu;            // one call at a time per communicator (RCCL's own rule for one communicator)
 };
+
+static double comm_timeout_s() {
+  const char* e = getenv("XHIST_AMD_COMM_TIMEOUT_S");  // read at every call: a test, or a host that knows better, may change it
+  if (e && *e) return atof(e);
+  return 60.0;
+}
+
+typedef std::chrono::steady_clock comm_clock;
+
+static int comm_dead(const xhist_comm* c) {
+  return fail(XHIST_ERR_COMM, "communicator (rank %d of %d, device %d) was aborted earlier: %s", c->rank, c->world, c->device, c->why.c_str());
+}
+
+// tear the communicator down and report; `what` says what was being waited for
+static int comm_abort_with(const RcclApi* api, xhist_comm* c, const char* what, const char* detail) {
+  if (c->comm) (void)api->comm_abort(c->comm);  // frees the communicator; kernels of a collective in flight return
+  c->comm = nullptr;
+  c->aborted = true;
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s (%s)", what, detail);
+  c->why = buf;
+  return fail(XHIST_ERR_COMM, "RCCL rank %d of %d on device %d: %s — %s; the communicator was aborted (XHIST_AMD_COMM_TIMEOUT_S = %g s)", c->rank,
+              c->world, c->device, what, detail, comm_timeout_s());
+}
+
+// Poll the communicator until RCCL reports it settled (ncclSuccess), failed, or the deadline passes.
+// A non-blocking communicator answers ncclInProgress while a rendezvous or a connection setup is still going on.
+static int comm_settle(const RcclApi* api, xhist_comm* c, const char* what, comm_clock::time_point t0) {
+  const double limit = comm_timeout_s();
+  for (int spin = 0;; ++spin) {
+    ncclResult_t state = ncclSuccess;
+    const ncclResult_t r = api->get_async_error(c->comm, &state);
+    if (r != ncclSuccess) return comm_abort_with(api, c, what, api->error_string(r));
+    if (state == ncclSuccess) return XHIST_OK;
+    if (state != ncclInProgress) return comm_abort_with(api, c, what, api->error_string(state));
+    if (limit > 0 && std::chrono::duration<double>(comm_clock::now() - t0).count() > limit)
+      return comm_abort_with(api, c, what, "deadline passed while RCCL was still waiting for a peer");
+    if (spin < 64) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spin < 1024 ? 50 : 1000));
+  }
+}
 
 static int nccl_dtype(int dtype, ncclDataType_t* out) {
   switch (dtype) {
@@ -114,11 +179,56 @@ extern "C" int xhist_comm_create(int device, int rank, int world_size, const voi
   c->device = device;
   c->rank = rank;
   c->world = world_size;
-  ncclResult_t r = api->comm_init_rank(&c->comm, world_size, u, rank);  // collective: returns once every rank has joined
-  if (r != ncclSuccess) {
-    delete c;
-    return fail(XHIST_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world_size, device, api->error_string(r));
+  // the rendezvous on a helper thread, watched from here (see the header comment)
+  struct InitJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t result = ncclSuccess;
+    ncclComm_t comm = nullptr;  // written by RCCL (on the helper thread) as soon as the communicator object exists
+  };
+  auto job = std::make_shared<InitJob>();
+  const int phys = physical_device(device);
+  const auto init_fn = api->comm_init_rank_config;
+  std::thread([job, init_fn, u, world_size, rank, phys] {
+    ncclResult_t r = ncclInternalError;
+    if (hipSetDevice(phys) == hipSuccess) {
+      ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+      cfg.blocking = 1;
+      r = init_fn(&job->comm, world_size, u, rank, &cfg);
+    }
+    std::lock_guard<std::mutex> lk(job->mu);
+    job->result = r;
+    job->done = true;
+    job->cv.notify_all();
+  }).detach();
+  const double limit = comm_timeout_s();
+  bool expired = false;
+  {
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (limit > 0) expired = !job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; });
+    else job->cv.wait(lk, [&] { return job->done; });
   }
+  if (expired) {
+    // nobody else joined in time: abort the half-built communicator so that the helper thread's rendezvous returns
+    ncclComm_t half = *(ncclComm_t volatile*)&job->comm;
+    if (half) (void)api->comm_abort(half);
+    bool back = false;
+    {
+      std::unique_lock<std::mutex> lk(job->mu);
+      back = job->cv.wait_for(lk, std::chrono::seconds(10), [&] { return job->done; });
+    }
+    delete c;
+    return fail(XHIST_ERR_COMM,
+                "RCCL rank %d of %d on device %d: rendezvous of %d ranks (xhist_comm_create) — deadline passed while RCCL was still waiting for a "
+                "peer; the communicator was aborted%s (XHIST_AMD_COMM_TIMEOUT_S = %g s)",
+                rank, world_size, device, world_size, back ? "" : " (its helper thread is still inside RCCL and was left behind)", limit);
+  }
+  if (job->result != ncclSuccess) {
+    delete c;
+    return fail(XHIST_ERR_COMM, "ncclCommInitRankConfig(rank %d of %d, device %d) failed: %s", rank, world_size, device, api->error_string(job->result));
+  }
+  c->comm = job->comm;
   *out = c;
   return XHIST_OK;
 }
@@ -138,7 +248,9 @@ extern "C" int xhist_comm_info(const xhist_comm* comm, int* rank, int* world_siz
 
 extern "C" int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, int op, void* stream) {
   Range range_("xhist_comm_allreduce[partials]");
-  if (!comm || !comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  if (!comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  if (comm->aborted) return comm_dead(comm);
+  if (!comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
   if (count < 0 || (count > 0 && !buf)) return fail(XHIST_ERR_INVALID, "buffer is NULL / count < 0");
   ncclDataType_t dt;
   if (int rc = nccl_dtype(dtype, &dt)) return rc;
@@ -152,25 +264,70 @@ extern "C" int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, 
   if (count == 0) return XHIST_OK;  // every rank sees the same count: nobody enters the collective
   const RcclApi* api;
   if (int rc = rccl_api(&api)) return rc;
+  std::lock_guard<std::mutex> lk(comm->mu);
+  if (comm->aborted) return comm_dead(comm);
   DeviceGuard g;
   if (int rc = g.set(comm->device)) return rc;
-  RCCLC(api, api->all_reduce(buf, buf, (size_t)count, dt, rop, comm->comm, static_cast<hipStream_t>(stream)));
-  return XHIST_OK;
+  const auto t0 = comm_clock::now();
+  const ncclResult_t r = api->all_reduce(buf, buf, (size_t)count, dt, rop, comm->comm, static_cast<hipStream_t>(stream));
+  if (r != ncclSuccess && r != ncclInProgress) return comm_abort_with(api, comm, "ncclAllReduce", api->error_string(r));
+  return comm_settle(api, comm, "enqueue of an all-reduce (connection setup)", t0);  // (the first poll answers in steady state)
 }
 
 extern "C" int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream) {
   Range range_("xhist_comm_allgather[rows]");
-  if (!comm || !comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  if (!comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  if (comm->aborted) return comm_dead(comm);
+  if (!comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
   if (count < 0 || (count > 0 && (!send || !recv))) return fail(XHIST_ERR_INVALID, "buffer is NULL / count < 0");
   ncclDataType_t dt;
   if (int rc = nccl_dtype(dtype, &dt)) return rc;
   if (count == 0) return XHIST_OK;
   const RcclApi* api;
   if (int rc = rccl_api(&api)) return rc;
+  std::lock_guard<std::mutex> lk(comm->mu);
+  if (comm->aborted) return comm_dead(comm);
   DeviceGuard g;
   if (int rc = g.set(comm->device)) return rc;
-  RCCLC(api, api->all_gather(send, recv, (size_t)count, dt, comm->comm, static_cast<hipStream_t>(stream)));
-  return XHIST_OK;
+  const auto t0 = comm_clock::now();
+  const ncclResult_t r = api->all_gather(send, recv, (size_t)count, dt, comm->comm, static_cast<hipStream_t>(stream));
+  if (r != ncclSuccess && r != ncclInProgress) return comm_abort_with(api, comm, "ncclAllGather", api->error_string(r));
+  return comm_settle(api, comm, "enqueue of an all-gather (connection setup)", t0);
+}
+
+// Wait until everything enqueued on `stream` — the collectives above — has completed, watching the communicator: a peer
+// that died inside a collective shows either as an asynchronous RCCL error or as a stream that never drains.  Returns
+// XHIST_OK, or XHIST_ERR_COMM after aborting the communicator (deadline: XHIST_AMD_COMM_TIMEOUT_S).
+extern "C" int xhist_comm_wait(xhist_comm* comm, void* stream) {
+  Range range_("xhist_comm_wait[collective completion]");
+  if (!comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  const RcclApi* api;
+  if (int rc = rccl_api(&api)) return rc;
+  std::lock_guard<std::mutex> lk(comm->mu);
+  if (comm->aborted) return comm_dead(comm);
+  if (!comm->comm) return fail(XHIST_ERR_INVALID, "comm is NULL");
+  DeviceGuard g;
+  if (int rc = g.set(comm->device)) return rc;
+  const double limit = comm_timeout_s();
+  const auto t0 = comm_clock::now();
+  for (int spin = 0;; ++spin) {
+    const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(stream));
+    if (q == hipSuccess) return XHIST_OK;
+    if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return comm_abort_with(api, comm, "completion of a collective (xhist_comm_wait)", hipGetErrorString(q));
+    }
+    (void)hipGetLastError();
+    ncclResult_t state = ncclSuccess;
+    const ncclResult_t r = api->get_async_error(comm->comm, &state);
+    if (r != ncclSuccess) return comm_abort_with(api, comm, "completion of a collective (xhist_comm_wait)", api->error_string(r));
+    if (state != ncclSuccess && state != ncclInProgress)
+      return comm_abort_with(api, comm, "completion of a collective (xhist_comm_wait)", api->error_string(state));
+    if (limit > 0 && std::chrono::duration<double>(comm_clock::now() - t0).count() > limit)
+      return comm_abort_with(api, comm, "completion of a collective (xhist_comm_wait)", "deadline passed with the collective still in flight: a peer never entered it, or died in it");
+    if (spin < 256) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spin < 4096 ? 20 : 500));
+  }
 }
 
 extern "C" int xhist_comm_destroy(xhist_comm* comm) {

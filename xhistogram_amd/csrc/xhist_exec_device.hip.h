@@ -273,16 +273,40 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
   if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
-  const int64_t n_tiles = ((n_cols + tile - 1) / tile) * rows;
+  // ---- sub-batches (VERDICT r3 "next" #1): the samples of ONE long row are cut into B pieces; the routing pass of piece
+  // k + 1 runs on the caller's stream while the adding-up pass of piece k runs on a stream of the plan's own, on the compute
+  // units the routing pass's grid leaves free (the two cannot share a CU: 93-142 KB + 136 KB of LDS).  Two record pools,
+  // used in turn.  Measured: DESIGN 4.2 / profiles/r04_b_*.
+  int n_batches = 1, cus_acc = 0, route_grid = 0, acc_grid = 0;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    n_batches = p->overlap;
+    cus_acc = p->overlap_cus;
+    route_grid = p->route_grid;
+    acc_grid = p->acc_grid;
+  }
+  if (n_batches == 0) n_batches = 1;  // auto: off (see the measurements)
+  if (rows != 1 || n_cols < (int64_t)n_batches * 16 * tile * p->cus) n_batches = 1;
+  const bool overlapped = n_batches > 1;
+  if (overlapped && cus_acc == 0) cus_acc = 48;
+  // columns per piece: whole tiles, so that every piece starts as aligned as the row does
+  const int64_t cols_piece = overlapped ? (((n_cols + n_batches - 1) / n_batches + tile - 1) / tile) * tile : n_cols;
+  if (overlapped) n_batches = (int)((n_cols + cols_piece - 1) / cols_piece);
+  // (a last piece of less than a tile goes with the one before it: pools are sized for a tile more)
+  const int64_t n_piece = (cols_piece + (overlapped ? tile : 0)) * rows;  // most samples one routing pass sees
+  const int64_t n_tiles = ((cols_piece + tile - 1) / tile) * rows;
   // workgroups resident per CU: by LDS — and by registers: the routing pass is held to 128 per lane (waves_per_eu 4), so a
   // CU holds 1024 of its threads.  (Sized by LDS alone, a 77 KB workgroup of 1024 threads got a grid of 2 per CU, ran it
   // in two rounds, and 10^7 float64 pairs + weights into 512 x 512 bins took 0.233 ms against 0.170 for the three-pass route.)
   const int per_cu = std::max<int>(1, std::min<int>(std::min<int>(4, 1024 / block), (int)((size_t)160 * 1024 / lds_route)));
-  const int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
-  const int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_total + 65535) / 65536));
+  const int cus_route = overlapped ? std::max(1, p->cus - cus_acc) : p->cus;
+  int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus_route * per_cu, n_tiles));
+  int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(overlapped ? cus_acc : p->cus, (n_piece + 65535) / 65536));
+  if (route_grid) G = (int)std::min<int64_t>(route_grid, n_tiles);
+  if (acc_grid) Gb = acc_grid;
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
-  while (lg < 14 && (((n_total / G) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
+  while (lg < 14 && (((n_piece / G) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
   static const int lg_env = [] { const char* e = getenv("XHIST_AMD_ROUTE_CHUNK_LOG2"); return e && *e ? atoi(e) : 0; }();  // A/B runs only
   if (lg_env >= 10 && lg_env <= 14 && lg_env > lg) lg = lg_env;
   const int64_t GP = (int64_t)G * n_parts;
@@ -290,12 +314,13 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
   // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
   // and ends with at most two ranges in hand.
-  const int64_t used = ((n_total + 7 * GP) >> lg) + GP;
+  const int64_t used = ((n_piece + 7 * GP) >> lg) + GP;
   int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
   // "route_pool_pct" < 100 (tests): a pool too small on purpose — what finds no chunk goes straight into the output
   if (p->route_pool_pct > 0 && p->route_pool_pct < 100) pool_chunks = std::max<int64_t>(1, pool_chunks * p->route_pool_pct / 100);
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
+  const int n_sets = overlapped ? 2 : 1;  // record pools (and their counters, lists, fills), used in turn by the pieces
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
   uint16_t* d_codes = nullptr;
   void* d_w = nullptr;
@@ -313,95 +338,135 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
   } while (0)
   const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [1] signs seen, [2 .. 2 + P) chunks filed per partition; two sets
-  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8 * 2, stream));
-  HIPR(scratch_malloc((void**)&d_plist, (size_t)n_parts * pool_chunks * 4, stream));
-  HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
-  HIPR(scratch_malloc((void**)&d_codes, ((size_t)pool_chunks << lg) * 2, stream));
-  if (weighted) HIPR(scratch_malloc(&d_w, ((size_t)pool_chunks << lg) * (rec_f32 ? 4 : 8), stream));
+  const size_t rec_bytes = rec_f32 ? 4 : 8;
+  const size_t plist_elems = (size_t)n_parts * pool_chunks, pool_recs = ((size_t)pool_chunks << lg);
+  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8 * 2 * n_sets, stream));
+  HIPR(scratch_malloc((void**)&d_plist, plist_elems * 4 * n_sets, stream));
+  HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4 * n_sets, stream));
+  HIPR(scratch_malloc((void**)&d_codes, pool_recs * 2 * n_sets, stream));
+  if (weighted) HIPR(scratch_malloc(&d_w, pool_recs * rec_bytes * n_sets, stream));
 
-  Params kp;
-  memset(&kp, 0, sizeof kp);
-  const DimTable* dims = tset.dim;
-  for (int d = 0; d < D; ++d) {
-    kp.s_ptr[d] = samples[d].data;
-    kp.s_rs[d] = samples[d].row_stride;
-    kp.s_cs[d] = 1;
-    kp.s_dt[d] = samples[d].dtype;
-    kp.dim[d] = dims[d];
+  // the plan's own stream and events (overlapped form only); one overlapped enqueue at a time per plan
+  std::unique_lock<std::mutex> side_lock(p->side_mu, std::defer_lock);
+  hipStream_t side = stream;
+  if (overlapped) {
+    side_lock.lock();
+    if (!p->side_stream) HIPR(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+    while (p->side_events.size() < (size_t)2 * n_batches) {
+      hipEvent_t e = nullptr;
+      HIPR(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      p->side_events.push_back(e);
+    }
+    side = p->side_stream;
   }
-  if (weighted) {
-    kp.w_ptr = weights->data;
-    kp.w_rs = weights->row_stride;
-    kp.w_cs = 1;
-    kp.w_dt = weights->dtype;
-  }
-  kp.n_dims = D;
-  kp.tables = tset.blob;
-  kp.table_words = table_words;
-  kp.tables_in_lds = 1;
-  kp.n_rows = rows;
-  kp.n_cols = n_cols;
-  kp.n_bins = p->n_bins;
-  kp.out = out;
-  kp.segs = G;
-  kp.part_shift = shift;
-  kp.n_parts = n_parts;
-  kp.parts_per_row = parts_per_row;
-  RouteArgs ra;
-  ra.pool = d_ctr;
-  ra.pcount = d_ctr + 2;
-  ra.plist = d_plist;
-  ra.cmeta = d_cmeta;
-  ra.codes = d_codes;
-  ra.wrec = d_w;
-  ra.list_cap = (uint32_t)pool_chunks;
-  ra.chunk_log2 = lg;
-  ra.flags = d_ctr + 1;
-  ra.gate = nullptr;
-  ra.hint = nullptr;
-  ra.gate_mode = 0;
-  ra.dry = p->mixed_hint ? p->mixed_hint + 1 : nullptr;
 
   if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
   kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
                                                    : (kernel_fn_acc_chunks)part_accumulate_chunks<true, double>)
                                         : (kernel_fn_acc_chunks)part_accumulate_chunks<false, double>;
   if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+  kernel_fn_acc_chunks k_acc48 = (kernel_fn_acc_chunks)part_accumulate_chunks<true, double, true>;
+  if (pack) {
+    if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
+    if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+  }
 
   if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
     if (int rrc = rec.begin(profile)) return release(rrc);
-  if (int zrc = zero_output(d_ctr, ctr_words * 2, stream)) return release(zrc);
-  if (pack) {
-    kernel_fn_acc_chunks k_acc48 = (kernel_fn_acc_chunks)part_accumulate_chunks<true, double, true>;
-    if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
-    if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-    hipLaunchKernelGGL(k_route48, dim3(G), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
-    HIPR(hipGetLastError());
+  const DimTable* dims = tset.dim;
+  for (int k = 0; k < n_batches; ++k) {
+    const int set = k % n_sets;
+    const int64_t c0 = (int64_t)k * cols_piece;
+    int64_t nc = std::min<int64_t>(cols_piece, n_cols - c0);
+    if (n_cols - (c0 + nc) < tile) {  // what is left after this piece is less than a tile: it goes with this one
+      nc = n_cols - c0;
+      n_batches = k + 1;
+    }
+    Params kp;
+    memset(&kp, 0, sizeof kp);
+    for (int d = 0; d < D; ++d) {
+      kp.s_ptr[d] = advance(samples[d].data, samples[d].dtype, c0);
+      kp.s_rs[d] = samples[d].row_stride;
+      kp.s_cs[d] = 1;
+      kp.s_dt[d] = samples[d].dtype;
+      kp.dim[d] = dims[d];
+    }
+    if (weighted) {
+      kp.w_ptr = advance(weights->data, weights->dtype, c0);
+      kp.w_rs = weights->row_stride;
+      kp.w_cs = 1;
+      kp.w_dt = weights->dtype;
+    }
+    kp.n_dims = D;
+    kp.tables = tset.blob;
+    kp.table_words = table_words;
+    kp.tables_in_lds = 1;
+    kp.n_rows = rows;
+    kp.n_cols = nc;
+    kp.n_bins = p->n_bins;
+    kp.out = out;
+    kp.part_shift = shift;
+    kp.n_parts = n_parts;
+    kp.parts_per_row = parts_per_row;
+    const int Gk = (int)std::max<int64_t>(1, std::min<int64_t>(G, ((nc + tile - 1) / tile) * rows));
+    kp.segs = Gk;
+    uint32_t* ctr = d_ctr + (size_t)set * ctr_words * 4;  // (two counter sets of ctr_words 8-byte words each)
+    RouteArgs ra;
+    ra.pool = ctr;
+    ra.pcount = ctr + 2;
+    ra.plist = d_plist + (size_t)set * plist_elems;
+    ra.cmeta = d_cmeta + (size_t)set * pool_chunks;
+    ra.codes = d_codes + (size_t)set * pool_recs;
+    ra.wrec = weighted ? static_cast<char*>(d_w) + (size_t)set * pool_recs * rec_bytes : nullptr;
+    ra.list_cap = (uint32_t)pool_chunks;
+    ra.chunk_log2 = lg;
+    ra.flags = ctr + 1;
+    ra.gate = nullptr;
+    ra.hint = nullptr;
+    ra.gate_mode = 0;
+    ra.dry = p->mixed_hint ? p->mixed_hint + 1 : nullptr;
+
+    // this piece's pool was last read by the adding-up pass of piece k - 2
+    if (overlapped && k >= 2) HIPR(hipStreamWaitEvent(stream, p->side_events[(size_t)2 * (k - 2) + 1], 0));
+    if (int zrc = zero_output(ctr, ctr_words * 2, stream)) return release(zrc);
     RouteArgs ra48 = ra;
-    ra48.gate = d_ctr + 1;
-    ra48.gate_mode = 1;  // one sign: add the packed records up
-    hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, stream, ra48, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
+    if (pack) {
+      hipLaunchKernelGGL(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
+      HIPR(hipGetLastError());
+      ra48.gate = ctr + 1;
+      ra48.gate_mode = 1;  // one sign: add the packed records up
+      // both signs: the exact pass below runs (its own counters: the second set), otherwise its kernels return at once
+      ra.pool = ctr + 2 * ctr_words;
+      ra.pcount = ra.pool + 2;
+      ra.flags = ra.pool + 1;
+      ra.gate = ctr + 1;
+      ra.gate_mode = 2;
+      ra.hint = p->mixed_hint;
+    }
+    hipLaunchKernelGGL(k_route, dim3(Gk), dim3(block), lds_route, stream, kp, ra);
     HIPR(hipGetLastError());
-    // both signs: the exact pass below runs (its own counters: the second set), otherwise its kernels return at once
-    ra.pool = d_ctr + 2 * ctr_words;
-    ra.pcount = ra.pool + 2;
-    ra.flags = ra.pool + 1;
-    ra.gate = d_ctr + 1;
-    ra.gate_mode = 2;
-    ra.hint = p->mixed_hint;
+    if (overlapped) {
+      HIPR(hipEventRecord(p->side_events[(size_t)2 * k], stream));
+      HIPR(hipStreamWaitEvent(side, p->side_events[(size_t)2 * k], 0));
+    }
+    if (pack) {
+      hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, side, ra48, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
+      HIPR(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, side, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
+    HIPR(hipGetLastError());
+    if (overlapped) HIPR(hipEventRecord(p->side_events[(size_t)2 * k + 1], side));
   }
-  hipLaunchKernelGGL(k_route, dim3(G), dim3(block), lds_route, stream, kp, ra);
-  HIPR(hipGetLastError());
-  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
-  HIPR(hipGetLastError());
+  if (overlapped) HIPR(hipStreamWaitEvent(stream, p->side_events[(size_t)2 * (n_batches - 1) + 1], 0));  // join: the stream is in order
   {
-    char desc[512];
+    char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s pieces=%d%s",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
-             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
+             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64", n_batches,
+             overlapped ? " (adding-up pass of piece k on a second stream, under the routing pass of piece k + 1)" : "");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }

@@ -410,6 +410,13 @@ struct xhist_plan {
   int route_spl = 0;       // routing pass: samples per lane and tile (0 auto; 4 / 8 — 8 only with 1024-thread workgroups, float64)
   int flat_rows = 0;       // dense short rows streamed flat (hist_flat_rows): -1 off, 0 auto, 1 for any row length below 65536
   int min_parts = 0;       // partitioned mode: bins are cut finer until a pass has this many partitions (0 auto = 16; 1 = never)
+  // routing pass and adding-up pass of sample sub-batches on two streams (execute_partitioned_fused): "overlap" = sub-batches
+  // (0 auto, 1 off), "overlap_cus" = compute units the routing pass leaves to the adding-up pass (0 auto);
+  // "route_grid" / "acc_grid": workgroups of the two passes (0 auto) — A/B runs
+  int overlap = 0, overlap_cus = 0, route_grid = 0, acc_grid = 0;
+  hipStream_t side_stream = nullptr;       // created on first use, destroyed with the plan
+  std::vector<hipEvent_t> side_events;     // fork / join events of the sub-batch pipeline
+  std::mutex side_mu;                      // one overlapped enqueue at a time per plan
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never
   int arith_pref = 0;  // 0 auto, 1 table-free digitize whenever the edges are arithmetic, -1 never

@@ -468,6 +468,8 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
         if (t.blob) (void)hipFree(t.blob);
     if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : p->side_events) (void)hipEventDestroy(e);
+    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
     if (p->mixed_hint) (void)hipHostFree(p->mixed_hint);
   }
   delete p;
@@ -517,6 +519,18 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "slices")) {
     p->slices_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "overlap")) {
+    if (value < 0 || value > 64) return fail(XHIST_ERR_INVALID, "overlap must be in [0, 64] (sub-batches; 0 auto, 1 off)");
+    p->overlap = (int)value;
+  } else if (!strcmp(key, "overlap_cus")) {
+    if (value < 0 || value > 128) return fail(XHIST_ERR_INVALID, "overlap_cus must be in [0, 128]");
+    p->overlap_cus = (int)value;
+  } else if (!strcmp(key, "route_grid")) {
+    if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "route_grid must be in [0, 4096]");
+    p->route_grid = (int)value;
+  } else if (!strcmp(key, "acc_grid")) {
+    if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "acc_grid must be in [0, 4096]");
+    p->acc_grid = (int)value;
   } else if (!strcmp(key, "pack")) {
     p->pack_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "arith")) {

@@ -408,8 +408,8 @@ def _allreduce_host_partials_locked(group, parts, tag, shape, dtype, count):
         try:
             buf.upload(np.ascontiguousarray(part))
             comms[rank].allreduce(buf.ptr, count, tag, _native.REDUCE_SUM, 0)
+            comms[rank].wait(0)  # (a deadline instead of a hang when a peer GPU never enters the collective)
             if rank != 0:
-                buf.synchronize()
                 return None
             out = np.empty(shape, dtype)
             buf.download(out)
@@ -475,7 +475,7 @@ def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None, _all
 
                         def one(rank, device, acc):
                             comms[rank].allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
-                            acc.buf.synchronize()
+                            comms[rank].wait(0)
 
                         group.run(one, sums)
             total = sums[0].to_numpy()  # (download waits for the NULL stream of that GPU)
@@ -660,7 +660,7 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
                 tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
                 stream = torch.cuda.current_stream(t.device).cuda_stream
                 comms[rank].allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
-                torch.cuda.current_stream(t.device).synchronize()
+                comms[rank].wait(stream)
                 return t
 
             counts = group.run(allreduce, parts)[0]
