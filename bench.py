@@ -64,6 +64,8 @@ def parse():
                          "replaced by a no-op (nothing is measured; `metric` says so) — exercises rank spawn, both scaling legs, the "
                          "gathers and the JSON line, which no 1-GPU box can")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default N = 1 run also times BASELINE configs C3, C4 and C5 in short legs (`\"configs\"` of the line, <= 45 s); this turns that off")
     ap.add_argument("--profiler-pass", action="store_true",
                     help="only the main leg's launches: no 8 B/sample leg riding along (c2), no cold burst (c4) — for rocprofv3 passes "
                          "that attribute counters and launch counts to ONE kernel")
@@ -237,12 +239,42 @@ def main():
     for kv in args.tune:
         key, _, val = kv.partition("=")
         plan.set_param(key, int(val))
-    measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd,
-                       sync=lambda: torch.cuda.synchronize(dev), stream=torch.cuda.current_stream(dev).cuda_stream)
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def other_configs():
+        """BASELINE.json configs[2..4] (C3, C4, C5) under the same clock as the headline: short legs in this process after the
+        C2 legs, reported under `"configs"` of the one JSON line (metric / config / dtype stay C2's).  Hard wall budget:
+        steps shrink, sizes never; what does not fit the budget is reported as skipped, never as a smaller problem."""
+        import copy
+
+        out = {}
+        t_start = time.perf_counter()
+        budget_s = 45.0
+        for cfg, steps, warmup in (("c3", 10, 2), ("c4", 100, 30), ("c5", 10, 2)):
+            if time.perf_counter() - t_start > budget_s:
+                out[cfg] = {"skipped": "wall budget of %.0f s used up by the configs before it" % budget_s}
+                continue
+            a = copy.copy(args)
+            a.config, a.steps, a.warmup, a.full, a.unweighted, a.no_cpu_baseline, a.profiler_pass = cfg, steps, warmup, False, False, True, False
+            a.samples = 1_000_000_000  # BASELINE.json's sizes, whatever --samples the headline was given
+            wl2 = build_workload(cfg, a, torch, dev, rank)
+            plan2 = core._get_plan(wl2["edges"], _native.CMP_F64, local)
+            out[cfg] = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+            del wl2
+            torch.cuda.empty_cache()
+        return out
+
+    default_run = (args.config == "c2" and world == 1 and not args.unweighted and not args.profiler_pass and not args.tune and
+                   args.samples == 1_000_000_000 and not args.no_other_configs)
+    measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream,
+                       extra=other_configs if default_run else None)
 
 
-def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync, stream):
-    """the timed legs and the JSON line (shared with --selftest, which passes a plan double and CPU tensors)"""
+def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync, stream, extra=None, as_extra=False):
+    """the timed legs and the JSON line (shared with --selftest, which passes a plan double and CPU tensors).
+    extra: callable returning the `"configs"` object (the other BASELINE configs, measured before the line is printed);
+    as_extra: this call IS one of those — return its summary instead of printing a line"""
     arrays, w, edges = wl["arrays"], wl["weights"], wl["edges"]
     weighted = w is not None
     n_rows = wl["rows"]
@@ -447,6 +479,15 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             roof["cold"] = {"launches": len(m["cold_ms"]), "after_idle_s": 0.5, "kernel_ms_mean": c_ms, "kernel_ms": [round(float(v), 4) for v in m["cold_ms"]],
                             "achieved": c_ach, "frac": c_ach / HBM_PEAK_GBS}
             roof["cold_frac"] = c_ach / HBM_PEAK_GBS
+        if as_extra:
+            summary = {"workload": wl["workload"], "metric": wl["metric"], "dtype": wl["dtype"], "steps": args.steps, "warmup": args.warmup,
+                       "value": m["value"], "unit": "samples/s", "ms_per_step": m["ms_per_step"], "kernel_ms_mean": roof["kernel_ms_mean"],
+                       "kernel_ms_min": roof["kernel_ms_min"], "achieved_GBps": roof["achieved"], "frac": roof["frac"],
+                       "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "kernel": m["desc"]}
+            if "cold_frac" in roof:
+                summary["cold_frac"] = roof["cold_frac"]
+                summary["cold_kernel_ms_mean"] = roof["cold"]["kernel_ms_mean"]
+            return summary
         if unweighted_leg is not None:
             u = unweighted_leg
             ur = roofline(u)
@@ -461,6 +502,10 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         for name, leg in legs.items():
             if name != main_leg:
                 line[name] = leg_summary(leg)
+        if extra is not None:
+            t0 = time.perf_counter()
+            line["configs"] = extra()
+            line["configs"]["wall_s"] = round(time.perf_counter() - t0, 2)
         if world == 1 and not args.no_cpu_baseline and not args.selftest:
             nflat = arrays[0].numel()
             k = min(args.cpu_sample // max(1, len(arrays)), nflat)

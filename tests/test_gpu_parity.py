@@ -2388,3 +2388,32 @@ def test_packed_bucket_entries_many_rows_and_ragged_tiles(xh):
         x[:, ::5] = rng.choice(edges[0], size=x[:, ::5].shape)  # plenty of samples ON an edge: the exact redo runs in most wavefronts
         got, desc = _run(xh, [x, y], edges, None, True)
         np.testing.assert_array_equal(got, onp.bincount_rows([x, y], edges), err_msg=desc)
+
+
+@pytest.mark.parametrize("name", ["sqrt", "sturges", "rice", "scott", "fd", "auto", "doane", "stone"])
+def test_bin_estimators_cut_float32_data_to_the_range_in_float32(xh, name):
+    """numpy's keep mask compares float32 data with the range bounds ROUNDED TO float32 (NEP 50), so elements equal
+    to float32(lo) < lo are kept — data clipped to 0.7 with range=(0.7, 1.0) has many of them"""
+    rng = np.random.default_rng(11)
+    a = np.clip(rng.uniform(0.0, 1.2, 40_000), 0.7, 1.1).astype(np.float32)
+    assert np.float32(0.7) < 0.7 and (a == np.float32(0.7)).sum() > 1000
+    t = _dev(a)
+    for r in ((0.7, 1.0), (0.7, 0.7), (0.3, 1.1)):
+        want = np.histogram_bin_edges(a, bins=name, range=r)
+        got = xh._device_bin_edges(t, name, r, False)
+        np.testing.assert_array_equal(got, want, err_msg=str((name, r)))
+
+
+@pytest.mark.parametrize("name", ["sqrt", "sturges", "rice", "scott"])
+def test_moment_estimators_leave_huge_64_bit_integers_to_numpy(xh, name):
+    """int64 magnitudes of 2^53 and more are not exact in the float64 reduction; numpy's integer arithmetic is"""
+    rng = np.random.default_rng(12)
+    a = (2 ** 60 + rng.integers(0, 1000, 5000)).astype(np.int64)
+    t = _dev(a)
+    want = np.histogram_bin_edges(a, bins=name)
+    got = xh._device_bin_edges(t, name, None, False)
+    np.testing.assert_array_equal(got, want)
+    assert xh._device_estimator_edges(t, name, None, np.dtype(np.int64), False) is None  # declined, not guessed
+    b = rng.integers(-(2 ** 40), 2 ** 40, 5000).astype(np.int64)  # ordinary 64-bit integers stay on the device
+    assert xh._device_estimator_edges(_dev(b), name, None, np.dtype(np.int64), False) is not None
+    np.testing.assert_array_equal(xh._device_bin_edges(_dev(b), name, None, False), np.histogram_bin_edges(b, bins=name))

@@ -468,6 +468,37 @@ def test_a_launched_rank_keeps_to_its_gpu(monkeypatch, var):
     assert multigpu.get_devices() == [0, 1, 2, 3, 4, 5, 6, 7]
 
 
+def test_launcher_rank_is_clamped_to_the_visible_gpus_and_a_lone_task_owns_the_node(monkeypatch):
+    """under srun --gpus-per-task=1 / --gpu-bind every task sees ONE GPU (device 0) whatever its local
+    rank; and a single task on a node (srun -n1 around a multi-GPU process) must keep every visible GPU"""
+    from xhistogram_amd import _native, core
+
+    for k in core.LOCAL_RANK_VARS + core.LOCAL_SIZE_VARS + ("XHIST_AMD_DEVICES",):
+        monkeypatch.delenv(k, raising=False)
+    multigpu.set_devices(None)
+    monkeypatch.setattr(multigpu, "visible_devices", lambda: [0, 1, 2, 3])
+    monkeypatch.setenv("SLURM_LOCALID", "3")
+    monkeypatch.setattr(_native, "device_count", lambda: 1)
+    assert core.default_device() == 0 and multigpu.get_devices() == [0]  # bound to one GPU: local rank 3 is device 0
+    monkeypatch.setattr(_native, "device_count", lambda: 4)
+    assert core.default_device() == 3 and multigpu.get_devices() == [3]
+    monkeypatch.setattr(_native, "device_count", lambda: 2)
+    assert core.default_device() == 1  # two GPUs shared by four tasks
+    # one task on the node: it is not "a rank that keeps to its GPU"
+    monkeypatch.setenv("SLURM_LOCALID", "0")
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "1")
+    assert multigpu.get_devices() == [0, 1, 2, 3]
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "4(x2)")  # Slurm's notation for "4 tasks on each of 2 nodes"
+    assert core.launcher_local_size() == 4 and multigpu.get_devices() == [0]
+    monkeypatch.delenv("SLURM_NTASKS_PER_NODE")
+    monkeypatch.delenv("SLURM_LOCALID")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "0")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "1")
+    assert multigpu.get_devices() == [0, 1, 2, 3]
+    monkeypatch.setenv("XHIST_AMD_DEVICE", "7")  # explicit: never second-guessed
+    assert core.default_device() == 7
+
+
 def test_device_containers_pickle_through_host_memory_or_fail_loudly():
     """DeviceBuffer / DevicePartial / DeviceArray must never pickle as a bare pointer.  Here (no GPU) the
     serialising side is a double and the receiving side has no device: unpickling raises instead of producing a foreign

@@ -109,11 +109,47 @@ def launcher_local_rank():
     return None
 
 
+# how many tasks the launcher started on THIS node (torch.distributed.run, Slurm, Open MPI, MVAPICH2, MPICH-hydra)
+LOCAL_SIZE_VARS = ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "SLURM_STEP_TASKS_PER_NODE", "SLURM_TASKS_PER_NODE",
+                   "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS")
+
+
+def launcher_local_size():
+    """tasks of this job on this node as the launcher reports them, or None when it does not say
+    (Slurm writes e.g. "4(x2)" or "2,1": the leading integer is this node's count)"""
+    for key in LOCAL_SIZE_VARS:
+        v = os.environ.get(key)
+        if v in (None, ""):
+            continue
+        digits = ""
+        for ch in v.strip():
+            if not ch.isdigit():
+                break
+            digits += ch
+        if digits:
+            return int(digits)
+    return None
+
+
 def default_device():
     """GPU used for host (numpy) inputs: $XHIST_AMD_DEVICE, else the launcher's local rank ($LOCAL_RANK, $SLURM_LOCALID,
-    $OMPI_COMM_WORLD_LOCAL_RANK, …), else 0."""
+    $OMPI_COMM_WORLD_LOCAL_RANK, …) — taken modulo the number of GPUs this process can see: a task the launcher bound to ONE
+    GPU (srun --gpus-per-task=1 / --gpu-bind, ROCR_VISIBLE_DEVICES: every task sees its GPU as device 0) has local rank k
+    and device 0 — else 0."""
+    explicit = os.environ.get("XHIST_AMD_DEVICE")
+    if explicit not in (None, ""):
+        try:
+            return int(explicit)  # (the user's own choice is not second-guessed: a wrong index fails loudly in require_device)
+        except ValueError:
+            pass
     r = launcher_local_rank()
-    return 0 if r is None else r
+    if r is None:
+        return 0
+    try:
+        n = _native.device_count()
+    except Exception:
+        n = 0
+    return r % n if n > 0 else r
 
 
 _tls = threading.local()
@@ -782,6 +818,18 @@ ESTIMATORS_FROM_MOMENTS = ("sqrt", "sturges", "rice", "scott")
 ESTIMATORS_FROM_QUARTILES = ("fd", "auto")  # float32 / float64 torch tensors: _device_quartile_edges
 
 
+def _range_cut(r, proto_dtype):
+    """the (lo, hi) the data is cut to before a bin-width selector sees it, as numpy's `keep` mask compares: an empty range
+    is widened by half a unit each way first (_get_outer_edges), and float32 data meets the bounds ROUNDED TO float32 —
+    numpy compares a float32 array with a Python float in float32 (NEP 50 weak scalars), so an element equal to
+    float32(lo) < lo is kept (data clipped to 0.7 with range=(0.7, 1.0): 8 bins, not 1)"""
+    lo, hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+    if proto_dtype == np.float32:
+        with np.errstate(over="ignore"):
+            lo, hi = float(np.float32(lo)), float(np.float32(hi))
+    return lo, hi
+
+
 def _estimator_cut(name, r, proto_dtype):
     """(supported, lo_hi): whether `name` is one of the estimators that need only moments of data of this dtype, and the
     range the data is cut to before the selector sees it (None: all of it).  numpy validates the range (its own errors)."""
@@ -792,8 +840,7 @@ def _estimator_cut(name, r, proto_dtype):
     if np.ndim(r[0]) or np.ndim(r[1]):
         return False, None
     np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
-    # (an empty range is widened by half a unit each way BEFORE the data is cut to it: _get_outer_edges)
-    return True, ((float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1])))
+    return True, _range_cut(r, proto_dtype)
 
 
 def _device_moments(a, lo_hi, want_m2):
@@ -979,7 +1026,7 @@ def _device_quartile_edges(a, name, r, proto_dtype, resident):
         if np.ndim(r[0]) or np.ndim(r[1]):
             return None
         np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
-        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+        lo_hi = _range_cut(r, proto_dtype)
     n, mn, mx, _, _ = _device_moments(a, lo_hi, False)
     n = int(n)
     if n == 0:
@@ -1029,7 +1076,7 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
         if np.ndim(r[0]) or np.ndim(r[1]):
             return None
         np.histogram_bin_edges(np.zeros(0, proto_dtype), bins=1, range=r)
-        lo_hi = (float(r[0]) - 0.5, float(r[1]) + 0.5) if r[0] == r[1] else (float(r[0]), float(r[1]))
+        lo_hi = _range_cut(r, proto_dtype)
     n, mn, mx, _, _ = _device_moments(a, lo_hi, False)
     n = int(n)
     if n == 0:
@@ -1047,14 +1094,21 @@ def _device_doane_stone_edges(a, name, r, proto_dtype, resident):
             if n <= 2:
                 return 0.0
             sg1 = np.sqrt(6.0 * (n - 2) / ((n + 1.0) * (n + 3)))
-            xd = flat.to(torch.float64)
-            if lo_hi is not None:
-                xd = xd[(xd >= lo_hi[0]) & (xd <= lo_hi[1])]
-            mean = xd.mean()
-            sigma = float(torch.sqrt(((xd - mean) ** 2).mean()))
-            if not sigma > 1e-5 * max(abs(mx), abs(mn)):
-                return None if sigma > 0.0 or mx != mn else 0.0  # exactly constant data: numpy's 0.0 as well
-            g1 = float((((xd - mean) / sigma) ** 3).mean())
+            # (float64 temporaries of the whole array live on the GPU here — several times a float32 input; a device that
+            # cannot hold them hands the case to numpy on a host copy instead of failing: ADVICE r3)
+            try:
+                xd = flat.to(torch.float64)
+                if lo_hi is not None:
+                    xd = xd[(xd >= lo_hi[0]) & (xd <= lo_hi[1])]
+                mean = xd.mean()
+                xd = xd - mean  # (a tensor of our own from here on — `flat.to` may have returned the caller's — so the division below is in place)
+                sigma = float(torch.sqrt((xd ** 2).mean()))
+                if not sigma > 1e-5 * max(abs(mx), abs(mn)):
+                    return None if sigma > 0.0 or mx != mn else 0.0  # exactly constant data: numpy's 0.0 as well
+                xd /= sigma
+                g1 = float((xd ** 3).mean())
+            except torch.cuda.OutOfMemoryError:
+                return None
             return ptp / (1.0 + np.log2(n) + np.log2(1.0 + np.absolute(g1) / sg1))
     else:
         upper = max(100, int(np.sqrt(n)))
@@ -1092,6 +1146,11 @@ def _device_estimator_edges(a, name, r, proto_dtype, resident):
         return None
     size = a.size if resident else a.numel()
     moments = _device_moments(a, lo_hi, name == "scott") if size else None
+    if moments is not None and proto_dtype.kind in "iu" and proto_dtype.itemsize == 8 and int(moments[0]) > 0:
+        # the reduction reads every element as float64: 64-bit integers of magnitude 2^53 and more would come back rounded,
+        # where numpy's min / max / ptp are exact integer arithmetic — numpy on a host copy decides those
+        if not (abs(moments[1]) < 2.0 ** 53 and abs(moments[2]) < 2.0 ** 53):
+            return None
     return _edges_from_moments(name, r, proto_dtype, size, moments)
 
 

@@ -91,7 +91,12 @@ static kernel_fn fast_pick_pack(int hist) {
     constexpr int U = unroll_for(D, VEC, SCAN);
     if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
     if (hist == kHistPacked) {
-      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+#ifdef XHIST_PACKED_UNROLL  // development A/B only, see fast_pick
+      constexpr int UP = XHIST_PACKED_UNROLL;
+#else
+      constexpr int UP = U;
+#endif
+      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, UP, kHistPacked, SCAN>;
     }
   }
   return nullptr;

@@ -88,7 +88,10 @@ def get_devices():
         if env:
             spec = "all" if env.lower() == "all" else [int(t) for t in env.split(",") if t.strip() != ""]
     if spec is None and core.launcher_local_rank() is not None:
-        return [core.default_device()]  # a rank of a one-process-per-GPU job (torchrun, srun, mpirun) keeps to its GPU
+        # a rank of a one-process-per-GPU job (torchrun, srun, mpirun) keeps to its GPU — unless the launcher says this is
+        # the ONLY task on the node (srun -n1 / mpirun -n 1 around a single-process multi-GPU job): that one owns them all
+        if core.launcher_local_size() != 1 or os.environ.get("XHIST_AMD_DEVICE") not in (None, ""):  # (the library's own variable always pins)
+            return [core.default_device()]
     if spec is None or spec == "all":
         return visible_devices() or [core.default_device()]
     return list(spec)
