@@ -67,7 +67,8 @@ def _worker(rank, world, port, case, q):
         conv = (lambda a: torch.from_numpy(np.ascontiguousarray(a))) if use_torch else (lambda a: a)
         mine = [conv(a[tuple(sl)]) for a in full]
         wmine = None if wfull is None else conv(wfull[tuple(sl)])
-        h, edges = xd.histogram(*mine, weights=wmine, shard_axis=shard_axis, _local=_oracle_local, **kw)
+        with xd._hooks(local=_oracle_local):  # (module-private test hook: the oracle is the rank-local compute on CPU)
+            h, edges = xd.histogram(*mine, weights=wmine, shard_axis=shard_axis, **kw)
         want, wedges = onp.histogram(*full, weights=wfull, **kw)
         h = h.numpy() if hasattr(h, "numpy") else np.asarray(h)
         ok = h.shape == want.shape and np.allclose(h, want, rtol=1e-12, atol=0, equal_nan=True)

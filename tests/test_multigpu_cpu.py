@@ -193,7 +193,8 @@ def test_sharded_tensors_reduce_and_gather_logic(case):
             continue
         args = [_cpu_shards(a, 3, shard_axis) for a in full]
         ws = None if w is None else _cpu_shards(w, 3, shard_axis)
-        got, edges = multigpu.histogram(*args, weights=ws, _local=_local_oracle, _reduce=lambda parts: sum(parts[1:], parts[0].clone()), **kw)
+        with multigpu._hooks(local=_local_oracle, reduce=lambda parts: sum(parts[1:], parts[0].clone())):
+            got, edges = multigpu.histogram(*args, weights=ws, **kw)
         want, _ = onp.histogram(*full, weights=w, **kw)
         np.testing.assert_allclose(got.numpy(), want, rtol=1e-12, equal_nan=True)
         assert tuple(got.shape) == np.asarray(want).shape
@@ -203,13 +204,13 @@ def test_sharded_inputs_must_match():
     a = _cpu_shards(np.zeros((6, 4)), 2, 0)
     b = _cpu_shards(np.zeros((6, 4)), 2, 1)
     with pytest.raises(ValueError):
-        multigpu.histogram(a, b, bins=[np.arange(3.0)] * 2, _local=_local_oracle)
+        multigpu.histogram(a, b, bins=[np.arange(3.0)] * 2)
     # sharded weights are cut like the inputs: another axis or other part shapes is an error, not a silent mismatch
     with pytest.raises(ValueError, match="sharded weights"):
-        multigpu.histogram(a, bins=[np.arange(3.0)], weights=b, _local=_local_oracle)
+        multigpu.histogram(a, bins=[np.arange(3.0)], weights=b)
     c = _cpu_shards(np.zeros((8, 4)), 2, 0)
     with pytest.raises(ValueError, match="sharded weights"):
-        multigpu.histogram(a, bins=[np.arange(3.0)], weights=c, _local=_local_oracle)
+        multigpu.histogram(a, bins=[np.arange(3.0)], weights=c)
     with pytest.raises(TypeError):
         multigpu.histogram(np.zeros(4), bins=3)
 
@@ -232,13 +233,15 @@ def test_sharded_inputs_take_the_cheap_bin_estimators(name):
     for shard_axis in (0, 1):
         sx = _cpu_shards(x, 3, shard_axis)
         for r in (None, (-2.0, 4.5)):
-            got, edges = multigpu.histogram(sx, bins=name, range=r, _local=_local_oracle, _moments=moments,
-                                            _reduce=lambda parts: sum(parts[1:], parts[0].clone()))
+            with multigpu._hooks(local=_local_oracle, moments=moments, reduce=lambda parts: sum(parts[1:], parts[0].clone())):
+                got, edges = multigpu.histogram(sx, bins=name, range=r)
             want_e = np.histogram_bin_edges(x, bins=name, range=r)
             np.testing.assert_array_equal(edges[0], want_e)
             np.testing.assert_array_equal(np.asarray(got), np.histogram(x, bins=want_e)[0])
-    with pytest.raises(TypeError, match="estimators"):
-        multigpu.histogram(_cpu_shards(x, 2, 0), bins="fd", _local=_local_oracle, _moments=moments)
+    with pytest.raises(TypeError, match="estimators"), multigpu._hooks(local=_local_oracle, moments=moments):
+        multigpu.histogram(_cpu_shards(x, 2, 0), bins="fd")
+    with pytest.raises(TypeError):  # the hooks are not keyword arguments of the public function
+        multigpu.histogram(_cpu_shards(x, 2, 0), bins=5, _local=_local_oracle)
 
 
 # ---- bench.py --gpus N spawns its own ranks -------------------------------------------------------

@@ -609,6 +609,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       return rec.end(desc);
     }
   }
+  // the flat kernel was the only reason to be here and was not launched (no such variant, or its LDS does not fit): beyond
+  // the column limits of the scratch-transpose route the row-streaming kernels are the faster answer
+  if (use_flat && !(all_rowmajor && n_cols <= ((D == 1 && !weighted) ? 400 : 80))) return XHIST_ERR_UNSUPPORTED;
   if (lds_least > p->lds_max) return XHIST_ERR_UNSUPPORTED;
   // one contiguous-row input, unweighted, < 65536 columns: fused load-transpose-count kernel
   if (transpose && D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0) {

@@ -24,6 +24,8 @@ reference does for dask inputs (core.py:377-381).
 
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 from . import core
@@ -218,8 +220,27 @@ def _default_local(arrays, has_weights, axis, edges, block_size):
     return core._bincount(*arrays, weights=has_weights, axis=axis, bins=edges, density=False, block_size=block_size)
 
 
+# Test hook (module-private, not part of any signature): the CPU tests run the collective logic under gloo with the oracle as
+# the rank-local compute.  Set only through `_hooks(local=...)` in tests/; production code never touches it.
+_test_hooks = {"local": None}
+
+
+@contextlib.contextmanager
+def _hooks(**kw):
+    """tests only: `with distributed._hooks(local=fn): ...` swaps the rank-local compute for the duration of the block"""
+    unknown = set(kw) - set(_test_hooks)
+    if unknown:
+        raise TypeError("unknown hook(s): %s" % sorted(unknown))
+    saved = dict(_test_hooks)
+    _test_hooks.update(kw)
+    try:
+        yield
+    finally:
+        _test_hooks.update(saved)
+
+
 def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto",
-              shard_axis=0, group=None, gather=True, _local=None):
+              shard_axis=0, group=None, gather=True):
     """``xhistogram.core.histogram`` over data sharded across the ranks of a process group.
 
     Every rank calls this with ITS shard of each argument (same shapes except along
@@ -228,13 +249,12 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     ``(hist, bin_edges)`` with ``hist`` on every rank: the all-reduced full histogram when
     ``shard_axis`` is one of the histogrammed axes, else the row-gathered one (this rank's rows
     only with ``gather=False``).  ``group`` is a torch.distributed process group (None = the default
-    one) or a :class:`xhistogram_amd._native.Comm` (the C ABI's own RCCL communicator).  ``_local`` swaps the rank-local compute (tests run the
-    collective logic on CPU with the oracle; production never sets it).
+    one) or a :class:`xhistogram_amd._native.Comm` (the C ABI's own RCCL communicator).
     """
     import torch
 
     ex = _exchange(group)
-    local = _local or _default_local
+    local = _test_hooks["local"] or _default_local
 
     n_inputs = len(args)
     all_arrays = list(args)

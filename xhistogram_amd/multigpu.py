@@ -582,8 +582,26 @@ def _global_edges(args, bins, ranges, group, _extrema, _moments=None):
     return out
 
 
-def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", exchange="rccl",
-              _local=None, _reduce=None, _extrema=None, _moments=None):
+# Test hooks (module-private, not part of any signature): the CPU tests run the sharding and exchange logic with the oracle as
+# the per-shard compute and a plain sum as the exchange.  Set only through `_hooks(...)` in tests/; production never does.
+_test_hooks = {"local": None, "reduce": None, "extrema": None, "moments": None}
+
+
+@contextlib.contextmanager
+def _hooks(**kw):
+    """tests only: `with multigpu._hooks(local=fn, reduce=fn): ...` for the duration of the block"""
+    unknown = set(kw) - set(_test_hooks)
+    if unknown:
+        raise TypeError("unknown hook(s): %s" % sorted(unknown))
+    saved = dict(_test_hooks)
+    _test_hooks.update(kw)
+    try:
+        yield
+    finally:
+        _test_hooks.update(saved)
+
+
+def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", exchange="rccl"):
     """``core.histogram`` of :class:`Sharded` inputs (same shard axis and devices for all; ``weights`` a
     Sharded too, or an array every shard broadcasts against).  Each GPU's thread bins its shard with the
     fused kernel; then
@@ -593,8 +611,8 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     * shard axis kept               -> the shards' rows are copied to the first GPU and concatenated;
 
     density (core.py:444-462) is applied after the exchange.  Returns ``(hist, edges)`` with ``hist`` a
-    torch tensor on ``devices[0]``.  ``_local`` / ``_reduce`` / ``_extrema`` / ``_moments`` are test seams (the CPU tests
-    run the sharding and exchange logic with the oracle as the per-shard compute); production never sets them."""
+    torch tensor on ``devices[0]``."""
+    _local, _reduce, _extrema, _moments = (_test_hooks[k] for k in ("local", "reduce", "extrema", "moments"))
     if not args or not all(isinstance(a, Sharded) for a in args):
         raise TypeError("multigpu.histogram takes Sharded inputs (see multigpu.scatter); plain arrays go to core.histogram")
     first = args[0]
