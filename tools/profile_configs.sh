@@ -26,4 +26,12 @@ for c in "${configs[@]}"; do
   done
   echo "$name done: $(python -c "import json; d=json.load(open('$out/${name}_bench.json')); print('%.4g samples/s, kernel %.3f ms, frac %.3f' % (d['value'], d['roofline']['kernel_ms_mean'], d['roofline']['frac']))" 2>&1)"
 done
-(cd "$R" && git rev-parse --short HEAD 2>/dev/null || echo "snapshot") > "$out/code_state.txt"
+# the code state every file of this set was measured on: the commit when the box has .git (it does not under gpurun: the
+# caller passes XHIST_CODE_STATE=$(git rev-parse --short HEAD)), so that *_bench.json, traffic.json and this file agree
+echo "${XHIST_CODE_STATE:-$(cd "$R" && git rev-parse --short HEAD 2>/dev/null || echo snapshot)}" > "$out/code_state.txt"
+# regression gate over the shape scanners (tools/check_cliffs.py): every evidence set carries its own cells
+if [ "${XHIST_SKIP_CLIFFS:-0}" != 1 ]; then
+  python "$R/tools/check_cliffs.py" run "$out/cliffs" > "$out/cliffs_run.log" 2>&1 \
+    && python "$R/tools/check_cliffs.py" compare "$R/profiles/cliffs_baseline" "$out/cliffs" > "$out/cliffs_gate.txt" 2>&1
+  tail -3 "$out/cliffs_gate.txt" 2>/dev/null
+fi
