@@ -2319,6 +2319,9 @@ def _sorted_uniform(rng, n, lo, hi):
 _PACK_EDGES = {
     "c3_like_257": lambda rng: _sorted_uniform(rng, 257, -4.0, 4.0),
     "geometric_300": lambda rng: np.geomspace(1e-3, 50.0, 300),
+    "geometric_2001": lambda rng: np.geomspace(1e-3, 50.0, 2001),
+    "logspace_negative": lambda rng: -np.logspace(3, -2, 400),
+    "symlog": lambda rng: np.concatenate([-np.geomspace(50.0, 1e-3, 200), [0.0], np.geomspace(1e-3, 50.0, 200)]),
     "negative_129": lambda rng: _sorted_uniform(rng, 129, -1000.0, -999.0),
     "few_5": lambda rng: np.array([-1.0, -0.25, 0.1, 0.7, 3.0]),
     "two_edges": lambda rng: np.array([0.3, 0.7]),
@@ -2332,7 +2335,8 @@ _PACK_EDGES = {
     "cluster_of_five": lambda rng: np.sort(np.concatenate([rng.uniform(-2, 2, 60), 0.123 + np.arange(5) * 1e-9])),
 }
 _PACK_NOT_OFFERED = {"beyond_float32", "below_float32", "one_float32_ulp", "duplicates", "cluster_of_five"}
-_PACK_EITHER = {"two_edges", "geometric_300"}  # (a linear bucket grid may or may not separate these)
+_PACK_EITHER = {"two_edges", "symlog"}  # (no bucket grid of the LDS budget separates the edges around zero of a symmetric log axis)
+_PACK_KEY_MAP = {"geometric_300", "geometric_2001", "logspace_negative"}  # float-bits buckets (scan=8)
 
 
 @pytest.mark.parametrize("weights", [None, "f64", "f32"])
@@ -2345,11 +2349,16 @@ def test_packed_bucket_entries_1d_on_and_around_every_edge(xh, kind, weights):
     want = onp.bincount_rows([x], edges, w)
     got, desc = _run(xh, [x], edges, w, True, pack=1)
     assert_hist_equal(got, want, w is not None)
-    offered = "scan=6" in desc or "scan=7" in desc
+    offered = "scan=6" in desc or "scan=7" in desc or "scan=8" in desc
     if kind in _PACK_NOT_OFFERED:
         assert not offered, desc
     elif kind not in _PACK_EITHER:
-        assert offered and "family=fast" in desc, desc
+        assert ("scan=8" in desc or offered) and "family=fast" in desc, desc
+    if kind in _PACK_KEY_MAP:
+        assert "scan=8" in desc, desc
+        got, desc = _run(xh, [x], edges, w, True)  # and it is the automatic choice where the alternative is a binary search
+        assert "scan=8" in desc, desc
+        assert_hist_equal(got, want, w is not None)
     got, _ = _run(xh, [x], edges, w, True, pack=-1)
     assert_hist_equal(got, want, w is not None)
 
@@ -2396,7 +2405,7 @@ def test_bin_estimators_cut_float32_data_to_the_range_in_float32(xh, name):
     to float32(lo) < lo are kept — data clipped to 0.7 with range=(0.7, 1.0) has many of them"""
     rng = np.random.default_rng(11)
     a = np.clip(rng.uniform(0.0, 1.2, 40_000), 0.7, 1.1).astype(np.float32)
-    assert np.float32(0.7) < 0.7 and (a == np.float32(0.7)).sum() > 1000
+    assert float(np.float32(0.7)) < 0.7 and (a == np.float32(0.7)).sum() > 1000
     t = _dev(a)
     for r in ((0.7, 1.0), (0.7, 0.7), (0.3, 1.1)):
         want = np.histogram_bin_edges(a, bins=name, range=r)
@@ -2408,7 +2417,7 @@ def test_bin_estimators_cut_float32_data_to_the_range_in_float32(xh, name):
 def test_moment_estimators_leave_huge_64_bit_integers_to_numpy(xh, name):
     """int64 magnitudes of 2^53 and more are not exact in the float64 reduction; numpy's integer arithmetic is"""
     rng = np.random.default_rng(12)
-    a = (2 ** 60 + rng.integers(0, 1000, 5000)).astype(np.int64)
+    a = (2 ** 60 + rng.integers(0, 2 ** 40, 5000)).astype(np.int64)  # (a span float64 edges can still resolve: numpy itself refuses less)
     t = _dev(a)
     want = np.histogram_bin_edges(a, bins=name)
     got = xh._device_bin_edges(t, name, None, False)
@@ -2417,3 +2426,16 @@ def test_moment_estimators_leave_huge_64_bit_integers_to_numpy(xh, name):
     b = rng.integers(-(2 ** 40), 2 ** 40, 5000).astype(np.int64)  # ordinary 64-bit integers stay on the device
     assert xh._device_estimator_edges(_dev(b), name, None, np.dtype(np.int64), False) is not None
     np.testing.assert_array_equal(xh._device_bin_edges(_dev(b), name, None, False), np.histogram_bin_edges(b, bins=name))
+
+
+def test_packed_bucket_entries_joint_of_a_log_axis_and_a_linear_one(xh):
+    """the map is chosen per dimension: geometric edges (float-bits buckets) next to uneven linear ones"""
+    rng = np.random.default_rng(440)
+    edges = [np.geomspace(1e-4, 10.0, 100), _sorted_uniform(rng, 80, -4.0, 4.0)]  # (float64 sums of 99 x 79 bins still fit LDS)
+    cols = [_pack_torture(e, rng, 80_000) for e in edges]
+    n = min(c.shape[1] for c in cols)
+    x, y = cols[0][:, :n].copy(), np.roll(cols[1][:, :n], 4099, axis=1)
+    for w in (None, rng.uniform(0, 1, x.shape)):
+        got, desc = _run(xh, [x, y], edges, w, True)
+        assert "scan=8" in desc and "family=fast" in desc, desc
+        assert_hist_equal(got, onp.bincount_rows([x, y], edges, w), w is not None)

@@ -35,6 +35,8 @@ cases = [
     ("1d 257 nonuniform", [nonuniform(257, 1)], False),
     ("1d 257 nonuniform, weighted", [nonuniform(257, 1)], True),
     ("1d 2001 geometric", [np.geomspace(1e-3, 4.0, 2001)], False),
+    ("1d 300 geometric, weighted", [np.geomspace(1e-3, 4.0, 301)], True),
+    ("2d 200 geometric x 200 geometric", [np.geomspace(1e-3, 4.0, 201), np.geomspace(1e-2, 5.0, 201)], False),
 ]
 for name, edges, weighted in cases:
     if only and only not in name:

@@ -1016,13 +1016,13 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     // dimension instead of two dependent ones — where the histogram stays in LDS with them.  Measured for joint histograms
     // (C3: see DESIGN 4); 1-D histograms keep the two-level tables unless "pack" = 1.
     if (fast && !mixed && !two && !i64dom && sdt == XHIST_F64 && p->pk_np && pack_pref >= 0 && scan != kScanArith && tables_fit &&
-        (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || pack_pref > 0)) {
+        (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || scan == 0 || pack_pref > 0)) {  // (scan 0: the alternative is a binary search)
       const int h0 = hist, c0 = cl2;
       const size_t b0 = hist_bytes, tb = (size_t)p->ts_pk.words * 8;
       if (tb + 1024 <= lds_cap) {
         place(tb, true);
         if ((hist == kHistLds || hist == kHistPacked) && (hist == h0 || pack_pref > 0)) {
-          scan = p->pk_np == 2 ? kScanPack2 : kScanPack3;
+          scan = p->pk_np == 2 ? kScanPack2 : (p->pk_np == 3 ? kScanPack3 : kScanPackG);
           tset = &p->ts_pk;
           table_bytes = tb;
         } else {

@@ -57,6 +57,12 @@ struct DimTable {
   // the kernels' own arithmetic, doubled for margin): a sample whose position t = (x - e_0) * inv_step has a fractional
   // part with |frac - 0.5| < arith_h lies strictly inside bin floor(t) (bin_arith_fast).  0 = never decide by arithmetic.
   double arith_h;
+  // packed bucket entries (count_le_pack): bucket map of this dimension — 0: linear in (float)x (scale / bias above),
+  // 1: the float32 BIT PATTERN of x (an order-preserving integer key, (key - key_lo) >> key_shift): uniform in log x —
+  // geometric / logarithmic edges, which a linear grid piles into its first buckets
+  int32_t map_kind;
+  uint32_t key_lo;
+  int32_t key_shift;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
   int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
@@ -297,15 +303,43 @@ __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool&
 // and the entries hold start - 1, so what comes out is the bin itself and the range test is `bin < nb` (unsigned):
 // no float64 compare, no subtraction.
 // ---------------------------------------------------------------------------------------------
-constexpr int kScanPack2 = 6, kScanPack3 = 7;
-constexpr bool scan_is_pack(int scan) { return scan == kScanPack2 || scan == kScanPack3; }
+constexpr int kScanPack2 = 6, kScanPack3 = 7;  // linear bucket map in every dimension, at most 2 / 3 edges per bucket
+constexpr int kScanPackG = 8;                    // general: the map is chosen per dimension (DimTable::map_kind), 3 edges per bucket
+constexpr bool scan_is_pack(int scan) { return scan == kScanPack2 || scan == kScanPack3 || scan == kScanPackG; }
+
+// Order-preserving integer key of a float32: for any a, b (not NaN)  a < b  =>  key(a) < key(b), and -0.0 / +0.0 — equal as
+// numbers — get the SAME key (the sample is canonicalised by adding +0.0 first: an edge at 0.0 and a sample -0.0 must
+// meet in one bucket).  NaN lands at either end (sign bit), compares false against every threshold and is dropped.
+__host__ __device__ __forceinline__ uint32_t float_order_key(float xf) {
+  xf += 0.0f;  // -0.0 -> +0.0
+  const uint32_t b = __builtin_bit_cast(uint32_t, xf);
+  return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+
+// bucket of the packed entries under the float-bits map: monotone in xf, hence in x
+__host__ __device__ __forceinline__ int bucket_of_key(float xf, uint32_t key_lo, int key_shift, int lut_k) {
+  const uint32_t k = float_order_key(xf);
+  const uint32_t d = (k > key_lo ? k - key_lo : 0u) >> key_shift;
+  return (int)(d < (uint32_t)(lut_k - 1) ? d : (uint32_t)(lut_k - 1));
+}
 typedef uint32_t pack_entry_t __attribute__((ext_vector_type(4), aligned(16)));
 
 // returns the real-bin index, or a value >= nb (as unsigned) for a sample the reference drops — valid unless `near`
-template <int NP, typename TabPtr>
+// KEYMAP: the bucket comes from the float32 bit pattern (DimTable::map_kind == 1) instead of the linear map
+template <int NP, bool KEYMAP, typename TabPtr>
 __device__ __forceinline__ uint32_t count_le_pack(double x, const DimTable& t, TabPtr tab, bool& near) {
-  const float xf = (float)x;
-  const pack_entry_t e = reinterpret_cast<const pack_entry_t*>(tab)[t.lut_off + bucket_of<2>(xf, t)];
+  float xf = (float)x;
+  int b;
+  if (KEYMAP) {
+    // NaN has no place in the key order (its bit pattern sorts above +inf): it becomes FLT_MAX — beyond every threshold
+    // (plan creation admits |e| <= 3e38 only), so it counts every edge and is dropped like any sample above e_last.
+    // (the linear map sends NaN to bucket 0, where it counts no edge: dropped as well)
+    xf = __builtin_fminf(xf, 3.402823466e+38f);
+    b = bucket_of_key(xf, t.key_lo, t.key_shift, t.lut_k);
+  } else {
+    b = bucket_of<2>(xf, t);
+  }
+  const pack_entry_t e = reinterpret_cast<const pack_entry_t*>(tab)[t.lut_off + b];
   const float ta = __uint_as_float(e[0]), tb = __uint_as_float(e[1]), tc = __uint_as_float(e[2]);
   uint32_t c = e[3];  // start - 1: the sum below is the BIN, -1 (as 2^32 - 1) below e_0, nb above e_last
   c += (xf > ta) ? 1u : 0u;
@@ -541,30 +575,47 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
     }
   } else if constexpr (scan_is_pack(SCAN)) {
     static_assert(CMP == 0, "packed entries: float64 samples");
-    constexpr int NP = SCAN == kScanPack3 ? 3 : 2;
+    constexpr int NP = SCAN == kScanPack2 ? 2 : 3;
+    constexpr bool G = SCAN == kScanPackG;
     bool near_any = false;  // (a lane mask in SGPRs: OR-ing the samples' flags costs the vector ALU nothing)
+    // (general variant: ONE uniform branch per dimension and tile picks that dimension's bucket map for the whole batch)
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          bool near;
-          cnt[d][u][v] = count_le_pack<NP>((double)xv[d][u][v], p.dim[d], tab, near);
-          near_any |= near;
-        }
-    if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {  // rare: a sample whose float32 image equals an edge's
-      if (near_any) {  // which of this lane's samples it was is found again here, not carried through the fast path
+    for (int d = 0; d < D; ++d) {
+      if (G && p.dim[d].map_kind) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
+          for (int v = 0; v < VEC; ++v) {
+            bool near;
+            cnt[d][u][v] = count_le_pack<NP, true>((double)xv[d][u][v], p.dim[d], tab, near);
+            near_any |= near;
+          }
+      } else {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            bool near;
+            cnt[d][u][v] = count_le_pack<NP, false>((double)xv[d][u][v], p.dim[d], tab, near);
+            near_any |= near;
+          }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {  // rare: a sample whose float32 image equals an edge's
+      if (near_any) {  // which of this lane's samples it was is found again here, not carried through the fast path
+#pragma unroll
+        for (int d = 0; d < D; ++d) {  // (unrolled: a run-time index into the register tile would send it to scratch)
+          const bool keymap = G && p.dim[d].map_kind;
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
               bool near;
-              (void)count_le_pack<NP>((double)xv[d][u][v], p.dim[d], tab, near);
+              if (keymap) (void)count_le_pack<NP, true>((double)xv[d][u][v], p.dim[d], tab, near);
+              else (void)count_le_pack<NP, false>((double)xv[d][u][v], p.dim[d], tab, near);
               if (near) cnt[d][u][v] = count_le_exact((double)xv[d][u][v], p.dim[d], tab);
             }
+        }
       }
     }
   } else if constexpr (SCAN > 0) {
@@ -1087,7 +1138,8 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
 static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t, uint64_t* blob, int32_t* scratch) {
   const double* edges = reinterpret_cast<const double*>(blob + t.edge_off);
   pack_entry_t* ent = reinterpret_cast<pack_entry_t*>(blob) + t.lut_off;
-  for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x) scratch[j] = bucket_of<2>((float)edges[j], t);
+  for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x)
+    scratch[j] = t.map_kind ? bucket_of_key((float)edges[j], t.key_lo, t.key_shift, t.lut_k) : bucket_of<2>((float)edges[j], t);
   __syncthreads();
   for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
     int lo = 0, hi = t.n_edges;

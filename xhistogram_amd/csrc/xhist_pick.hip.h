@@ -108,6 +108,7 @@ static kernel_fn fast_pick_s(int scan, int hist) {
     case kScanArith: return fast_pick_arith<ST, WT, D>(hist);
     case kScanPack2: return fast_pick_pack<ST, WT, D, kScanPack2>(hist);
     case kScanPack3: return fast_pick_pack<ST, WT, D, kScanPack3>(hist);
+    case kScanPackG: return fast_pick_pack<ST, WT, D, kScanPackG>(hist);
     case 1: return fast_pick<ST, WT, D, 1>(hist);
     case 2: return fast_pick<ST, WT, D, 2>(hist);
     case 3: return fast_pick<ST, WT, D, 3>(hist);

@@ -190,13 +190,43 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
       }
       if (mx < best_cnt) { best_cnt = mx; best_k = K; }
     }
-    if (!best_k || best_cnt > 3) return XHIST_OK;
-    const float scale = (float)((double)best_k / (double)range);
+    if (best_k && best_cnt <= 3) {
+      const float scale = (float)((double)best_k / (double)range);
+      t.lut_k = best_k;
+      t.scale = (double)scale;
+      t.bias = (double)(-thr[0] * scale);
+      t.steps = 1;
+      continue;
+    }
+    // a linear grid cannot separate these edges (geometric / logarithmic spacing: most of them sit in its first buckets):
+    // buckets on the float32 bit pattern instead — uniform in log x; integer arithmetic, the same on host and device
+    const uint32_t k0 = float_order_key(thr[0]), k1 = float_order_key(thr[(size_t)E - 1]);
+    int best_shift = -1;
+    best_k = 0;
+    for (int shift = 0; shift < 32; ++shift) {
+      const uint64_t K64 = ((uint64_t)(k1 - k0) >> shift) + 1;
+      if (K64 > (uint64_t)k_cap) continue;
+      const int K = (int)std::max<uint64_t>(K64, 2);
+      int run = 0, prev = -1, mx = 0;
+      for (int j = 0; j < E; ++j) {
+        const int b = bucket_of_key(thr[(size_t)j], k0, shift, K);
+        run = b == prev ? run + 1 : 1;
+        prev = b;
+        mx = std::max(mx, run);
+      }
+      if (mx <= 3) { best_shift = shift; best_k = K; }
+      break;  // (the first shift that fits the budget is the finest grid: coarser ones only merge buckets)
+    }
+    if (best_shift < 0) return XHIST_OK;
     t.lut_k = best_k;
-    t.scale = (double)scale;
-    t.bias = (double)(-thr[0] * scale);
+    t.map_kind = 1;
+    t.key_lo = k0;
+    t.key_shift = best_shift;
     t.steps = 1;
+    ts->max_cnt = -1;  // (marks "some dimension uses the float-bits map" until the device-built table is verified below)
   }
+  const bool any_key_map = ts->max_cnt == -1;
+  ts->max_cnt = 0;
   int64_t stride = 1;
   for (int d = n_inputs - 1; d >= 0; --d) {
     ts->dim[d].out_stride = stride;
@@ -248,7 +278,7 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
   ts->blob = d_blob;
   ts->words = table_words;
   ts->max_cnt = np;
-  p->pk_np = np <= 2 ? 2 : 3;
+  p->pk_np = any_key_map ? 4 : (np <= 2 ? 2 : 3);  // 4: the general kernels (map per dimension, three edges per bucket)
   return cleanup(XHIST_OK, true);
 }
 
