@@ -2439,3 +2439,47 @@ def test_packed_bucket_entries_joint_of_a_log_axis_and_a_linear_one(xh):
         got, desc = _run(xh, [x, y], edges, w, True)
         assert "scan=8" in desc and "family=fast" in desc, desc
         assert_hist_equal(got, onp.bincount_rows([x, y], edges, w), w is not None)
+
+
+@pytest.mark.parametrize("weights", [None, "f64", "f32"])
+@pytest.mark.parametrize("kind", sorted(_PACK_EDGES))
+def test_packed_bucket_entries_float32_samples(xh, kind, weights):
+    """float32 samples: thresholds = smallest float32 >= e_j (> e_last for the last edge), exact without a redo path; the
+    samples are the float32 values on and around every edge's float32 neighbourhood"""
+    rng = np.random.default_rng(7 + sum(map(ord, kind)))
+    edges = [_PACK_EDGES[kind](rng)]
+    with np.errstate(over="ignore", invalid="ignore"):
+        x = _pack_torture(edges[0], rng, 100_000).astype(np.float32)
+    w = None if weights is None else rng.uniform(-1, 2, x.shape).astype(np.float64 if weights == "f64" else np.float32)
+    want = onp.bincount_rows([x], edges, w)
+    got, desc = _run(xh, [x], edges, w, True, pack=1)
+    assert_hist_equal(got, want, w is not None)
+    offered = any("scan=%d" % k in desc for k in (6, 7, 8))
+    if kind in _PACK_KEY_MAP:
+        assert "scan=8" in desc and "f32thr" in desc, desc
+    elif kind not in _PACK_NOT_OFFERED and kind not in _PACK_EITHER and kind not in ("big_magnitude", "small_magnitude"):
+        assert offered and "f32thr" in desc, desc
+    got, _ = _run(xh, [x], edges, w, True, pack=-1)
+    assert_hist_equal(got, want, w is not None)
+    got, _ = _run(xh, [x], edges, w, False)  # host route, automatic choice
+    assert_hist_equal(got, want, w is not None)
+
+
+@pytest.mark.parametrize("weights", [None, "f32"])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_packed_bucket_entries_float32_joint(xh, dims, weights):
+    rng = np.random.default_rng(500 + dims)
+    nb = ([257, 257] if weights is None else [65, 90]) if dims == 2 else ([33, 17, 41] if weights is None else [17, 9, 21])
+    edges = [_sorted_uniform(rng, k, -4.0, 4.0) for k in nb]
+    edges[-1] = np.geomspace(1e-3, 4.0, nb[-1])  # one logarithmic axis: the general kernels
+    cols = [_pack_torture(e, rng, 60_000).astype(np.float32) for e in edges]
+    n = min(c.shape[1] for c in cols)
+    samples = [np.roll(c[:, :n], 7919 * d, axis=1).copy() for d, c in enumerate(cols)]
+    w = None if weights is None else rng.uniform(0, 1, samples[0].shape).astype(np.float32)
+    want = onp.bincount_rows(samples, edges, w)
+    got, desc = _run(xh, samples, edges, w, True)
+    assert "scan=8" in desc and "f32thr" in desc and "family=fast" in desc, desc
+    assert_hist_equal(got, want, w is not None)
+    got, desc = _run(xh, samples, edges, w, True, pack=-1)
+    assert "scan=8" not in desc, desc
+    assert_hist_equal(got, want, w is not None)

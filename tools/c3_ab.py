@@ -12,12 +12,14 @@ from xhistogram_amd import _native
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 only = sys.argv[2] if len(sys.argv) > 2 and "=" not in sys.argv[2] else None  # substring of a case name
+f32 = os.environ.get("C3_AB_F32") == "1"  # float32 samples (float64 weights stay)
 tune = dict(kv.split("=") for kv in sys.argv[2:] if "=" in kv)  # plan parameters applied to every variant, e.g. block_threads=1024
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(1234)
-x = torch.empty(n, dtype=torch.float64, device=dev).normal_(generator=g)
-y = torch.empty(n, dtype=torch.float64, device=dev).normal_(generator=g)
+sdt = torch.float32 if f32 else torch.float64
+x = torch.empty(n, dtype=sdt, device=dev).normal_(generator=g)
+y = torch.empty(n, dtype=sdt, device=dev).normal_(generator=g)
 w = torch.empty(n, dtype=torch.float64, device=dev).uniform_(generator=g)
 stream = torch.cuda.current_stream(dev).cuda_stream
 
@@ -48,7 +50,7 @@ for name, edges, weighted in cases:
         for k, v in params.items():
             plan.set_param(k, v)
         arrs = [x, y][: len(edges)]
-        xv = [_native.make_view(a.data_ptr(), _native.F64, n, 1) for a in arrs]
+        xv = [_native.make_view(a.data_ptr(), _native.F32 if f32 else _native.F64, n, 1) for a in arrs]
         wv = _native.make_view(w.data_ptr(), _native.F64, n, 1) if weighted else None
         out = torch.zeros(plan.bins_shape, dtype=torch.float64 if weighted else torch.int64, device=dev)
         run = plan.bind(xv, wv, 1, n, out.data_ptr(), weighted, _native.MEM_DEVICE, False, stream)
@@ -61,7 +63,7 @@ for name, edges, weighted in cases:
         torch.cuda.synchronize()
         t = plan.profile_read()
         ms = float(np.mean(t))
-        byts = n * (8 * len(edges) + (8 if weighted else 0))
+        byts = n * ((4 if f32 else 8) * len(edges) + (8 if weighted else 0))
         res = out.cpu().numpy()
         if ref is None:
             ref = res

@@ -1015,15 +1015,19 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     // Non-uniform edges, float64 samples: packed 16-byte bucket entries (count_le_pack) — one LDS read per sample and
     // dimension instead of two dependent ones — where the histogram stays in LDS with them.  Measured for joint histograms
     // (C3: see DESIGN 4); 1-D histograms keep the two-level tables unless "pack" = 1.
-    if (fast && !mixed && !two && !i64dom && sdt == XHIST_F64 && p->pk_np && pack_pref >= 0 && scan != kScanArith && tables_fit &&
-        (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || scan == 0 || pack_pref > 0)) {  // (scan 0: the alternative is a binary search)
+    const int pk_np = sdt == XHIST_F64 ? p->pk_np : (sdt == XHIST_F32 && use_f32 ? p->pk32_np : 0);
+    if (fast && !mixed && !two && !i64dom && pk_np && pack_pref >= 0 && scan != kScanArith && tables_fit &&
+        (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || scan == 0 || (sdt == XHIST_F32 && !weighted) || pack_pref > 0)) {
+      // (scan 0: the alternative is a binary search; 1-D: measured level for float64 samples and for weighted float32 ones,
+      //  0.74 -> 0.85 of 8 TB/s for float32 counts — twice the table reads per byte streamed: profiles/r04_h_*)
+      const TableSet& pk = sdt == XHIST_F64 ? p->ts_pk : p->ts_pk32;
       const int h0 = hist, c0 = cl2;
-      const size_t b0 = hist_bytes, tb = (size_t)p->ts_pk.words * 8;
+      const size_t b0 = hist_bytes, tb = (size_t)pk.words * 8;
       if (tb + 1024 <= lds_cap) {
         place(tb, true);
         if ((hist == kHistLds || hist == kHistPacked) && (hist == h0 || pack_pref > 0)) {
-          scan = p->pk_np == 2 ? kScanPack2 : (p->pk_np == 3 ? kScanPack3 : kScanPackG);
-          tset = &p->ts_pk;
+          scan = pk_np == 2 ? kScanPack2 : (pk_np == 3 ? kScanPack3 : kScanPackG);
+          tset = &pk;
           table_bytes = tb;
         } else {
           hist = h0; cl2 = c0; hist_bytes = b0;

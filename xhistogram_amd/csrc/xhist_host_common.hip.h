@@ -390,6 +390,8 @@ struct xhist_plan {
   // pk_np = 0 (not offered: some bucket would hold more than three edges, or the edges leave float32's range), 2 or 3
   TableSet ts_pk;
   int pk_np = 0;
+  TableSet ts_pk32;    // the same for float32 SAMPLES: entries only (exact float32 thresholds, no redo path, no edges in LDS)
+  int pk32_np = 0;
   int pack_pref = 0;   // 0 auto, 1 packed entries whenever the plan has them, -1 never
   bool uns = false;    // the int64-domain inputs hold unsigned 64-bit values (XHIST_CMP_UNSIGNED)
   bool huge = false;   // some dimension has more than 65535 edges: no bucket tables (lut_k = 0)

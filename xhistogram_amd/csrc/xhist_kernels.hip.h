@@ -352,6 +352,27 @@ __device__ __forceinline__ uint32_t count_le_pack(double x, const DimTable& t, T
   return c;
 }
 
+// float32 SAMPLES need no pre-compare and no redo: the entry holds thr_j = the smallest float32 >= e_j, for which
+// (double)x >= e_j  <=>  x >= thr_j  exactly (Dom<2>'s argument) — and, for the LAST edge, the smallest float32 > e_last, so
+// that x == e_last counts E - 1 edges and lands in the last bin while anything above it counts E and is dropped: the
+// right-edge rule of core.py:170-173 sits in the table, not in the kernel.  Buckets come from the same maps applied to thr.
+template <int NP, bool KEYMAP, typename TabPtr>
+__device__ __forceinline__ uint32_t count_le_pack_f32(float x, const DimTable& t, TabPtr tab) {
+  int b;
+  if (KEYMAP) {
+    x = __builtin_fminf(x, 3.402823466e+38f);  // NaN (and +inf) -> FLT_MAX: counts every threshold, dropped (see count_le_pack)
+    b = bucket_of_key(x, t.key_lo, t.key_shift, t.lut_k);
+  } else {
+    b = bucket_of<2>(x, t);
+  }
+  const pack_entry_t e = reinterpret_cast<const pack_entry_t*>(tab)[t.lut_off + b];
+  uint32_t c = e[3];
+  c += (x >= __uint_as_float(e[0])) ? 1u : 0u;
+  c += (x >= __uint_as_float(e[1])) ? 1u : 0u;
+  if (NP == 3) c += (x >= __uint_as_float(e[2])) ? 1u : 0u;
+  return c;
+}
+
 // exact bin over ALL float64 edges of a dimension, in the packed counts' convention: 2^32 - 1 for dropped samples
 // (x < e_0, x > e_last, NaN), else min(#{e_j <= x}, nb) - 1 so that x == e_last lands in the last bin
 template <typename TabPtr>
@@ -573,8 +594,25 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
             for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_arith((double)xv[d][u][v], p.dim[d]);
       }
     }
+  } else if constexpr (scan_is_pack(SCAN) && CMP == 2) {  // float32 samples: exact in one compare per threshold
+    constexpr int NP = SCAN == kScanPack2 ? 2 : 3;
+    constexpr bool G = SCAN == kScanPackG;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (G && p.dim[d].map_kind) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_pack_f32<NP, true>((float)xv[d][u][v], p.dim[d], tab);
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_pack_f32<NP, false>((float)xv[d][u][v], p.dim[d], tab);
+      }
+    }
   } else if constexpr (scan_is_pack(SCAN)) {
-    static_assert(CMP == 0, "packed entries: float64 samples");
+    static_assert(CMP == 0, "packed entries: float64 or float32 samples");
     constexpr int NP = SCAN == kScanPack2 ? 2 : 3;
     constexpr bool G = SCAN == kScanPackG;
     bool near_any = false;  // (a lane mask in SGPRs: OR-ing the samples' flags costs the vector ALU nothing)
@@ -686,7 +724,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   // float32 samples: float32-threshold tables — except with arithmetic edges, which are float64
   constexpr int CMP = I64DOM ? 1 : ((__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0);
   static_assert(!I64DOM || (__is_same(ST, int64_t) && SCAN == 0), "int64 domain: int64 samples, (start, cnt) tables");
-  static_assert(!scan_is_pack(SCAN) || (__is_same(ST, double) && !MIXED && !I64DOM), "packed bucket entries: float64 samples");
+  static_assert(!scan_is_pack(SCAN) || ((__is_same(ST, double) || __is_same(ST, float)) && !MIXED && !I64DOM), "packed bucket entries: float64 / float32 samples");
   using CT = typename Dom<CMP>::T;
   // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
   // integer samples: zero, masked by the past_end bit
@@ -1135,11 +1173,14 @@ __global__ void __launch_bounds__(256) build_tables(const DimTable t, uint64_t* 
 // packed-entry tables (count_le_pack): one workgroup per dimension.  thr_j = (float)e_j is computed HERE, with the
 // conversion the kernels apply to the samples; entry b = { thr of the first three edges of bucket b (NaN beyond the
 // bucket's own), start }.  The host reads the table back and offers it only if no bucket holds more than three edges.
-static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t, uint64_t* blob, int32_t* scratch) {
+// thr_given (float32-sample tables): the thresholds come from the host (smallest float32 >= e_j; > e_last for the last) and only
+// the bucket map is applied here.
+static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t, uint64_t* blob, int32_t* scratch, const float* thr_given) {
   const double* edges = reinterpret_cast<const double*>(blob + t.edge_off);
   pack_entry_t* ent = reinterpret_cast<pack_entry_t*>(blob) + t.lut_off;
+  auto thr_of = [&](int j) { return thr_given ? thr_given[j] : (float)edges[j]; };
   for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x)
-    scratch[j] = t.map_kind ? bucket_of_key((float)edges[j], t.key_lo, t.key_shift, t.lut_k) : bucket_of<2>((float)edges[j], t);
+    scratch[j] = t.map_kind ? bucket_of_key(thr_of(j), t.key_lo, t.key_shift, t.lut_k) : bucket_of<2>(thr_of(j), t);
   __syncthreads();
   for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
     int lo = 0, hi = t.n_edges;
@@ -1150,7 +1191,7 @@ static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t
     const int cnt = lo - start;
     pack_entry_t e;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) e[k] = k < cnt ? __float_as_uint((float)edges[start + k]) : 0x7fc00000u;
+    for (int k = 0; k < 3; ++k) e[k] = k < cnt ? __float_as_uint(thr_of(start + k)) : 0x7fc00000u;
     e[3] = (uint32_t)start - 1u;  // (count_le_pack's sum is then the bin itself)
     ent[b] = e;
   }

@@ -81,10 +81,11 @@ static kernel_fn fast_pick_arith(int hist) {
   return nullptr;
 }
 
-// packed bucket entries (count_le_pack): float64 samples, histograms in LDS (replicated or packed uint16 counters)
+// packed bucket entries (count_le_pack / count_le_pack_f32): float64 or float32 samples, histograms in LDS (replicated or
+// packed uint16 counters)
 template <typename ST, typename WT, int D, int SCAN>
 static kernel_fn fast_pick_pack(int hist) {
-  if constexpr (std::is_same<ST, double>::value) {
+  if constexpr (std::is_same<ST, double>::value || std::is_same<ST, float>::value) {
     constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
     constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
     constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);

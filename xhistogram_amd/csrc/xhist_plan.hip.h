@@ -148,10 +148,14 @@ static int build_domain(xhist_plan* p, int dom_all, bool lut16, int n_inputs, co
 // than three edges (C3: 257 random edges, K ~ 850: most grids qualify, a few put four edges of a tight cluster into one
 // bucket); the search runs on the host with the float32 arithmetic of bucket_of<2>, the table is BUILT on the device and
 // read back, and only what the device built decides whether the set is offered.
-static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges, const std::vector<std::vector<uint64_t>>& words,
+// f32dom: the set for float32 SAMPLES (count_le_pack_f32) — thresholds are the smallest float32 >= e_j (> e_last for the
+// last edge: the right-edge rule lives in the table), computed here; the blob holds entries only.
+static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int64_t* n_edges, const std::vector<std::vector<uint64_t>>& words,
                              const void* const* edges, size_t entry_budget_bytes) {
-  TableSet* ts = &p->ts_pk;
-  p->pk_np = 0;
+  TableSet* ts = f32dom ? &p->ts_pk32 : &p->ts_pk;
+  int& np_out = f32dom ? p->pk32_np : p->pk_np;
+  np_out = 0;
+  std::vector<std::vector<float>> thr_all((size_t)n_inputs);
   int32_t edge_off = 0;
   int64_t max_e = 0;
   const int k_cap = (int)std::min<size_t>(entry_budget_bytes / (16 * (size_t)n_inputs), 2048);
@@ -166,12 +170,17 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
     t.e0_f = e[0];
     t.eL_f = e[E - 1];
     t.edge_off = edge_off;
-    edge_off += (int32_t)words[d].size();
+    if (!f32dom) edge_off += (int32_t)words[d].size();
     if (E < 2 || E > 65535) return XHIST_OK;
-    std::vector<float> thr((size_t)E);
+    std::vector<float>& thr = thr_all[(size_t)d];
+    thr.resize((size_t)E);
     for (int j = 0; j < E; ++j) {
       if (!std::isfinite(e[j]) || std::fabs(e[j]) > 3.0e38) return XHIST_OK;
-      thr[(size_t)j] = (float)e[j];
+      float f = (float)e[j];
+      if (f32dom) {
+        if (j < E - 1 ? (double)f < e[j] : (double)f <= e[j]) f = std::nextafterf(f, INFINITY);
+      }
+      thr[(size_t)j] = f;
     }
     const float range = thr[(size_t)E - 1] - thr[0];
     if (!(range > 0.0f) || !std::isfinite(range)) return XHIST_OK;
@@ -239,7 +248,8 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
   }
   const int32_t table_words = off * 2;
   std::vector<uint64_t> blob((size_t)table_words, 0);
-  for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + ts->dim[d].edge_off, words[d].data(), words[d].size() * 8);
+  if (!f32dom)
+    for (int d = 0; d < n_inputs; ++d) memcpy(blob.data() + ts->dim[d].edge_off, words[d].data(), words[d].size() * 8);
   uint64_t* d_blob = nullptr;
   int32_t* d_scratch = nullptr;
   auto cleanup = [&](int rc, bool keep) {
@@ -253,10 +263,15 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
     if (e_ != hipSuccess) return cleanup(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)), false); \
   } while (0)
   HIPP(hipMalloc(&d_blob, blob.size() * 8));
-  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4));
+  HIPP(hipMalloc(&d_scratch, (size_t)max_e * 4 * 2));  // bucket ids, and (float32 domain) the thresholds behind them
   HIPP(hipMemcpy(d_blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
   for (int d = 0; d < n_inputs; ++d) {
-    hipLaunchKernelGGL(build_pack_tables, dim3(1), dim3(256), 0, 0, ts->dim[d], d_blob, d_scratch);
+    float* d_thr = nullptr;
+    if (f32dom) {
+      d_thr = reinterpret_cast<float*>(d_scratch + max_e);
+      HIPP(hipMemcpy(d_thr, thr_all[(size_t)d].data(), thr_all[(size_t)d].size() * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(build_pack_tables, dim3(1), dim3(256), 0, 0, ts->dim[d], d_blob, d_scratch, (const float*)d_thr);
     HIPP(hipGetLastError());
     HIPP(hipDeviceSynchronize());
   }
@@ -278,7 +293,7 @@ static int build_pack_domain(xhist_plan* p, int n_inputs, const int64_t* n_edges
   ts->blob = d_blob;
   ts->words = table_words;
   ts->max_cnt = np;
-  p->pk_np = any_key_map ? 4 : (np <= 2 ? 2 : 3);  // 4: the general kernels (map per dimension, three edges per bucket)
+  np_out = any_key_map ? 4 : (np <= 2 ? 2 : 3);  // 4: the general kernels (map per dimension, three edges per bucket)
   return cleanup(XHIST_OK, true);
 }
 
@@ -406,7 +421,11 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     const size_t fixed = edge_bytes + 16 + 1024 + hist_min;
     size_t budget = p->lds_max > fixed ? p->lds_max - fixed : 0;
     budget = std::min<size_t>(budget, 32 * 1024);  // (C3: 27 KiB are left)
-    if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, n_inputs, n_edges, words, edges, budget);
+    if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, false, n_inputs, n_edges, words, edges, budget);
+    // float32 samples: no edges in LDS next to the entries
+    const size_t fixed32 = 16 + 1024 + hist_min;
+    size_t budget32 = std::min<size_t>(p->lds_max > fixed32 ? p->lds_max - fixed32 : 0, 32 * 1024);
+    if (rc == XHIST_OK && budget32 >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, true, n_inputs, n_edges, words, edges, budget32);
   }
   if (rc == XHIST_OK && vector_sets) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
@@ -430,6 +449,7 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
       for (auto& t : dom)
         if (t.blob) (void)hipFree(t.blob);
     if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
+    if (p->ts_pk32.blob) (void)hipFree(p->ts_pk32.blob);
     delete p;
     return rc;
   }
@@ -497,6 +517,7 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
       for (auto& t : dom)
         if (t.blob) (void)hipFree(t.blob);
     if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
+    if (p->ts_pk32.blob) (void)hipFree(p->ts_pk32.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : p->side_events) (void)hipEventDestroy(e);
     if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
