@@ -219,6 +219,10 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       float64 records in the same call; XHIST_AMD_EXACT_RECORDS=1 is the process-wide "never"),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
+ *       "pack" (0 auto / 1 whenever the plan has them / -1 never: packed 16-byte bucket entries — one LDS read per sample and
+ *       dimension — for float64 / float32 samples on non-uniform edges, on a linear or a float-bit-pattern (logarithmic) grid),
+ *       "overlap" (sub-batches of one long row whose routing and adding-up passes run on two streams; 0 = 1 = off: measured
+ *       slower, kept for A/B runs) with "overlap_cus", "route_grid", "acc_grid" (workgroups of the two passes; 0 auto),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
  *       "route_block" (0 auto / 512 / 1024 threads), "route_spl" (0 auto / 4 / 8 samples per lane and tile) and "min_parts"
  *       (0 auto = 16 / 1 = as few as the histogram's size asks for / up to 128: partitions per row) shape the routing pass of

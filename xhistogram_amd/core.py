@@ -778,6 +778,18 @@ def _ensure_correctly_formatted_range(range_, N_expected):
     return range_
 
 
+def _devarr_as_torch(a):
+    """zero-copy torch view of a DeviceArray (the array keeps owning the memory), or None: no torch in this interpreter, no
+    GPU visible to it, or a dtype / stride pattern torch's `__cuda_array_interface__` import does not take"""
+    try:
+        torch = _torch()
+        if not torch.cuda.is_available() or a.dtype.kind not in "fiu" or a.dtype == np.float16:
+            return None
+        return torch.as_tensor(a, device=torch.device("cuda", _native.physical_device(a.device)))
+    except Exception:
+        return None
+
+
 def _device_bin_edges(a, b, r, has_weights):
     """np.histogram_bin_edges (core.py:383-388) for a GPU-resident array without moving it:
     explicit edges are validated by numpy; an integer ``bins`` needs only the data's min/max
@@ -793,9 +805,19 @@ def _device_bin_edges(a, b, r, has_weights):
             edges = _device_quartile_edges(a, b, r, proto_dtype, resident)
         if edges is None:
             edges = _device_doane_stone_edges(a, b, r, proto_dtype, resident)
+        if edges is None and resident:
+            # a DeviceArray where torch is importable: the order-statistics search and the "doane" / "stone" selectors run on
+            # a zero-copy torch view of the same memory (`__cuda_array_interface__`); without torch (the dask interpreter of
+            # this image) the host copy below remains
+            t = _devarr_as_torch(a)
+            if t is not None:
+                edges = _device_quartile_edges(t, b, r, proto_dtype, False)
+                if edges is None:
+                    edges = _device_doane_stone_edges(t, b, r, proto_dtype, False)
+                del t
         if edges is not None:
             return edges
-        # what is left — a DeviceArray, float16 data, "stone" of more than 1.6 x 10^7 elements, a bin
+        # what is left — a DeviceArray without torch, float16 data, "stone" of more than 1.6 x 10^7 elements, a bin
         # count that hangs on numpy's own summation order ("scott", "doane") — takes numpy's implementation on a host copy
         return np.histogram_bin_edges(a.to_numpy() if resident else a.detach().cpu().numpy(), bins=b, range=r)
     if np.ndim(b) == 0 and r is None:
