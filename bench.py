@@ -45,7 +45,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 200 for the sub-millisecond steps of --config c4)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; 50 for --config c4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 10; 50 for --config c4)")
     ap.add_argument("--samples", type=int, default=1_000_000_000, help="samples per GPU")
     ap.add_argument("--bins", type=int, default=100)
     ap.add_argument("--unweighted", action="store_true", help="8 B/sample variant (not the headline)")
@@ -78,7 +78,9 @@ def parse():
     if args.steps is None:
         args.steps = 200 if short_steps else 20
     if args.warmup is None:
-        args.warmup = 50 if short_steps else 3
+        # (millisecond kernels: the first ~6 launches after the idle gap of data generation run up to 14 % slow — the clock
+        # excursion over the first ~13 ms of a burst, profiles/r04_z_c3_launch_series.txt — so 10 untimed launches, not 3)
+        args.warmup = 50 if short_steps else 10
     return args
 
 

@@ -445,7 +445,7 @@ def test_bench_default_run_lengths(monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     bench = importlib.import_module("bench")
-    for argv, want in (([], (20, 3)), (["--config", "c4"], (200, 50)), (["--config", "c4", "--full"], (20, 3)), (["--config", "c5"], (20, 3)),
+    for argv, want in (([], (20, 10)), (["--config", "c4"], (200, 50)), (["--config", "c4", "--full"], (20, 10)), (["--config", "c5"], (20, 10)),
                        (["--config", "c4", "--steps", "7"], (7, 50)), (["--steps", "5", "--warmup", "2"], (5, 2))):
         monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
         a = bench.parse()

@@ -23,6 +23,15 @@ def main(path):
     tot = sum(r[2] for r in rows) or 1.0
     for r in rows:
         print("%-112s | %5d | %12.1f | %10.2f | %10.2f | %10.2f | %5.2f" % (short(r[0]), r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
+    # the dominant xhist kernel launch by launch, in dispatch order: where inside a run the slow launches sit (VERDICT r3 "weak" #2:
+    # "one in 23 launches at +27 %")
+    top = [r for r in rows if "xhist::" in r[0] and "zero_words" not in r[0] and "build" not in r[0]]
+    if top:
+        try:
+            series = [d for (d,) in cur.execute("select duration/1e3 from kernels where name = ? order by start", (top[0][0],))]
+            print("## launches of the dominant kernel in dispatch order, us (%d): %s" % (len(series), " ".join("%.0f" % d for d in series[:64])))
+        except sqlite3.Error:
+            pass
     k = list(cur.execute(
         "select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels where name like '%xhist::%' group by name, grid_x, workgroup_x"))
     if k:
