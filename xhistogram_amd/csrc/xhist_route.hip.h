@@ -144,6 +144,21 @@ __device__ __forceinline__ V pulled_back(V q, int sh, S fill) {
   return r;
 }
 
+// Inclusive add-scan over the 64 lanes of a wavefront with DPP moves (row shifts inside the rows of 16, then the two row
+// broadcasts of GCN / CDNA): six dependent VALU operations.  The ds_bpermute form (__shfl_up x 6) costs an LDS round trip per
+// step — ~700 cycles of pure latency in a phase of the routing pass in which ONE wavefront works and fifteen wait
+// (profiles/r04_i_route_phase_cycles.txt: the block-layout scan took 2700 of a tile's 14700 cycles).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t x) {
+  // (old = 0, bound_ctrl off: lanes without a source — and rows masked out — contribute 0)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8: inclusive inside every row of 16
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
 // `need` consecutive chunk ids from the workgroup's two LDS-resident id ranges a = {next0, end0, next1, end1};
 // 0xFFFFFFFF when both are used up (the caller then goes to the global pool itself)
 __device__ __forceinline__ uint32_t route_take_ids(uint32_t* a, uint32_t need) {
@@ -329,6 +344,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
   int cur_set = 0;
+#ifdef XHIST_ROUTE_TIMING  // development build only: where a workgroup's cycles go, phase by phase (wave 0's clock)
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define XH_T(i) do { const long long now_ = clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+  long long tlast = clock64();
+#else
+#define XH_T(i) do { } while (0)
+#endif
   for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
     if constexpr (EARLY) {
       const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
@@ -407,6 +429,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         flat[u][v] = ok ? fl + row_off : 0xffffffffu;
       }
     }
+    XH_T(0);  // wait for the tile's loads + digitize
     uint32_t rank[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -418,23 +441,22 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
       load_tile(tile_base(kn), tile_row(kn), xv, wn, true, !WSPLIT);
     }
+    XH_T(1);  // rank atomics issued (+ next tile's loads issued)
     __syncthreads();
+    XH_T(2);  // barrier 1 (waits for every wave's digitize + ranks)
     // ---- block layout (as in part_scatter) + record space of every partition's block: LDS only -------
     if (tid < ((P + 63) & ~63)) {
       const int lane = tid & 63;
       const uint32_t c_in = tid < P ? cin[tid] : 0u;
       const uint32_t T = c_in + (tid < P ? cnt[tid] : 0u);
       const uint32_t block = (T + kGm) & ~kGm;
-      uint32_t x = block;  // inclusive scan over the wavefront
+      const uint32_t x = wave_inclusive_scan_u32(block);  // inclusive scan over the wavefront
+      uint32_t before = 0;  // blocks of the partitions handled by earlier wavefronts (none for up to 64 partitions: C5)
+      if (__builtin_amdgcn_readfirstlane(tid) >= 64) {
+        for (int q = lane; q < (tid & ~63); q += 64) before += (cin[q] + cnt[q] + kGm) & ~kGm;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off, 64);
-        x += lane >= off ? y : 0u;
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
       }
-      uint32_t before = 0;  // blocks of the partitions handled by earlier wavefronts
-      for (int q = lane; q < (tid & ~63); q += 64) before += (cin[q] + cnt[q] + kGm) & ~kGm;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
       const uint32_t B = before + x - block;
       if (tid < P) {
         const uint32_t whole = T & ~kGm;
@@ -474,7 +496,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       }
     }
     if (tid < 256) cnt2[((cur_set ^ 1) << 8) + tid] = 0u;
+    XH_T(3);  // scan / block layout (wave 0 works, the others wait)
     __syncthreads();
+    XH_T(4);  // barrier 2
     // ---- the tile, sorted by partition, into LDS -----------------------------------------------------
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -521,7 +545,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         asm volatile("" : "+v"(xv[d][u]));
       }
     }
+    XH_T(5);  // sort into LDS (+ wait for the weights, + the prefetch's arrival)
     __syncthreads();
+    XH_T(6);  // barrier 3
     const uint32_t total = misc[0];
     // ---- records out: one lane per group of 8 codes / per 16 bytes of weights -------------------------
     for (uint32_t g0 = (uint32_t)tid * GRP; g0 < total; g0 += BLOCK * GRP) {
@@ -591,7 +617,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     // no barrier here: the next tile's ranking touches only the other counter set, and nobody passes
     // that tile's first barrier before every lane has finished this write-out
+    XH_T(7);  // records out (stores issued) + id stock
   }
+#ifdef XHIST_ROUTE_TIMING
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255)) {
+    long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += tph[i];
+    printf("route_timing wg %d tiles %lld cycles/tile %lld : load+digitize %lld | rank %lld | bar1 %lld | scan %lld | bar2 %lld | sort %lld | bar3 %lld | out %lld\n",
+           (int)blockIdx.x, (long long)my_tiles, tot / my_tiles, tph[0] / my_tiles, tph[1] / my_tiles, tph[2] / my_tiles, tph[3] / my_tiles, tph[4] / my_tiles,
+           tph[5] / my_tiles, tph[6] / my_tiles, tph[7] / my_tiles);
+  }
+#endif
+#undef XH_T
   __syncthreads();
   // the last group of each partition (carried records padded with neutral ones), the fill of the chunk in use,
   // and this workgroup's chunk lists handed over to the partitions' global lists
