@@ -260,9 +260,13 @@ def main():
             a = copy.copy(args)
             a.config, a.steps, a.warmup, a.full, a.unweighted, a.no_cpu_baseline, a.profiler_pass = cfg, steps, warmup, False, False, True, False
             a.samples = 1_000_000_000  # BASELINE.json's sizes, whatever --samples the headline was given
-            wl2 = build_workload(cfg, a, torch, dev, rank)
-            plan2 = core._get_plan(wl2["edges"], _native.CMP_F64, local)
-            out[cfg] = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+            wl2 = None
+            try:  # (a failure here must not take the headline line with it)
+                wl2 = build_workload(cfg, a, torch, dev, rank)
+                plan2 = core._get_plan(wl2["edges"], _native.CMP_F64, local)
+                out[cfg] = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+            except Exception as e:  # noqa: BLE001
+                out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             del wl2
             torch.cuda.empty_cache()
         return out
