@@ -28,6 +28,8 @@ def edges_for(rng, kind, nb, lo=-3.0, hi=3.0):
         return e
     if kind == "geom":
         return lo + np.concatenate([[0.0], np.cumsum(np.geomspace(1e-6, 1.0, nb))]) * (hi - lo) / np.geomspace(1e-6, 1.0, nb).sum()
+    if kind == "logspace":  # geometric edges: the float-bit-pattern bucket grid of the packed entries (round 4)
+        return np.geomspace(10.0 ** float(rng.integers(-6, 0)), hi * float(rng.choice([1.0, 3.0, 1e3])), nb + 1)
     if kind == "int":
         return np.arange(-nb // 2, nb - nb // 2 + 1).astype(np.int64)
     raise ValueError(kind)
@@ -47,7 +49,7 @@ def one(seed):
     dtype = rng.choice(["f64", "f32", "i32", "i64", "u8", "f16"])
     # a third of the joint histograms mix dtypes (the mixed-dtype vector kernels / the generic family)
     dtypes = [str(rng.choice(["f64", "f32", "i32", "i16", "u8", "f16"])) if (d > 1 and rng.random() < 0.35) else str(dtype) for _ in range(d)]
-    kinds = ["int" if dt in ("i32", "i64", "u8", "i16") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "geom"])) for dt in dtypes]
+    kinds = ["int" if dt in ("i32", "i64", "u8", "i16") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "random", "geom", "logspace"])) for dt in dtypes]
     nbmax = {1: 70_000, 2: 400, 3: 50}[d]
     nbs = [int(rng.choice([1, 3, 17, 100, int(rng.integers(1, nbmax))])) for _ in range(d)]
     edges = [edges_for(rng, k, nb) for k, nb in zip(kinds, nbs)]
@@ -61,6 +63,15 @@ def one(seed):
         elif npdt == np.uint8:
             a = np.abs(np.round(a * 20)) % 256
         a = a.astype(npdt)
+        if a.dtype.kind == "f" and a.size > 8 and rng.random() < 0.4:
+            # some samples ON an edge, or next to one in the sample's own precision (the exact-redo path of the packed entries,
+            # the float32 thresholds, the right-edge rule)
+            e = edges[len(args)].astype(np.float64)
+            k = int(rng.integers(1, max(2, a.size // 4)))
+            pick = rng.choice(e, size=k).astype(npdt)
+            if rng.random() < 0.5:
+                pick = np.nextafter(pick, npdt(rng.choice([-np.inf, np.inf])))
+            a.reshape(-1)[rng.integers(0, a.size, k)] = pick
         if a.dtype.kind == "f" and a.size > 3 and rng.random() < 0.5:
             a.reshape(-1)[rng.integers(0, a.size, 3)] = [np.nan, np.inf, -np.inf]
         args.append(a)
