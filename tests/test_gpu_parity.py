@@ -2483,3 +2483,37 @@ def test_packed_bucket_entries_float32_joint(xh, dims, weights):
     got, desc = _run(xh, samples, edges, w, True, pack=-1)
     assert "scan=8" not in desc, desc
     assert_hist_equal(got, want, w is not None)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("weights", [None, "f32"])
+@pytest.mark.parametrize("shape,axis,family", [((300, 40, 50), 0, "lanes"), ((700, 33, 9), 0, "lanes"), ((40, 90, 37), 1, "lanes"),
+                                               ((5000, 365), 1, "flat_rows"), ((4097, 20), 1, "flat_rows"), ((70_000, 7), 1, None)])
+def test_packed_bucket_entries_in_the_row_per_lane_and_flat_rows_kernels(xh, shape, axis, family, weights, dtype):
+    """geometric edges (a binary search in the round-3 tables) through the kernels that digitize sample by sample: packed
+    entries on the float-bit-pattern grid, samples on and around the edges in the data's own precision"""
+    rng = np.random.default_rng(600 + len(shape) + axis)
+    edges = np.geomspace(1e-3, 8.0, 41)
+    a = np.abs(rng.standard_normal(shape) * 2).astype(dtype)
+    flat = a.reshape(-1)
+    k = flat.size // 5
+    pick = rng.choice(edges, size=k).astype(dtype)
+    pick[::3] = np.nextafter(pick[::3], dtype(np.inf))
+    pick[1::3] = np.nextafter(pick[1::3], dtype(-np.inf))
+    flat[rng.integers(0, flat.size, k)] = pick
+    flat[:3] = [np.nan, np.inf, -1.0]
+    w = None if weights is None else rng.uniform(0, 1, shape).astype(np.float32)
+    want, _ = onp.histogram(a, bins=edges, axis=axis, weights=w)
+    got, _ = xh.histogram(_dev(a), bins=edges, axis=axis, weights=None if w is None else _dev(w))
+    desc = _describe_last(xh, [_dev(a.reshape(1, -1)[:, :4])], [edges])
+    if family:
+        assert "family=%s" % family in desc and "scan=8" in desc, desc
+    assert_hist_equal(got.cpu().numpy(), want, w is not None)
+    plan = _plan_for(xh, [_dev(a.reshape(1, -1)[:, :4])], [edges])
+    plan.set_param("pack", -1)
+    try:
+        got, _ = xh.histogram(_dev(a), bins=edges, axis=axis, weights=None if w is None else _dev(w))
+        assert "scan=8" not in plan.describe(), plan.describe()
+    finally:
+        plan.set_param("pack", 0)
+    assert_hist_equal(got.cpu().numpy(), want, w is not None)

@@ -511,6 +511,20 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     picked = &p->ts[0][0];
     scan = 0;
   }
+  // crowded buckets (geometric edges: a binary search in the two-level tables): the packed entries, general variant — the
+  // row-per-lane and flat-rows kernels digitize sample by sample and feel every table read ((1825, 360, 720) float32 over
+  // time, 50 geometric bins: 0.97 -> see profiles/r04_j_*)
+  {
+    int pack_pref;
+    { std::lock_guard<std::mutex> lk(p->mu); pack_pref = p->pack_pref; }
+    const int pk_np = small ? 0 : (sdt == XHIST_F64 ? p->pk_np : (use_f32 ? p->pk32_np : 0));
+    // (only against the binary search: with 3-4 edges per bucket the two-level tables are AHEAD in these LDS-hungry kernels —
+    //  400 random edges, float32: row-per-lane 0.62 against 0.89 ms, flat rows 0.95 against 1.60)
+    if (pk_np && pack_pref >= 0 && (scan == 0 || pack_pref > 0)) {
+      picked = sdt == XHIST_F64 ? &p->ts_pk : &p->ts_pk32;
+      scan = kScanPackG;
+    }
+  }
   const TableSet& tset = *picked;
   const size_t table_bytes = (size_t)tset.words * 8;
   const size_t lds_bytes = table_bytes + (size_t)p->n_bins * kLanePitch * (weighted ? 8 : 4);

@@ -416,6 +416,32 @@ __device__ __forceinline__ int bin_from_count(typename Dom<CMP>::T x, const DimT
   return Dom<CMP>::in_range(x, t) ? bin : -1;
 }
 
+// One sample, packed entries (count_le_pack / count_le_pack_f32): the real-bin index or -1.  For the kernels that digitize
+// sample by sample (row-per-lane family) — the float64 redo is a per-lane branch there.
+template <int CMP, int SCAN, typename TabPtr>
+__device__ __forceinline__ int bin_of_sample_pack(typename Dom<CMP>::T x, const DimTable& t, TabPtr tab) {
+  static_assert(scan_is_pack(SCAN) && (CMP == 0 || CMP == 2), "packed entries: float64 / float32 samples");
+  constexpr int NP = SCAN == kScanPack2 ? 2 : 3;
+  constexpr bool G = SCAN == kScanPackG;
+  uint32_t c;
+  if constexpr (CMP == 2) {
+    c = (G && t.map_kind) ? count_le_pack_f32<NP, true>(x, t, tab) : count_le_pack_f32<NP, false>(x, t, tab);
+  } else {
+    bool near;
+    c = (G && t.map_kind) ? count_le_pack<NP, true>(x, t, tab, near) : count_le_pack<NP, false>(x, t, tab, near);
+    if (near) c = count_le_exact(x, t, tab);
+  }
+  return c < (uint32_t)t.nb ? (int)c : -1;
+}
+
+// bin of a sample from what count_le_tile returned for it: a count of edges (table / arithmetic digitize) or, for the packed
+// entries, the bin itself (>= nb as unsigned when dropped)
+template <int CMP, int SCAN>
+__device__ __forceinline__ int bin_from_tile_count(typename Dom<CMP>::T x, const DimTable& t, uint32_t cnt) {
+  if constexpr (scan_is_pack(SCAN)) return cnt < (uint32_t)t.nb ? (int)cnt : -1;
+  else return bin_from_count<CMP>(x, t, cnt);
+}
+
 // Real-bin index in [0, nb), or -1 when the reference would drop the sample.
 // s.lo == #{j : e_j <= x} (searchsorted side="right"); x == e_last gives E -> last bin.
 __device__ __forceinline__ int digitize_end(const DimTable& t, const DigState& s) {

@@ -82,15 +82,20 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes(const Params p, int32_t
     uint32_t flat = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      uint32_t cnt;
-      if constexpr (SCAN > 0) {
-        cnt = count_le_scan<CMP, SCAN>((CT)x[d], p.dim[d], tab);
+      int b;
+      if constexpr (scan_is_pack(SCAN)) {
+        b = bin_of_sample_pack<CMP, SCAN>((CT)x[d], p.dim[d], tab);
       } else {
-        DigState s = digitize_begin<CMP>((CT)x[d], p.dim[d], tab);
-        for (int k = 1; k < max_steps; ++k) upper_bound_step<CMP>((CT)x[d], p.dim[d], tab, s);
-        cnt = s.lo;
+        uint32_t cnt;
+        if constexpr (SCAN > 0) {
+          cnt = count_le_scan<CMP, SCAN>((CT)x[d], p.dim[d], tab);
+        } else {
+          DigState s = digitize_begin<CMP>((CT)x[d], p.dim[d], tab);
+          for (int k = 1; k < max_steps; ++k) upper_bound_step<CMP>((CT)x[d], p.dim[d], tab, s);
+          cnt = s.lo;
+        }
+        b = bin_from_count<CMP>((CT)x[d], p.dim[d], cnt);
       }
-      const int b = bin_from_count<CMP>((CT)x[d], p.dim[d], cnt);
       ok &= (b >= 0);
       flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
     }
@@ -209,15 +214,20 @@ __global__ void __launch_bounds__(kLaneBlock) hist_lanes_rows1(const Params p, i
 #pragma unroll 8
     for (int c = 0; c < W; ++c) {
       const CT x = (CT)mine[c];
-      uint32_t cnt;
-      if constexpr (SCAN > 0) {
-        cnt = count_le_scan<CMP, SCAN>(x, t, tab);
+      int b;
+      if constexpr (scan_is_pack(SCAN)) {
+        b = bin_of_sample_pack<CMP, SCAN>(x, t, tab);
       } else {
-        DigState s = digitize_begin<CMP>(x, t, tab);
-        for (int k = 1; k < t.steps; ++k) upper_bound_step<CMP>(x, t, tab, s);
-        cnt = s.lo;
+        uint32_t cnt;
+        if constexpr (SCAN > 0) {
+          cnt = count_le_scan<CMP, SCAN>(x, t, tab);
+        } else {
+          DigState s = digitize_begin<CMP>(x, t, tab);
+          for (int k = 1; k < t.steps; ++k) upper_bound_step<CMP>(x, t, tab, s);
+          cnt = s.lo;
+        }
+        b = bin_from_count<CMP>(x, t, cnt);
       }
-      const int b = bin_from_count<CMP>(x, t, cnt);
       atomicAdd(myword + (b >= 0 ? (uint32_t)b : 0u) * HP, b >= 0 ? myinc : 0u);
     }
 #pragma unroll
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(kLaneBlock) hist_flat_rows(const Params p, int
         uint32_t flat = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const int b = bin_from_count<CMP>((CT)xv[d][u][v], p.dim[d], cnt[d][u][v]);
+          const int b = bin_from_tile_count<CMP, SCAN>((CT)xv[d][u][v], p.dim[d], cnt[d][u][v]);
           ok &= (b >= 0);
           flat = (d == 0) ? (uint32_t)b : __umul24(flat, (uint32_t)p.dim[d].nb) + (uint32_t)b;
         }

@@ -90,6 +90,13 @@ static kernel_fn fast_pick_pack(int hist) {
     constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
     constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
     constexpr int U = unroll_for(D, VEC, SCAN);
+    if constexpr (SCAN == kScanPackG) {  // the row-per-lane family takes the general variant only (one set of kernels)
+      if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+      if (hist == kHistLanes16) {
+        if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
+        else return nullptr;
+      }
+    }
     if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
     if (hist == kHistPacked) {
 #ifdef XHIST_PACKED_UNROLL  // development A/B only, see fast_pick

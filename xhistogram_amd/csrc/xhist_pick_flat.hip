@@ -10,6 +10,7 @@ static kernel_fn_flat flat_pick_scan(int scan) {
     case 2: return (kernel_fn_flat)hist_flat_rows<ST, WT, D, 2>;
     case 3: if constexpr (D == 1) return (kernel_fn_flat)hist_flat_rows<ST, WT, D, 3>; else return nullptr;
     case 4: if constexpr (D == 1) return (kernel_fn_flat)hist_flat_rows<ST, WT, D, 4>; else return nullptr;
+    case kScanPackG: return (kernel_fn_flat)hist_flat_rows<ST, WT, D, kScanPackG>;  // packed bucket entries, map per dimension
     default: return nullptr;
   }
 }

@@ -156,6 +156,7 @@ static kernel_fn_rows1 rows1_pick(int scan) {
     case 2: return (kernel_fn_rows1)hist_lanes_rows1<ST, 2>;
     case 3: return (kernel_fn_rows1)hist_lanes_rows1<ST, 3>;
     case 4: return (kernel_fn_rows1)hist_lanes_rows1<ST, 4>;
+    case kScanPackG: return (kernel_fn_rows1)hist_lanes_rows1<ST, kScanPackG>;
     default: return (kernel_fn_rows1)hist_lanes_rows1<ST, 0>;
   }
 }
