@@ -32,7 +32,9 @@ def cells(path, scanner):
         except ValueError:
             continue
         if scanner == "shape_cliffs":
-            out["%dx%d %s bins=%s w=%d" % (d["rows"], d["cols"], d["dtype"], "x".join(map(str, d["bins"])), d["weighted"])] = d["ms"]
+            kind = d.get("edges", "linspace")
+            out["%dx%d %s bins=%s w=%d%s" % (d["rows"], d["cols"], d["dtype"], "x".join(map(str, d["bins"])), d["weighted"],
+                                              "" if kind == "linspace" else " edges=" + kind)] = d["ms"]
         elif scanner == "size_ramp":
             out["%s n=%d" % (d["case"], d["n"])] = d["us"] / 1e3
         else:

@@ -42,15 +42,38 @@ CASES = [
     (2000, 200_000, torch.float32, (400,), True),
     (40, 10_000_000, torch.float32, (2000,), True),
 ]
-for rows, cols, dt, nbs, weighted in CASES:
+def edges_of(kind, nb, seed):
+    if kind == "random":  # sorted uniform draws, end points kept (BASELINE C3's kind)
+        e = np.sort(np.random.default_rng(seed).uniform(-4, 4, nb + 1))
+        e[0], e[-1] = -4.0, 4.0
+        return e
+    if kind == "geometric":
+        return np.geomspace(1e-3, 4.0, nb + 1)
+    return np.linspace(-4, 4, nb + 1)
+
+
+# non-uniform edges (round 4: packed bucket entries on a linear or a float-bit-pattern grid) over the shape classes above
+NONUNIFORM = [
+    (456, 1_036_800, torch.float32, (50,), False, "random"),
+    (456, 1_036_800, torch.float32, (50,), False, "geometric"),
+    (1, 500_000_000, torch.float64, (256, 256), False, "random"),
+    (1, 500_000_000, torch.float64, (200, 200), False, "geometric"),
+    (1, 1_000_000_000, torch.float32, (2000,), False, "geometric"),
+    (1, 500_000_000, torch.float64, (300,), True, "geometric"),
+    (1_000_000, 365, torch.float32, (50,), False, "geometric"),
+    (64, 8_000_000, torch.float32, (64, 64), True, "random"),
+]
+for case in CASES + NONUNIFORM:
+    rows, cols, dt, nbs, weighted = case[:5]
+    kind = case[5] if len(case) > 5 else "linspace"
     d = len(nbs)
     arrs = [torch.empty((rows, cols), dtype=dt, device=dev).normal_(generator=g) for _ in range(d)]
     w = torch.empty((rows, cols), dtype=dt, device=dev).uniform_(generator=g) if weighted else None
-    bins = [np.linspace(-4, 4, nb + 1) for nb in nbs]
+    bins = [edges_of(kind, nb, 7 + k) for k, nb in enumerate(nbs)]
     ms = timed(lambda: core.histogram(*arrs, bins=bins if d > 1 else bins[0], weights=w, axis=1))
     plan = core._get_plan([np.asarray(b, dtype=np.float64) for b in bins], _native.CMP_F64, 0)
     byts = rows * cols * (d + (1 if weighted else 0)) * arrs[0].element_size()
-    print(json.dumps(dict(rows=rows, cols=cols, dtype=str(dt).split(".")[1], bins=list(nbs), weighted=weighted, ms=round(ms, 3),
+    print(json.dumps(dict(rows=rows, cols=cols, dtype=str(dt).split(".")[1], bins=list(nbs), weighted=weighted, edges=kind, ms=round(ms, 3),
                           gbs=round(byts / ms / 1e6), desc=plan.describe()[:120])), flush=True)
     del arrs, w
     torch.cuda.empty_cache()
