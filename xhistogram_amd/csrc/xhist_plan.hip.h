@@ -171,7 +171,7 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
     t.eL_f = e[E - 1];
     t.edge_off = edge_off;
     if (!f32dom) edge_off += (int32_t)words[d].size();
-    if (E < 2 || E > 65535) return XHIST_OK;
+    if (E < 2 || E > 65535 || E > 3 * k_budget) return XHIST_OK;  // (more than three edges per bucket whatever the grid)
     // buckets: eight per edge are plenty (a finer grid separates nothing more that matters) — every workgroup stages the
     // table, and a 32 KB table behind 50 edges cost the many-small-workgroups shapes 30 % (456 rows x 10^6 float32, 50 random
     // edges: 0.377 ms against 0.29; profiles/r04_j_*)
@@ -416,21 +416,7 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   int rc = build_domain(p, cmp_domain == XHIST_CMP_F64 ? 0 : 1, false, n_inputs, n_edges, words, edges, &p->ts[0][0],
                         mixed ? dim_dom : nullptr);
   if (rc == XHIST_OK && vector_sets) rc = build_domain(p, 0, true, n_inputs, n_edges, words, edges, &p->ts[0][1]);
-  if (rc == XHIST_OK && vector_sets && !mixed) {
-    // packed entries share the LDS with the histogram they serve: whatever the smallest form of this plan's histogram
-    // (packed uint16 counters) leaves, at most 32 KiB
-    size_t edge_bytes = 0;
-    for (int d = 0; d < n_inputs; ++d) edge_bytes += words[d].size() * 8;
-    const size_t hist_min = (((size_t)std::min<int64_t>(n_bins, (int64_t)1 << 24) + 1) / 2 + 32) * 4;
-    const size_t fixed = edge_bytes + 16 + 1024 + hist_min;
-    size_t budget = p->lds_max > fixed ? p->lds_max - fixed : 0;
-    budget = std::min<size_t>(budget, 32 * 1024);  // (C3: 27 KiB are left)
-    if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, false, n_inputs, n_edges, words, edges, budget);
-    // float32 samples: no edges in LDS next to the entries
-    const size_t fixed32 = 16 + 1024 + hist_min;
-    size_t budget32 = std::min<size_t>(p->lds_max > fixed32 ? p->lds_max - fixed32 : 0, 32 * 1024);
-    if (rc == XHIST_OK && budget32 >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, true, n_inputs, n_edges, words, edges, budget32);
-  }
+  const std::vector<std::vector<uint64_t>> words64 = words;  // (float64 edges + sentinels: the packed-entry sets below are built from them)
   if (rc == XHIST_OK && vector_sets) {
     // float32 thresholds: thr_j = smallest float32 >= e_j (then (double)x >= e_j <=> x >= thr_j)
     for (int d = 0; d < n_inputs; ++d) {
@@ -507,6 +493,33 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
         }
     }
     p->arith = all;
+  }
+  // (not for arithmetic edges — bins=int, np.linspace: their digitize is one compare per bucket or table-free, the packed
+  //  entries would never be picked, and every plan would pay their construction)
+  if (vector_sets && !mixed && !p->arith) {
+    int rc = XHIST_OK;
+    // packed entries share the LDS with the histogram they serve: whatever the smallest form of this plan's histogram
+    // (packed uint16 counters) leaves, at most 32 KiB
+    size_t edge_bytes = 0;
+    for (int d = 0; d < n_inputs; ++d) edge_bytes += words64[d].size() * 8;
+    const size_t hist_min = (((size_t)std::min<int64_t>(n_bins, (int64_t)1 << 24) + 1) / 2 + 32) * 4;
+    const size_t fixed = edge_bytes + 16 + 1024 + hist_min;
+    size_t budget = p->lds_max > fixed ? p->lds_max - fixed : 0;
+    budget = std::min<size_t>(budget, 32 * 1024);  // (C3: 27 KiB are left)
+    if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, false, n_inputs, n_edges, words64, edges, budget);
+    // float32 samples: no edges in LDS next to the entries
+    const size_t fixed32 = 16 + 1024 + hist_min;
+    size_t budget32 = std::min<size_t>(p->lds_max > fixed32 ? p->lds_max - fixed32 : 0, 32 * 1024);
+    if (rc == XHIST_OK && budget32 >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, true, n_inputs, n_edges, words64, edges, budget32);
+    if (rc != XHIST_OK) {
+      for (auto& dom : p->ts)
+        for (auto& t : dom)
+          if (t.blob) (void)hipFree(t.blob);
+      if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
+      if (p->ts_pk32.blob) (void)hipFree(p->ts_pk32.blob);
+      delete p;
+      return rc;
+    }
   }
   *out_plan = p;
   return XHIST_OK;
