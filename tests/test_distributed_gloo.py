@@ -277,3 +277,49 @@ def test_native_comm_deadline_through_the_python_shim():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RAISED after" in r.stdout and "rendezvous of 2 ranks" in r.stdout, r.stdout + r.stderr
     assert "SUM 28" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_native_comm_wait_gives_up_on_a_stream_that_does_not_drain():
+    """xhist_comm_wait's deadline on ONE GPU: a long spin kernel stands in for a collective whose peer died — the wait returns
+    XHIST_ERR_COMM after the deadline (not after the kernel), the communicator is aborted, later calls fail at once"""
+    import subprocess
+    import sys
+
+    code = (
+        "import time, torch\n"
+        "from xhistogram_amd import _native\n"
+        "_native.load()\n"
+        "c = _native.Comm(0, 0, 1, _native.comm_unique_id())\n"
+        "s = torch.cuda.current_stream().cuda_stream\n"
+        "t = torch.arange(8, dtype=torch.int64, device='cuda')\n"
+        "c.allreduce(t.data_ptr(), 8, _native.I64, _native.REDUCE_SUM, s)\n"
+        "c.wait(s)\n"
+        "torch.cuda._sleep(int(2.0e9 * 8))\n"  # ~7-8 s of GPU time on the stream
+        "t0 = time.time()\n"
+        "try:\n"
+        "    c.wait(s)\n"
+        "    print('NO ERROR')\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED after %.1f s: %s' % (time.time() - t0, e))\n"
+        "try:\n"
+        "    c.allreduce(t.data_ptr(), 8, _native.I64, _native.REDUCE_SUM, s)\n"
+        "    print('SECOND CALL WENT THROUGH')\n"
+        "except RuntimeError as e:\n"
+        "    print('AFTERWARDS: %s' % e)\n"
+        "c.close()\n"
+        "torch.cuda.synchronize()\n"
+        "print('DONE', int(t.sum()))\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XHIST_AMD_COMM_TIMEOUT_S="1.5", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RAISED after" in r.stdout and "deadline passed with the collective still in flight" in r.stdout, r.stdout + r.stderr
+    took = float(r.stdout.split("RAISED after ")[1].split(" s")[0])
+    # (the deadline fires after 1.5 s; ncclCommAbort then waits for the device to drain — for RCCL's own kernels that is immediate,
+    #  they poll the abort flag; the spin kernel of this test is not RCCL's and runs its 7-8 s out.  A wait that had simply
+    #  returned when the stream drained would not have raised at all.)
+    assert 1.0 < took < 20.0, r.stdout
+    assert "AFTERWARDS" in r.stdout and "was aborted earlier" in r.stdout, r.stdout
+    assert "DONE 28" in r.stdout, r.stdout + r.stderr
