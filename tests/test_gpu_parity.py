@@ -70,11 +70,11 @@ def test_hotpath_golden(xh, golden, name, resident):
     assert_hist_equal(got, want, weighted=w is not None)
 
 
-@pytest.mark.parametrize("mode", ["force_global", "force_generic", "lds_copies1"])
+@pytest.mark.parametrize("mode", ["force_global", "force_generic", "lds_copies1", "pack"])
 @pytest.mark.parametrize("name", sorted(MANIFEST["hotpath"]))
 def test_hotpath_golden_all_kernel_families(xh, golden, name, mode):
     samples, edges, w, want = golden.hotpath_case(name)
-    params = {"lds_copies": 1} if mode == "lds_copies1" else {mode: 1}
+    params = {"lds_copies": 1} if mode == "lds_copies1" else {mode: 1}  # ("pack": packed bucket entries wherever the plan has them)
     got, desc = _run(xh, samples, edges, w, True, **params)
     if desc:
         if mode == "force_global":
