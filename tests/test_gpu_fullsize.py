@@ -125,3 +125,40 @@ def test_c5_full_size_4e9_samples_weighted_density(xh):
     assert int(c1.sum()) == inside
     del x, y, c1, c2
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("signs", ["one", "both"])
+def test_partitioned_mode_sub_batches_on_two_streams_give_the_serial_result(xh, signs):
+    """the "overlap" form of the partitioned mode (routing pass of piece k + 1 under the adding-up pass of piece k, two record
+    pools in turn, fork / join by events; measured slower and off by default — DESIGN 4.2) must stay CORRECT: same
+    histogram as the serial form, for packed records (one sign) and for the exact redo (both signs)"""
+    if _free_gb() < 20:
+        pytest.skip("needs 20 GB of free device memory")
+    from xhistogram_amd import _native
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    n = 150_000_000
+    x = torch.empty(n, dtype=torch.float64, device=dev).normal_(generator=g)
+    y = torch.empty(n, dtype=torch.float64, device=dev).normal_(generator=g)
+    w = torch.empty(n, dtype=torch.float64, device=dev).uniform_(generator=g)
+    if signs == "both":
+        w -= 0.5
+    edges = [np.linspace(-4.0, 4.0, 1025)] * 2
+    plan = xh._get_plan(edges, _native.CMP_F64, 0)
+    want, _ = xh.histogram(x, y, bins=edges, weights=w)
+    assert "pieces=1" in plan.describe(), plan.describe()
+    try:
+        for pieces, cus in ((4, 48), (7, 32)):
+            plan.set_param("overlap", pieces)
+            plan.set_param("overlap_cus", cus)
+            got, _ = xh.histogram(x, y, bins=edges, weights=w)
+            desc = plan.describe()
+            assert "pieces=%d" % pieces in desc and "second stream" in desc, desc
+            torch.testing.assert_close(got, want, rtol=1e-9, atol=1e-6 if signs == "both" else 0.0)
+    finally:
+        plan.set_param("overlap", 0)
+        plan.set_param("overlap_cus", 0)
+    # a prefix against the oracle through the same overlapped call shape would need >= 6.7e7 samples: the sum stands in
+    assert abs(float(want.sum()) - float(w[(x >= -4) & (x <= 4) & (y >= -4) & (y <= 4)].sum())) <= 1e-6 * float(w.abs().sum())
