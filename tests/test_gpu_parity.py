@@ -2304,7 +2304,8 @@ def _pack_torture(edges, rng, n_random):
         parts += [m, np.nextafter(m, -np.inf), np.nextafter(m, np.inf)]
     parts += [np.repeat(e, 8) + rng.uniform(-1.5, 1.5, e.size * 8) * np.repeat(ulp, 8),
               rng.uniform(e[0] - 0.1 * (e[-1] - e[0]), e[-1] + 0.1 * (e[-1] - e[0]), n_random),
-              np.array([np.nan, np.inf, -np.inf, e[0], e[-1], 0.0, -0.0])]
+              np.array([np.nan, np.inf, -np.inf, e[0], e[-1], 0.0, -0.0, 1e-10, -1e-10, 1e-40, -1e-40, 5e-324, -5e-324]),
+              0.5 * np.abs(e[e != 0]).min() * np.array([1.0, -1.0, 1.0 - 1e-9, -1.0 + 1e-9])]
     x = np.concatenate(parts)
     rng.shuffle(x)
     return x.reshape(1, -1)
@@ -2322,6 +2323,7 @@ _PACK_EDGES = {
     "geometric_2001": lambda rng: np.geomspace(1e-3, 50.0, 2001),
     "logspace_negative": lambda rng: -np.logspace(3, -2, 400),
     "symlog": lambda rng: np.concatenate([-np.geomspace(50.0, 1e-3, 200), [0.0], np.geomspace(1e-3, 50.0, 200)]),
+    "symlog_no_zero": lambda rng: np.concatenate([-np.geomspace(9.0, 1e-5, 120), np.geomspace(3e-4, 700.0, 333)]),
     "negative_129": lambda rng: _sorted_uniform(rng, 129, -1000.0, -999.0),
     "few_5": lambda rng: np.array([-1.0, -0.25, 0.1, 0.7, 3.0]),
     "two_edges": lambda rng: np.array([0.3, 0.7]),
@@ -2335,8 +2337,10 @@ _PACK_EDGES = {
     "cluster_of_five": lambda rng: np.sort(np.concatenate([rng.uniform(-2, 2, 60), 0.123 + np.arange(5) * 1e-9])),
 }
 _PACK_NOT_OFFERED = {"beyond_float32", "below_float32", "one_float32_ulp", "duplicates", "cluster_of_five"}
-_PACK_EITHER = {"two_edges", "symlog"}  # (no bucket grid of the LDS budget separates the edges around zero of a symmetric log axis)
-_PACK_KEY_MAP = {"geometric_300", "geometric_2001", "logspace_negative"}  # float-bits buckets (scan=8)
+_PACK_EITHER = {"two_edges"}
+# float-bits buckets (scan=8); "symlog": edges on both sides of zero — magnitudes below the smallest |edge| are lifted to it and the
+# empty binades around zero cut out of the key space
+_PACK_KEY_MAP = {"geometric_300", "geometric_2001", "logspace_negative", "symlog", "symlog_no_zero"}
 
 
 @pytest.mark.parametrize("weights", [None, "f64", "f32"])

@@ -38,6 +38,8 @@ cases = [
     ("1d 257 nonuniform, weighted", [nonuniform(257, 1)], True),
     ("1d 2001 geometric", [np.geomspace(1e-3, 4.0, 2001)], False),
     ("1d 300 geometric, weighted", [np.geomspace(1e-3, 4.0, 301)], True),
+    ("1d 401 symlog", [np.concatenate([-np.geomspace(4.0, 1e-3, 200), [0.0], np.geomspace(1e-3, 4.0, 200)])], False),
+    ("2d 121 symlog x 200 geometric, weighted", [np.concatenate([-np.geomspace(4.0, 1e-2, 60), [0.0], np.geomspace(1e-2, 4.0, 60)]), np.geomspace(1e-3, 4.0, 51)], True),
     ("2d 200 geometric x 200 geometric", [np.geomspace(1e-3, 4.0, 201), np.geomspace(1e-2, 5.0, 201)], False),
 ]
 for name, edges, weighted in cases:

@@ -30,6 +30,11 @@ def edges_for(rng, kind, nb, lo=-3.0, hi=3.0):
         return lo + np.concatenate([[0.0], np.cumsum(np.geomspace(1e-6, 1.0, nb))]) * (hi - lo) / np.geomspace(1e-6, 1.0, nb).sum()
     if kind == "logspace":  # geometric edges: the float-bit-pattern bucket grid of the packed entries (round 4)
         return np.geomspace(10.0 ** float(rng.integers(-6, 0)), hi * float(rng.choice([1.0, 3.0, 1e3])), nb + 1)
+    if kind == "symlog":  # edges on both sides of zero, logarithmic away from it
+        h = max(1, nb // 2)
+        pos = np.geomspace(10.0 ** float(rng.integers(-5, -1)), hi, h)
+        e = np.concatenate([-pos[::-1], [0.0], pos]) if rng.random() < 0.5 else np.concatenate([-pos[::-1] * float(rng.choice([1.0, 0.3])), pos])
+        return e
     if kind == "int":
         return np.arange(-nb // 2, nb - nb // 2 + 1).astype(np.int64)
     raise ValueError(kind)
@@ -49,7 +54,7 @@ def one(seed):
     dtype = rng.choice(["f64", "f32", "i32", "i64", "u8", "f16"])
     # a third of the joint histograms mix dtypes (the mixed-dtype vector kernels / the generic family)
     dtypes = [str(rng.choice(["f64", "f32", "i32", "i16", "u8", "f16"])) if (d > 1 and rng.random() < 0.35) else str(dtype) for _ in range(d)]
-    kinds = ["int" if dt in ("i32", "i64", "u8", "i16") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "random", "geom", "logspace"])) for dt in dtypes]
+    kinds = ["int" if dt in ("i32", "i64", "u8", "i16") and rng.random() < 0.5 else str(rng.choice(["linspace", "linspace", "random", "random", "geom", "logspace", "symlog"])) for dt in dtypes]
     nbmax = {1: 70_000, 2: 400, 3: 50}[d]
     nbs = [int(rng.choice([1, 3, 17, 100, int(rng.integers(1, nbmax))])) for _ in range(d)]
     edges = [edges_for(rng, k, nb) for k, nb in zip(kinds, nbs)]

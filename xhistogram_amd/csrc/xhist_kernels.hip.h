@@ -63,6 +63,12 @@ struct DimTable {
   int32_t map_kind;
   uint32_t key_lo;
   int32_t key_shift;
+  // edges on BOTH sides of zero (a symmetric-log axis): magnitudes below key_floor = the smallest non-zero |edge| are lifted to
+  // it before the key is taken (still monotone: everything in (-floor, +floor) holds no edge but possibly 0), and the ~250
+  // empty binades between key(-floor) and key(+floor) are cut out of the key space: keys >= key_pos0 move down by key_gap.
+  // key_floor = 0: one-sided edges, nothing of this
+  float key_floor;
+  uint32_t key_pos0, key_gap;
   int32_t is_i64;       // per-dimension domains (Dom<3>): this input compares in int64
   int64_t xor_bias;     // int64 domain of UNSIGNED values: 2^63, flipping the sign bit maps uint64 order onto int64 order
 };
@@ -317,10 +323,19 @@ __host__ __device__ __forceinline__ uint32_t float_order_key(float xf) {
 }
 
 // bucket of the packed entries under the float-bits map: monotone in xf, hence in x
-__host__ __device__ __forceinline__ int bucket_of_key(float xf, uint32_t key_lo, int key_shift, int lut_k) {
-  const uint32_t k = float_order_key(xf);
+__host__ __device__ __forceinline__ int bucket_of_key(float xf, uint32_t key_lo, int key_shift, int lut_k, float key_floor = 0.0f,
+                                                      uint32_t key_pos0 = 0u, uint32_t key_gap = 0u) {
+  if (key_floor > 0.0f) {  // (uniform: a kernel argument) two-sided edges — see DimTable
+    xf += 0.0f;            // -0.0 -> +0.0 BEFORE the sign is copied: both zeros go to +floor
+    xf = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(xf), key_floor), xf);
+  }
+  uint32_t k = float_order_key(xf);
+  if (key_floor > 0.0f && k >= key_pos0) k -= key_gap;
   const uint32_t d = (k > key_lo ? k - key_lo : 0u) >> key_shift;
   return (int)(d < (uint32_t)(lut_k - 1) ? d : (uint32_t)(lut_k - 1));
+}
+__host__ __device__ __forceinline__ int bucket_of_key(float xf, const DimTable& t) {
+  return bucket_of_key(xf, t.key_lo, t.key_shift, t.lut_k, t.key_floor, t.key_pos0, t.key_gap);
 }
 typedef uint32_t pack_entry_t __attribute__((ext_vector_type(4), aligned(16)));
 
@@ -335,7 +350,7 @@ __device__ __forceinline__ uint32_t count_le_pack(double x, const DimTable& t, T
     // (plan creation admits |e| <= 3e38 only), so it counts every edge and is dropped like any sample above e_last.
     // (the linear map sends NaN to bucket 0, where it counts no edge: dropped as well)
     xf = __builtin_fminf(xf, 3.402823466e+38f);
-    b = bucket_of_key(xf, t.key_lo, t.key_shift, t.lut_k);
+    b = bucket_of_key(xf, t);
   } else {
     b = bucket_of<2>(xf, t);
   }
@@ -361,7 +376,7 @@ __device__ __forceinline__ uint32_t count_le_pack_f32(float x, const DimTable& t
   int b;
   if (KEYMAP) {
     x = __builtin_fminf(x, 3.402823466e+38f);  // NaN (and +inf) -> FLT_MAX: counts every threshold, dropped (see count_le_pack)
-    b = bucket_of_key(x, t.key_lo, t.key_shift, t.lut_k);
+    b = bucket_of_key(x, t);
   } else {
     b = bucket_of<2>(x, t);
   }
@@ -1206,7 +1221,7 @@ static __global__ void __launch_bounds__(256) build_pack_tables(const DimTable t
   pack_entry_t* ent = reinterpret_cast<pack_entry_t*>(blob) + t.lut_off;
   auto thr_of = [&](int j) { return thr_given ? thr_given[j] : (float)edges[j]; };
   for (int j = threadIdx.x; j < t.n_edges; j += blockDim.x)
-    scratch[j] = t.map_kind ? bucket_of_key(thr_of(j), t.key_lo, t.key_shift, t.lut_k) : bucket_of<2>(thr_of(j), t);
+    scratch[j] = t.map_kind ? bucket_of_key(thr_of(j), t) : bucket_of<2>(thr_of(j), t);
   __syncthreads();
   for (int b = threadIdx.x; b < t.lut_k; b += blockDim.x) {
     int lo = 0, hi = t.n_edges;

@@ -213,7 +213,30 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
     }
     // a linear grid cannot separate these edges (geometric / logarithmic spacing: most of them sit in its first buckets):
     // buckets on the float32 bit pattern instead — uniform in log x; integer arithmetic, the same on host and device
-    const uint32_t k0 = float_order_key(thr[0]), k1 = float_order_key(thr[(size_t)E - 1]);
+    // edges on both sides of zero: lift magnitudes below the smallest non-zero |edge| and cut the empty binades around zero out
+    // of the key space (DimTable::key_floor) — a symmetric-log axis then has as many buckets per decade as a one-sided one
+    float kfloor = 0.0f;
+    uint32_t kpos0 = 0u, kgap = 0u;
+    if (thr[0] < 0.0f && thr[(size_t)E - 1] > 0.0f) {
+      float m = INFINITY;
+      for (int j = 0; j < E; ++j)
+        if (thr[(size_t)j] != 0.0f) m = std::min(m, std::fabs(thr[(size_t)j]));
+      if (std::isfinite(m) && m > 0.0f) {
+        kfloor = m;
+        kpos0 = float_order_key(m);
+        kgap = kpos0 - float_order_key(-m) - 1u;
+      }
+    }
+    auto key_of = [&](float v) {  // (as bucket_of_key sees it, before the shift)
+      if (kfloor > 0.0f) {
+        v += 0.0f;
+        v = std::copysign(std::fmax(std::fabs(v), kfloor), v);
+      }
+      uint32_t k = float_order_key(v);
+      if (kfloor > 0.0f && k >= kpos0) k -= kgap;
+      return k;
+    };
+    const uint32_t k0 = key_of(thr[0]), k1 = key_of(thr[(size_t)E - 1]);
     int best_shift = -1;
     best_k = 0;
     for (int shift = 0; shift < 32; ++shift) {
@@ -222,7 +245,7 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
       const int K = (int)std::max<uint64_t>(K64, 2);
       int run = 0, prev = -1, mx = 0;
       for (int j = 0; j < E; ++j) {
-        const int b = bucket_of_key(thr[(size_t)j], k0, shift, K);
+        const int b = bucket_of_key(thr[(size_t)j], k0, shift, K, kfloor, kpos0, kgap);
         run = b == prev ? run + 1 : 1;
         prev = b;
         mx = std::max(mx, run);
@@ -235,6 +258,9 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
     t.map_kind = 1;
     t.key_lo = k0;
     t.key_shift = best_shift;
+    t.key_floor = kfloor;
+    t.key_pos0 = kpos0;
+    t.key_gap = kgap;
     t.steps = 1;
     ts->max_cnt = -1;  // (marks "some dimension uses the float-bits map" until the device-built table is verified below)
   }
