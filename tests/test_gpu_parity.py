@@ -2521,3 +2521,31 @@ def test_packed_bucket_entries_in_the_row_per_lane_and_flat_rows_kernels(xh, sha
     finally:
         plan.set_param("pack", 0)
     assert_hist_equal(got.cpu().numpy(), want, w is not None)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("weights", ["none", "f32", "f64_one_sign", "f64_both_signs"])
+@pytest.mark.parametrize("kind", ["geometric", "random", "symlog"])
+def test_partitioned_mode_routes_with_packed_bucket_entries(xh, kind, weights, dtype):
+    """histograms beyond LDS on non-uniform edges: the one-pass routing pass digitizes with the packed entries (general
+    variant) instead of a binary search / a 3-edge scan; samples on and around every edge"""
+    rng = np.random.default_rng(700 + len(kind))
+    if kind == "geometric":
+        edges = [np.geomspace(1e-3, 5.0, 301), np.geomspace(1e-2, 9.0, 281)]
+    elif kind == "symlog":
+        edges = [np.concatenate([-np.geomspace(5.0, 1e-3, 150), [0.0], np.geomspace(1e-3, 5.0, 150)]), np.geomspace(1e-2, 9.0, 281)]
+    else:
+        edges = [_sorted_uniform(rng, 257, -4.0, 4.0), _sorted_uniform(rng, 300, -4.0, 4.0)]
+    cols = [_pack_torture(e, rng, 150_000) for e in edges]
+    n = min(c.shape[1] for c in cols)
+    with np.errstate(over="ignore", invalid="ignore"):
+        samples = [np.roll(c[:, :n], 7919 * d, axis=1).astype(dtype) for d, c in enumerate(cols)]
+    w = {"none": None, "f32": rng.uniform(0, 1, (1, n)).astype(np.float32), "f64_one_sign": rng.uniform(0, 1, (1, n)),
+         "f64_both_signs": rng.uniform(-1, 1, (1, n))}[weights]
+    want = onp.bincount_rows(samples, edges, w)
+    got, desc = _run(xh, samples, edges, w, True, partition=1)
+    assert "hist=partitioned" in desc and "route=fused" in desc and "scan=8" in desc, desc
+    assert_hist_equal(got, want, w is not None)
+    got, desc = _run(xh, samples, edges, w, True, partition=1, pack=-1)
+    assert "scan=8" not in desc, desc
+    assert_hist_equal(got, want, w is not None)

@@ -1226,6 +1226,23 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
           }
         }
       }
+      // non-uniform edges: the packed entries (general variant) instead of a binary search or a 2-4-edge scan per sample and
+      // dimension — the routing pass feels its digitize (5*10^8 float64 pairs into 512 x 512 counts: linspace 2.07 ms, random
+      // edges 2.48, geometric 3.42; profiles/r04_l_*) — where entries and sort buffers fit the LDS together
+      {
+        const int pk_np = sdt == XHIST_F64 ? p->pk_np : (sdt == XHIST_F32 && use_f32 ? p->pk32_np : 0);
+        if (pk_np && pack_pref >= 0 && r_scan != kScanArith && (r_scan == 0 || r_scan >= 2 || pack_pref > 0) && n_parts <= 128) {
+          const TableSet& pk = sdt == XHIST_F64 ? p->ts_pk : p->ts_pk32;
+          int spl = geom.spl;
+          if (spl == 8 && part_route_lds((size_t)pk.words * 8, (int)n_parts, weighted, route_tile(geom.block, 8), geom.block) > p->lds_max) spl = 4;
+          if (part_route_lds((size_t)pk.words * 8, (int)n_parts, weighted, route_tile(geom.block, spl), geom.block) <= p->lds_max &&
+              route_kernel(sdt, w_tag, D, kScanPackG, false, geom.block, spl)) {
+            r_scan = kScanPackG;
+            r_tset = &pk;
+            geom.spl = spl;
+          }
+        }
+      }
       const int r_block = geom.block, r_tile = route_tile(r_block, geom.spl);
       // rows that follow each other at one stride go through the routing pass several at a time
       // (32 x 3*10^7 float32 pairs + weights, 300 x 300 bins: 8.05 -> 6.02 ms; 8 x 6*10^7 float64, 512 x 512: 5.17 -> 4.18;

@@ -224,6 +224,7 @@ static kernel_fn_route route_pick_ds(int D, int scan, bool multi) {
     if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, false, BLOCK, SPL>;            \
     if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2, false, BLOCK, SPL>;            \
     if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, false, BLOCK, SPL>; \
+    if (scan == kScanPackG) return (kernel_fn_route)part_route<ST, WT, DD, kScanPackG, false, BLOCK, SPL>; \
     return nullptr;
   switch (D) {
     XH_ROUTE_CASE(1)

@@ -530,13 +530,21 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
     for (int d = 0; d < n_inputs; ++d) edge_bytes += words64[d].size() * 8;
     const size_t hist_min = (((size_t)std::min<int64_t>(n_bins, (int64_t)1 << 24) + 1) / 2 + 32) * 4;
     const size_t fixed = edge_bytes + 16 + 1024 + hist_min;
-    size_t budget = p->lds_max > fixed ? p->lds_max - fixed : 0;
+    // (a histogram that cannot live in LDS at all leaves it to the routing pass of the partitioned mode, whose sort buffers
+    //  sit next to the entries: the full 32 KiB)
+    const bool beyond_lds = hist_min + edge_bytes + 2048 > p->lds_max;
+    size_t budget = beyond_lds ? 32 * 1024 : (p->lds_max > fixed ? p->lds_max - fixed : 0);
     budget = std::min<size_t>(budget, 32 * 1024);  // (C3: 27 KiB are left)
     if (budget >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, false, n_inputs, n_edges, words64, edges, budget);
+    // a histogram that fills most of the LDS leaves too little for a usable grid — but its WEIGHTED form (float64 sums) is
+    // beyond LDS anyway and goes to the routing pass, which has room: the full budget then (the LDS kernels check the fit)
+    const bool big_hist = hist_min > p->lds_max / 4;
+    if (rc == XHIST_OK && !p->pk_np && big_hist && budget < 32 * 1024) rc = build_pack_domain(p, false, n_inputs, n_edges, words64, edges, 32 * 1024);
     // float32 samples: no edges in LDS next to the entries
     const size_t fixed32 = 16 + 1024 + hist_min;
-    size_t budget32 = std::min<size_t>(p->lds_max > fixed32 ? p->lds_max - fixed32 : 0, 32 * 1024);
+    size_t budget32 = beyond_lds ? 32 * 1024 : std::min<size_t>(p->lds_max > fixed32 ? p->lds_max - fixed32 : 0, 32 * 1024);
     if (rc == XHIST_OK && budget32 >= 16 * 8 * (size_t)n_inputs) rc = build_pack_domain(p, true, n_inputs, n_edges, words64, edges, budget32);
+    if (rc == XHIST_OK && !p->pk32_np && big_hist && budget32 < 32 * 1024) rc = build_pack_domain(p, true, n_inputs, n_edges, words64, edges, 32 * 1024);
     if (rc != XHIST_OK) {
       for (auto& dom : p->ts)
         for (auto& t : dom)

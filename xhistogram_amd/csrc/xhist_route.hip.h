@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) bins[d][v] = bin_from_count<CMP>((CT)xs[d][0][v], p.dim[d], cntle[d][0][v]);
+          for (int v = 0; v < 4; ++v) bins[d][v] = bin_from_tile_count<CMP, SCAN>((CT)xs[d][0][v], p.dim[d], cntle[d][0][v]);
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
