@@ -7,10 +7,12 @@ cut up:   tools/shape_cliffs.py (rows x cols x bins x dtype),  tools/size_ramp.p
 tools/hist2d_sizes.py (64^2 ... 1024^2 bins x 10^5 ... 10^8 samples).
 
   python tools/check_cliffs.py run <dir>                       run the scanners on this GPU, write <dir>/*.jsonl
-  python tools/check_cliffs.py compare <baseline dir> <dir>    exit 1 if a cell is more than --tol (10 %) slower than the baseline
+  python tools/check_cliffs.py compare <baseline dir> <dir>    exit 1 if a cell is more than --tol (12 %) slower than the baseline
 
 Boxes differ by a few percent in HBM rate and clocks, so `compare` first takes the MEDIAN ratio new / baseline over all cells
-(the box factor) and judges every cell against it; cells under 20 us get 2 us of slack (launch jitter).  The committed
+(the box factor) and judges every cell against it; cells under 20 us get 2 us of slack (launch jitter).  Noise floor: the same
+code scanned three times on ONE box differs by up to 11 % in one cell of 122 per pair of scans (mid-size kernels, whose clocks
+move with what ran before them) even though every measurement now warms up for 25 ms first — hence 12 %, not 10.  The committed
 baseline is profiles/cliffs_baseline/ (its README line says which commit and when); tools/profile_configs.sh runs the gate
 at the end of every evidence set.
 """
@@ -92,7 +94,7 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "run":
         run(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "compare":
-        tol = 0.10
+        tol = 0.12
         if "--tol" in sys.argv:
             tol = float(sys.argv[sys.argv.index("--tol") + 1])
         raise SystemExit(compare(sys.argv[2], sys.argv[3], tol))

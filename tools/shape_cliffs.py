@@ -21,6 +21,10 @@ def timed(fn, reps=5):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.025:  # warm up past the clock excursion of the first ~13 ms of a burst
+        fn()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
