@@ -253,7 +253,7 @@ def main():
         out = {}
         t_start = time.perf_counter()
         budget_s = 45.0
-        for cfg, steps, warmup in (("c3", 10, 8), ("c4", 100, 30), ("c5", 10, 6)):  # (warm-up past the first ~13 ms of a burst, see parse())
+        for cfg, steps, warmup in (("c3", 20, 10), ("c4", 200, 50), ("c5", 20, 10)):  # (the steps / warm-up of a dedicated --config run, see parse())
             if time.perf_counter() - t_start > budget_s:
                 out[cfg] = {"skipped": "wall budget of %.0f s used up by the configs before it" % budget_s}
                 continue
