@@ -503,14 +503,12 @@ def test_dense_short_rows_streamed_flat(xh, shape, dtype, edges_kind):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("weights", [None, "f32", "f64", "both_signs_and_nan"])
-@pytest.mark.parametrize("dims", [1, 2])
+@pytest.mark.parametrize("dims,weights", [(d, w) for d in (1, 2) for w in (None, "f32", "f64", "both_signs_and_nan")
+                                          if not (d == 1 and w is None)])  # (one input without weights: test_dense_short_rows_streamed_flat)
 @pytest.mark.parametrize("shape", [(5000, 365), (4097, 20), (9000, 1), (4097, 3), (7777, 64), (5001, 255), (4099, 800)])
 def test_dense_short_rows_streamed_flat_weights_and_joint(xh, shape, dims, weights, dtype):
     """hist_flat_rows with weights (float64 sums in LDS, one copy) and with two inputs (joint bins): the reference's per-row
     result, NaN weights poisoning only their own bin, NaN weights on dropped samples discarded (core.py:73-83)."""
-    if dims == 1 and weights is None:
-        pytest.skip("covered by test_dense_short_rows_streamed_flat")
     rng = np.random.default_rng(shape[1] * 3 + dims)
     xs = [rng.standard_normal(shape).astype(dtype) for _ in range(dims)]
     xs[0][::7, ::5] = np.nan
