@@ -17,6 +17,10 @@ cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 export XHIST_AMD_COMM_TIMEOUT_S="${XHIST_AMD_COMM_TIMEOUT_S:-60}"
 ngpu=$(python -c "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)" 2>/dev/null || echo 0)
+# FIRST_CONTACT_DRY=1 FIRST_CONTACT_NGPU=8: print the commands of an 8-GPU run without running anything (a syntax check of the
+# branches no one-GPU box reaches; profiles/r04_d_first_contact_dry_run_8_gpus.txt)
+dry="${FIRST_CONTACT_DRY:-0}"
+[ "$dry" = 1 ] && ngpu="${FIRST_CONTACT_NGPU:-8}"
 echo "first_contact: $ngpu GPU(s) visible, deadline ${XHIST_AMD_COMM_TIMEOUT_S} s, output in $out"
 summary="$out/summary.txt"
 : > "$summary"
@@ -24,6 +28,7 @@ note() { echo "$*" | tee -a "$summary"; }
 step() {  # step <name> <timeout s> <command...>
   local name="$1" limit="$2"; shift 2
   local t0=$SECONDS
+  if [ "$dry" = 1 ]; then note "   [dry] timeout $limit $*"; return 0; fi
   timeout "$limit" "$@" > "$out/$name.log" 2>&1
   local rc=$?
   note "$(printf '%-34s rc %-3d %4d s   %s' "$name" "$rc" "$((SECONDS - t0))" "$(grep -E 'passed|failed|skipped|^OK|^FAIL' "$out/$name.log" | tail -1 | cut -c1-90)")"
@@ -44,7 +49,7 @@ else
 fi
 
 note "== 3  plain-C client, one process per GPU"
-gcc -O2 -Wall -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/capi_comm_client.c -o "$out/capi_comm_client" \
+[ "$dry" = 1 ] || gcc -O2 -Wall -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/capi_comm_client.c -o "$out/capi_comm_client" \
     -L xhistogram_amd -lxhist_amd -Wl,-rpath,"$R/xhistogram_amd" -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lm > "$out/3_build.log" 2>&1 \
   || note "   build failed: see $out/3_build.log"
 for n in 1 2 4 8; do
@@ -63,7 +68,7 @@ for n in 1 2 4 8; do
   # (N = 1 also under the launcher: the nccl path is on, one all-reduce per step — the per-step overhead the strong leg has to afford)
   step "5_bench_${n}_gpus" 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
        bench.py --gpus "$n" --no-cpu-baseline --no-other-configs
-  grep -E '^\{' "$out/5_bench_${n}_gpus.log" | tail -1 > "$out/bench_${n}.json"
+  [ "$dry" = 1 ] || grep -E '^\{' "$out/5_bench_${n}_gpus.log" | tail -1 > "$out/bench_${n}.json"
 done
 python - "$out" <<'PY' | tee -a "$summary"
 import json, os, sys
