@@ -237,6 +237,8 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
       return k;
     };
     const uint32_t k0 = key_of(thr[0]), k1 = key_of(thr[(size_t)E - 1]);
+    // buckets per edge the search stops at (development override: XHIST_AMD_KEY_K_PER_EDGE)
+    static const double key_k_per_edge = [] { const char* e = getenv("XHIST_AMD_KEY_K_PER_EDGE"); return e && *e ? atof(e) : 0.0; }();
     int best_shift = -1;
     best_k = 0;
     for (int shift = 0; shift < 32; ++shift) {
@@ -250,8 +252,13 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
         prev = b;
         mx = std::max(mx, run);
       }
-      if (mx <= 3) { best_shift = shift; best_k = K; }
-      break;  // (the first shift that fits the budget is the finest grid: coarser ones only merge buckets)
+      // the general kernels always compare three thresholds, so the COARSEST grid that keeps three edges per bucket is the
+      // best one: the smallest table to stage and to hold in LDS (401 geometric edges: 192 buckets = 3 KB instead of 1536 =
+      // 24 KB).  Coarser grids only merge buckets, so the search ends at the first one that holds four.
+      if (mx > 3) break;
+      best_shift = shift;
+      best_k = K;
+      if ((double)K <= key_k_per_edge * (double)E) break;  // coarse enough (see key_k_per_edge)
     }
     if (best_shift < 0) return XHIST_OK;
     t.lut_k = best_k;
