@@ -103,7 +103,7 @@ def spread():
 
     seen, lock = [], threading.Lock()
 
-    def oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+    def oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
         arrays = [np.asarray(a) for a in all_arrays]
         w = arrays.pop() if weights else None
         nd = arrays[0].ndim

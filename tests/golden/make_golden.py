@@ -179,7 +179,29 @@ def jsonable(v):
     return v
 
 
+def signatures():
+    """the reference's public / hot-path signatures as text (north_star: "exact signatures"): core functions through
+    inspect; xarray.histogram from the SOURCE with ast — the module cannot be imported here (no xarray in any interpreter)"""
+    import ast
+    import inspect
+
+    out = {"core.%s" % n: str(inspect.signature(getattr(ref, n))) for n in ("histogram", "_bincount", "_bincount_2d_vectorized")}
+    src = os.path.join(os.path.dirname(ref.__file__), "xarray.py")
+    for node in ast.parse(open(src).read()).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "histogram":
+            out["xarray.histogram"] = "(" + ast.unparse(node.args) + ")"
+    return out
+
+
 def main():
+    if "--signatures-only" in sys.argv:  # refresh manifest["signatures"] without rewriting the .npz archives
+        path = os.path.join(HERE, "manifest.json")
+        manifest = json.load(open(path))
+        manifest["signatures"] = signatures()
+        with open(path, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print("wrote", len(manifest["signatures"]), "signatures")
+        return
     manifest = {
         "python": sys.version.split()[0],
         "numpy": np.__version__,
@@ -188,6 +210,7 @@ def main():
         "hotpath": {},
         "core": {},
         "dask_cases": {},
+        "signatures": signatures(),
     }
     hp = {}
     for name, (samples, edges, weights) in hotpath_cases().items():

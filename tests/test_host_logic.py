@@ -156,7 +156,7 @@ def test_collapse_describes_the_reference_layout_by_strides():
     assert d == (60, 3, 6, 2, 0, 0) and core._view_of(y, d, "numpy")[4:6] == (60, 0)
 
 
-def _oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+def _oracle_bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
     """stand-in for core._bincount with the same contract, computed by the oracle (CPU): lets the
     host-side rewrites around it run without a GPU"""
     arrays = list(all_arrays)
@@ -326,3 +326,19 @@ def test_moments_of_shards_combine_to_the_moments_of_the_whole():
     nan_part = (3, np.nan, np.nan, np.nan, np.nan)
     assert np.isnan(core.combine_moments([parts[0], nan_part, parts[3]])[1])
 
+
+
+def test_public_signatures_are_the_references():
+    """north_star: "exact signatures".  tests/golden/manifest.json holds str(inspect.signature(...)) of the reference's
+    histogram / _bincount / _bincount_2d_vectorized (core.py:250-258, :197-199, :137-139) and xarray.histogram's
+    (xarray.py:13-23, from its source), written by make_golden.py in the build container"""
+    import inspect
+    import json
+    import os
+
+    from xhistogram_amd import xarray as xh_xarray
+
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest.json")))["signatures"]
+    got = {"core.%s" % n: str(inspect.signature(getattr(core, n))) for n in ("histogram", "_bincount", "_bincount_2d_vectorized")}
+    got["xarray.histogram"] = str(inspect.signature(xh_xarray.histogram))
+    assert got == want

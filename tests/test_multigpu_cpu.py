@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _oracle_bincount(seen):
-    def fn(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
+    def fn(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
         arrays = [a.numpy() if hasattr(a, "numpy") else np.asarray(a) for a in all_arrays]
         w = arrays.pop() if weights else None
         nd = arrays[0].ndim

@@ -679,15 +679,25 @@ def _bincount_partial(*all_arrays, **kwargs):
             _tls.device_out = prev
 
 
-def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None, second_weights=False):
-    """Block adapter with the reference's contract (core.py:197-247): N-D block(s) in, array of
-    shape kept-axes (1 for each reduced axis) + bin dims out.  Called directly for numpy/torch
-    inputs and once per block by the dask branch (core.py:429-437).
+def _bincount(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
+    """Block adapter with the reference's contract AND signature (core.py:197-247): N-D block(s) in,
+    array of shape kept-axes (1 for each reduced axis) + bin dims out.  Called directly for
+    numpy/torch inputs and once per block by the dask branch (core.py:429-437).
 
     Where the reference moves the reduced axes last and reshapes (a copy for anything but
     trailing axes), the block is DESCRIBED to the native library as a strided [rows, cols] view —
     broadcast inputs, leading-axis and middle-axis reductions included — and only layouts no
     three strides can express fall back to that copy."""
+    return _block_adapter(all_arrays, weights, axis, bins, density, block_size, False)
+
+
+def _bincount_two_weights(*all_arrays, weights=False, axis=None, bins=None, density=None, block_size=None):
+    """`_bincount` for histogram_two_weights (an extension, private): the LAST TWO of `all_arrays` are weight
+    arrays, the result carries a leading pair axis."""
+    return _block_adapter(all_arrays, weights, axis, bins, density, block_size, True)
+
+
+def _block_adapter(all_arrays, weights, axis, bins, density, block_size, second_weights):
     backend = _backend_of(all_arrays)
     if backend == "device":
         # a dask block: chunks that live on a GPU next to host chunks (weights from a numpy-backed dask array) — the
@@ -1375,7 +1385,7 @@ def histogram_two_weights(*args, bins=None, range=None, axis=None, weights=None,
         ha, bins_out = histogram(*args, bins=bins, range=range, axis=axis, weights=wa, block_size=block_size)
         hb, _ = histogram(*args, bins=bins_out, axis=axis, weights=wb, block_size=block_size)
         return ha, hb, bins_out
-    ha, bins_out = histogram(*args, bins=bins, range=range, axis=axis, weights=wa, block_size=block_size, _second_weights=wb)
+    ha, bins_out = _histogram(args, bins, range, axis, wa, False, block_size, wb)
     return ha[0], ha[1], bins_out
 
 
@@ -1531,7 +1541,7 @@ def _counts_one_device(all_arrays, w_raw, n_inputs, has_weights, two, drop_axes,
     if counts is None and not two:
         counts = _reduce_in_two_steps(all_arrays, has_weights, drop_axes, bins, block_size, backend)
     if counts is None:
-        counts = _bincount(*all_arrays, **bincount_kwargs)
+        counts = (_bincount_two_weights if two else _bincount)(*all_arrays, **bincount_kwargs)
     return counts
 
 
@@ -1578,7 +1588,7 @@ def _dask_graph(all_arrays, has_weights, drop_axes, bins, bincount_kwargs):
     )
 
 
-def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto", _second_weights=None):
+def histogram(*args, bins=None, range=None, axis=None, weights=None, density=False, block_size="auto"):
     """Histogram applied along specified axis / axes, computed on an MI355X.
 
     Same signature, argument meaning, return value and error behaviour as
@@ -1609,6 +1619,12 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     int64 counts, or float64 when weighted / density.  numpy in -> numpy out, torch in -> torch
     out (same device), dask in -> lazy dask array.
     """
+    return _histogram(args, bins, range, axis, weights, density, block_size, None)
+
+
+def _histogram(args, bins, range, axis, weights, density, block_size, _second_weights):
+    """body of :func:`histogram`; `_second_weights` is histogram_two_weights' second weight array (private: the public
+    functions keep the reference's exact signatures, core.py:250-258 and :197-199)"""
     n_inputs = len(args)
     axis = _normalise_axis(axis, args[0].ndim if hasattr(args[0], "ndim") else np.ndim(args[0]))  # (np.ndim would compute a dask array)
     if _second_weights is None:
@@ -1666,8 +1682,6 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
     if backend == "dask":
         bin_counts = _dask_graph(all_arrays, has_weights, drop_axes, bins, bincount_kwargs)
     else:
-        if two:
-            bincount_kwargs["second_weights"] = True
         bin_counts = None
         if backend == "numpy":
             # host inputs big enough to be worth it are cut into shards, one per visible GPU: every shard is
