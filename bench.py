@@ -23,6 +23,13 @@ Also reported on the same JSON line:
                reference's golden vectors) timed on this box's host cores on a bounded sample:
                one thread, and a thread pool over sample chunks on every host core
                (os.cpu_count() and the CPU model are reported)
+  verified     every timed leg's LAST output is compared, in this process and at full size, with an independent
+               restatement in torch ops only (bucketize(right=True) + the last-edge rule + joint index + bincount:
+               core.py:170-173, 178-181, 81) — int64 counts identical, float64 sums within 1e-6 relative (north_star);
+               a mismatch is reported in the line AND ends the run with exit status 1
+  distributions  (default N = 1 run) the headline's two legs again on uniform[-4,4) samples, on samples that all fall
+               into ONE bin and on samples of which 90 % are out of range (the LDS-atomic contention legs)
+  first_call_ms  plan creation + module load + first launch of the headline kernel, cold
 """
 import argparse
 import json
@@ -69,6 +76,9 @@ def parse():
     ap.add_argument("--profiler-pass", action="store_true",
                     help="only the main leg's launches: no 8 B/sample leg riding along (c2), no cold burst (c4) — for rocprofv3 passes "
                          "that attribute counters and launch counts to ONE kernel")
+    ap.add_argument("--no-verify", action="store_true", help="skip the in-process torch cross-check of every leg's output (profiler passes)")
+    ap.add_argument("--distributions", action="store_true",
+                    help="c2: also time (and verify) the headline's legs on uniform, one-bin and 90 %%-out-of-range samples; on by default in the default N = 1 run")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     args = ap.parse_args()
     # a C4 shard step is one 0.3 ms kernel: the first tens of launches after an idle GPU run 5-8 % slower (0.309 ms over steps
@@ -145,6 +155,64 @@ def cpu_baseline(xs_host, w_host, edges, one_chunk=False):
         "sample": "%d of the same samples (%s), %d-sample chunks on a pool of %d threads (= os.cpu_count()), partial histograms summed, %.2f s"
         % (n, nin, chunk, threads, dt),
     }, **base)
+
+
+def torch_reference(torch, arrays, w, edges, n_rows, n_cols, weighted, chunk=1 << 27):
+    """The histogram of the first n_cols samples of every row, restated with torch ops ONLY — nothing of libxhist_amd.so and
+    nothing of oracle/ is involved: bucketize(right=True) is searchsorted(side="right") (core.py:170), samples equal to the
+    last edge move into the last bin (core.py:171-173), the joint index is the C-order ravel of the per-input bins
+    (core.py:178-181), bincount adds ones / float64 weights (core.py:81), under- and overflow are dropped (core.py:189-192).
+    Compares in float64 like numpy's promotion.  Returns [n_rows, prod(bins)] int64 / float64 on the inputs' device."""
+    dev = arrays[0].device
+    nb = [len(e) - 1 for e in edges]
+    n_bins = int(np.prod(nb))
+    et = [torch.as_tensor(np.asarray(e, dtype=np.float64), device=dev) for e in edges]
+    out = torch.zeros(n_rows * n_bins, dtype=torch.float64 if weighted else torch.int64, device=dev)
+    a2 = [a.reshape(n_rows, -1) for a in arrays]
+    w2 = w.reshape(n_rows, -1) if weighted else None
+    rows_per = max(1, chunk // max(1, n_cols))
+    cols_per = n_cols if rows_per > 1 else chunk
+    for r0 in range(0, n_rows, rows_per):
+        r1 = min(n_rows, r0 + rows_per)
+        for c0 in range(0, n_cols, cols_per):
+            c1 = min(n_cols, c0 + cols_per)
+            flat, ok = None, None
+            for d in range(len(a2)):
+                x = a2[d][r0:r1, c0:c1].to(torch.float64)
+                idx = torch.bucketize(x, et[d], right=True)
+                idx = torch.where(x == et[d][-1], idx - 1, idx)
+                ok_d = (idx >= 1) & (idx <= nb[d])
+                ok = ok_d if ok is None else ok & ok_d
+                flat = (idx - 1) if flat is None else flat * nb[d] + (idx - 1)
+                del x, idx, ok_d
+            if n_rows > 1:
+                flat = flat + (torch.arange(r0, r1, device=dev, dtype=torch.int64) * n_bins)[:, None]
+            sel = flat[ok]
+            if weighted:
+                out += torch.bincount(sel, weights=w2[r0:r1, c0:c1][ok].to(torch.float64), minlength=n_rows * n_bins)
+            else:
+                out += torch.bincount(sel, minlength=n_rows * n_bins)
+            del flat, ok, sel
+    return out.reshape(n_rows, n_bins)
+
+
+VERIFY_RTOL = 1e-6  # north_star: float64 weighted sums / density within 1e-6 relative; int64 counts bit-exact
+
+
+def compare_with_reference(torch, got, ref):
+    """{"ok", "kind", "max_rel", ...}: int64 counts must be identical; float64 sums within VERIFY_RTOL of the reference bin
+    by bin (bins the reference leaves empty must be exactly empty)"""
+    got = got.reshape(ref.shape)
+    if ref.dtype == torch.int64:
+        bad = int((got != ref).sum().item())
+        return {"ok": bad == 0, "kind": "int64 counts identical", "bins_different": bad, "total": int(ref.sum().item())}
+    diff = (got - ref).abs()
+    scale = ref.abs()
+    rel = torch.where(scale > 0, diff / scale.clamp_min(1e-300), torch.where(diff > 0, torch.full_like(diff, float("inf")), torch.zeros_like(diff)))
+    rel = torch.nan_to_num(rel, nan=float("inf"))
+    max_rel = float(rel.max().item())
+    return {"ok": bool(max_rel <= VERIFY_RTOL), "kind": "float64 sums within %g relative, bin by bin" % VERIFY_RTOL, "max_rel": max_rel,
+            "total": float(ref.sum().item())}
 
 
 def build_workload(cfg, args, torch, dev, rank):
@@ -237,7 +305,9 @@ def main():
     _native.require_device(local)
 
     wl = build_workload(args.config, args, torch, dev, rank)
+    t0 = time.perf_counter()
     plan = core._get_plan(wl["edges"], _native.CMP_F64, local)
+    plan.create_ms = round((time.perf_counter() - t0) * 1e3, 3)  # the first plan of the process: library load + context + edge tables
     for kv in args.tune:
         key, _, val = kv.partition("=")
         plan.set_param(key, int(val))
@@ -265,6 +335,18 @@ def main():
                 wl2 = build_workload(cfg, a, torch, dev, rank)
                 plan2 = core._get_plan(wl2["edges"], _native.CMP_F64, local)
                 out[cfg] = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+                if cfg == "c5":
+                    # the leg above moves float64 weights between its two passes as 48-bit records (36 mantissa bits, 2^-37
+                    # relative per weight; one sign only, decided on the GPU) — narrower than the reference's float64 adds
+                    # (core.py:81) though inside the 1e-6 contract.  The same call with FULL float64 records beside it:
+                    out[cfg]["records"] = "packed48 (float64 weights rounded to 36 mantissa bits between the two passes; exact_records = full float64)"
+                    plan2.set_param("records48", -1)
+                    try:
+                        a.steps, a.warmup = 10, 5
+                        ex = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+                        out[cfg]["exact_records"] = {k: ex[k] for k in ("steps", "warmup", "value", "ms_per_step", "kernel_ms_mean", "kernel_ms_min", "achieved_GBps", "frac", "kernel", "verified")}
+                    finally:
+                        plan2.set_param("records48", 0)
             except Exception as e:  # noqa: BLE001
                 out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             del wl2
@@ -283,6 +365,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     as_extra: this call IS one of those — return its summary instead of printing a line"""
     arrays, w, edges = wl["arrays"], wl["weights"], wl["edges"]
     weighted = w is not None
+    failed = [False]
     n_rows = wl["rows"]
     tag = {torch.float64: _native.F64, torch.float32: _native.F32}
     # two result buffers: the RCCL all-reduce of step k runs while step k+1's kernel streams
@@ -297,7 +380,29 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             dist.barrier()
         sync()
 
-    def run_leg(n_cols, steps, warmup, weighted=weighted, outs=outs, cold=0):
+    verify = not args.no_verify and not args.profiler_pass and not args.selftest
+
+    def check_leg(out, dens_out, n_cols, weighted):
+        """the leg's last output against torch_reference at full size (all-reduced like the output when the partials are)"""
+        t0 = time.perf_counter()
+        ref = torch_reference(torch, arrays, w if weighted else None, edges, n_rows, n_cols, weighted)
+        if reduce_partials:
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        v = compare_with_reference(torch, out, ref)
+        if density and dens_out is not None:  # core.py:444-462 restated: counts / bin areas / the row's in-range total
+            area = torch.as_tensor(np.diff(edges[0]), device=dev)
+            for e in edges[1:]:
+                area = (area[:, None] * torch.as_tensor(np.diff(e), device=dev)[None, :]).reshape(-1)
+            vd = compare_with_reference(torch, dens_out, ref.to(torch.float64) / area[None, :] / ref.sum(dim=1, keepdim=True))
+            v["density_ok"], v["density_max_rel"] = vd["ok"], vd["max_rel"]
+            v["ok"] = v["ok"] and vd["ok"]
+        del ref
+        sync()
+        v["reference"] = "torch.bucketize(right=True) + last-edge rule + joint index + torch.bincount over all %d samples, in this process" % (n_rows * n_cols)
+        v["seconds"] = round(time.perf_counter() - t0, 3)
+        return v
+
+    def run_leg(n_cols, steps, warmup, weighted=weighted, outs=outs, cold=0, time_first=False):
         """`warmup` untimed + `steps` timed passes over the first n_cols samples of every row of this rank's
         resident arrays; returns what the JSON line needs.  A step = output zeroing + histogram kernel(s)
         (+ all-reduce of the partial over RCCL, overlapped with the next step's kernel; + the density epilogue).
@@ -336,6 +441,12 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             fence()
 
         cold_ms = None
+        first_ms = None
+        if time_first:  # the very first launch of this plan in this process: module load + function attributes + the kernel
+            t0 = time.perf_counter()
+            step()
+            drain()
+            first_ms = (time.perf_counter() - t0) * 1e3
         if cold:
             step()  # (the very first launch of a plan pays module loading and function attributes: 8 ms, not a clock effect)
             drain()
@@ -371,9 +482,10 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             ks = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
             dist.all_gather(ks, torch.tensor([k_mean], dtype=torch.float64, device=dev))
             per_rank = [float(k.item()) for k in ks]
-        # sanity: the result of the last step is a real histogram (of all ranks' shards when reduced)
+        # the result of the last step must be the histogram of these samples: checked against torch ops at full size
         total = float(out.sum().item())
         assert total > 0
+        verdict = check_leg(out, dens[0], n_cols, weighted) if verify else None
         # the exchange on its own: `steps` all-reduces of the partial, nothing else on the GPU
         allreduce_ms = None
         if reduce_partials:
@@ -387,6 +499,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         n = n_rows * n_cols
         desc = plan.describe()
         return dict(desc=desc, dt=dt, n=n, kernel_ms=kernel_ms, kernel_ms_per_rank=per_rank, allreduce_ms=allreduce_ms, cold_ms=cold_ms,
+                    verified=verdict, first_ms=first_ms,
                     value=world * n * steps / dt, ms_per_step=dt / steps * 1e3, last=out, dens=dens[0], bytes_per_sample=bytes_per_sample)
 
     cols_weak = wl["cols"]
@@ -395,13 +508,33 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     main_leg = args.scaling
     # sub-millisecond kernels (the C4 shard): the first launches after an idle GPU are reported next to the steady rate
     cold = 20 if (args.config == "c4" and not args.full and not args.selftest and not args.profiler_pass) else 0
-    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold)
+    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold, time_first=not as_extra)
     # the headline's 8 B/sample variant — north_star's target sentence is the 1-D 10^9-sample f64 histogram WITHOUT weights
     # (BASELINE.md section 3 "headline unweighted variant") — rides along on the same samples: `"unweighted": {...}`
     unweighted_leg = None
     if args.config == "c2" and weighted and not args.profiler_pass:
         outs_u = [torch.zeros(out_shape, dtype=torch.int64, device=dev) for _ in range(2)]
         unweighted_leg = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, weighted=False, outs=outs_u)
+    # the bounded host sample of the CPU baseline is taken NOW: the distribution legs below overwrite the samples in place
+    host_sample = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest and not as_extra:
+        k = min(args.cpu_sample // max(1, len(arrays)), arrays[0].numel())
+        host_sample = ([a.reshape(-1)[:k].cpu().numpy() for a in arrays], w.reshape(-1)[:k].cpu().numpy() if weighted else None)
+    # SURVEY.md 8(d) / hard part #2: the headline again on three other sample distributions — uniform[-4,4) (every bin equally
+    # likely: the low-contention bound), ALL samples in one bin (every lane of every wavefront on one counter: the contention
+    # bound of core.py:81's sequential add turned into LDS atomics) and 90 % of the samples out of range (the drop path).
+    # Same buffers, samples overwritten in place; a few steps each; every leg verified like the main ones.
+    dist_legs = None
+    if args.config == "c2" and world == 1 and unweighted_leg is not None and (args.distributions or extra is not None) and not args.selftest:
+        dist_legs = {}
+        x = arrays[0]
+        fills = (("uniform[-4,4)", lambda: x.uniform_(-4.0, 4.0)), ("all_in_one_bin", lambda: x.fill_(0.5)),
+                 ("90pct_out_of_range", lambda: x.uniform_(-40.0, 40.0)))
+        torch.manual_seed(4321)
+        for name, fill in fills:
+            fill()
+            sync()
+            dist_legs[name] = (run_leg(cols_weak, 5, 3), run_leg(cols_weak, 5, 3, weighted=False, outs=outs_u))
     if world > 1:  # the other leg rides along (N = 1: the two legs are the same run)
         other = "strong" if main_leg == "weak" else "weak"
         legs[other] = run_leg(cols_weak if other == "weak" else cols_strong, args.steps, args.warmup)
@@ -438,6 +571,15 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"]:
             roof["traffic"] = entry["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/traffic.json: %s (code state %s)" % (entry.get("source", "?"), entry.get("code_state", "?"))
+            # the rocprofv3 --kernel-trace average of the same command (the first launches after the idle gap of data generation
+            # left out) next to the HIP-event mean of THAT profiled process: the tracer slows these kernels by a few
+            # percent, so profiles/ reproduces `frac` only through `profiled_slowdown`
+            if entry.get("rocprof_avg_us") is not None:
+                roof["rocprof_avg_us"] = entry["rocprof_avg_us"]
+                roof["rocprof_launches_skipped"] = entry.get("rocprof_launches_skipped")
+                roof["events_ms_under_rocprof"] = entry.get("events_ms_under_rocprof")
+                if entry.get("events_ms_under_rocprof"):
+                    roof["profiled_slowdown"] = entry["events_ms_under_rocprof"] / roof["kernel_ms_mean"]
         else:
             roof["traffic_source"] = None
 
@@ -460,7 +602,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             "higher_is_better": True,
             "scaling": main_leg,
             "vs_baseline": None,
-            "dtype": wl["dtype"],
+            "dtype": wl["dtype"] + (" (records: %s)" % ("packed48" if "packed48" in m["desc"] else "float64") if args.config == "c5" else ""),
             "data": wl["data"],
             "config": {
                 "workload": wl["workload"],
@@ -485,11 +627,14 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             roof["cold"] = {"launches": len(m["cold_ms"]), "after_idle_s": 0.5, "kernel_ms_mean": c_ms, "kernel_ms": [round(float(v), 4) for v in m["cold_ms"]],
                             "achieved": c_ach, "frac": c_ach / HBM_PEAK_GBS}
             roof["cold_frac"] = c_ach / HBM_PEAK_GBS
+        verified = {}
+        if m["verified"] is not None:
+            verified[args.config] = m["verified"]
         if as_extra:
             summary = {"workload": wl["workload"], "metric": wl["metric"], "dtype": wl["dtype"], "steps": args.steps, "warmup": args.warmup,
                        "value": m["value"], "unit": "samples/s", "ms_per_step": m["ms_per_step"], "kernel_ms_mean": roof["kernel_ms_mean"],
                        "kernel_ms_min": roof["kernel_ms_min"], "achieved_GBps": roof["achieved"], "frac": roof["frac"],
-                       "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "kernel": m["desc"]}
+                       "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "kernel": m["desc"], "verified": m["verified"]}
             if "cold_frac" in roof:
                 summary["cold_frac"] = roof["cold_frac"]
                 summary["cold_kernel_ms_mean"] = roof["cold"]["kernel_ms_mean"]
@@ -505,23 +650,58 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                                                 "kernel_launches_timed", "algorithmic_bytes_per_launch")},
                 "kernel": u.get("desc"),
             }
+            if u["verified"] is not None:
+                verified["c2_unweighted"] = u["verified"]
+        if dist_legs:
+            def short(leg):
+                r = roofline(leg)
+                return {"kernel_ms_mean": r["kernel_ms_mean"], "frac": r["frac"], "value": leg["value"], "kernel": leg["desc"],
+                        "verified": None if leg["verified"] is None else leg["verified"]["ok"]}
+
+            line["distributions"] = {"steps": 5, "warmup": 3,
+                                     "N(0,1) (the headline)": {"weighted": {"kernel_ms_mean": roof["kernel_ms_mean"], "frac": roof["frac"]},
+                                                              "unweighted": {"kernel_ms_mean": line["unweighted"]["kernel_ms_mean"],
+                                                                             "frac": line["unweighted"]["roofline"]["frac"]}}}
+            for name, (lw, lu) in dist_legs.items():
+                line["distributions"][name] = {"weighted": short(lw), "unweighted": short(lu)}
+                for tag_, leg in (("weighted", lw), ("unweighted", lu)):
+                    if leg["verified"] is not None:
+                        verified["c2 %s %s" % (name, tag_)] = leg["verified"]
+        if m["first_ms"] is not None:
+            # cold start of the headline call in this process: table building + plan (xhist_plan_create), then module load +
+            # function attributes + the first launch; the library is %d MB of code objects for ~1 350 kernel instantiations
+            line["first_call_ms"] = {"first_launch_ms": round(m["first_ms"], 3), "plan_create_ms": getattr(plan, "create_ms", None),
+                                     "so_bytes": os.path.getsize(_native.LIB_PATH) if hasattr(_native, "LIB_PATH") and os.path.exists(_native.LIB_PATH) else None}
         for name, leg in legs.items():
             if name != main_leg:
                 line[name] = leg_summary(leg)
+        for name, leg in legs.items():
+            if name != main_leg and leg["verified"] is not None:
+                verified["%s %s leg" % (args.config, name)] = leg["verified"]
         if extra is not None:
             t0 = time.perf_counter()
             line["configs"] = extra()
             line["configs"]["wall_s"] = round(time.perf_counter() - t0, 2)
-        if world == 1 and not args.no_cpu_baseline and not args.selftest:
-            nflat = arrays[0].numel()
-            k = min(args.cpu_sample // max(1, len(arrays)), nflat)
-            flat = [a.reshape(-1)[:k].cpu().numpy() for a in arrays]
-            line["cpu_baseline"] = cpu_baseline(flat, w.reshape(-1)[:k].cpu().numpy() if weighted else None, edges, one_chunk=args.config == "c1")
+            for cfg, summary in line["configs"].items():
+                if isinstance(summary, dict):
+                    if summary.get("verified") is not None:
+                        verified[cfg] = summary["verified"]
+                    ex = summary.get("exact_records")
+                    if isinstance(ex, dict) and ex.get("verified") is not None:
+                        verified[cfg + " exact records"] = ex["verified"]
+        if host_sample is not None:
+            line["cpu_baseline"] = cpu_baseline(host_sample[0], host_sample[1], edges, one_chunk=args.config == "c1")
+        if verified:
+            line["verified"] = dict(all_ok=all(v["ok"] for v in verified.values()), rtol_float64=VERIFY_RTOL, legs=verified)
+            failed[0] = not line["verified"]["all_ok"]
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed[0]:
+        print("bench.py: a leg's output did NOT match the torch reference — see \"verified\" in the line", file=sys.stderr)
+        raise SystemExit(1)
 
 
 def selftest(args, torch, dist, result_fd):

@@ -177,7 +177,8 @@ int xhist_comm_allreduce(xhist_comm* comm, void* buf, int64_t count, int dtype, 
 /* recv holds world_size * count elements, rank r's block at offset r * count */
 int xhist_comm_allgather(xhist_comm* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
 /* Deadlines: xhist_comm_create (the rendezvous) and xhist_comm_wait (the completion of collectives) do not wait for a
- * peer for ever: XHIST_AMD_COMM_TIMEOUT_S seconds (environment, default 60; <= 0: no deadline).  On expiry, or on an
+ * peer for ever: XHIST_AMD_COMM_TIMEOUT_S seconds (environment, default 300; <= 0: no deadline;
+ * XHIST_AMD_COMM_CREATE_TIMEOUT_S, when set, overrides it for the rendezvous alone).  On expiry, or on an
  * asynchronous RCCL error, the communicator is aborted (ncclCommAbort: kernels of a collective in flight return), the call
  * returns XHIST_ERR_COMM with a message naming rank, world size and what was waited for, and every later call on the
  * communicator returns XHIST_ERR_COMM at once; xhist_comm_destroy is still due.
@@ -221,10 +222,9 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "pack" (0 auto / 1 whenever the plan has them / -1 never: packed 16-byte bucket entries — one LDS read per sample and
  *       dimension — for float64 / float32 samples on non-uniform edges, on a linear or a float-bit-pattern (logarithmic) grid),
- *       "overlap" (sub-batches of one long row whose routing and adding-up passes run on two streams; 0 = 1 = off: measured
- *       slower, kept for A/B runs) with "overlap_cus", "route_grid", "acc_grid" (workgroups of the two passes; 0 auto),
+ *       "route_grid", "acc_grid" (workgroups of the routing / adding-up pass of the multi-pass mode; 0 auto),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
- *       "route_block" (0 auto / 512 / 1024 threads), "route_spl" (0 auto / 4 / 8 samples per lane and tile) and "min_parts"
+ *       "route_spl" (0 auto / 4: never the long 8-samples-per-lane tile) and "min_parts"
  *       (0 auto = 16 / 1 = as few as the histogram's size asks for / up to 128: partitions per row) shape the routing pass of
  *       the multi-pass mode; "route_pool_pct" (tests: its chunk pool cut to this percentage),
  *       "flat_rows" (0 auto / 1 for any row length below 65536 / -1 never: many dense short rows streamed as one array),

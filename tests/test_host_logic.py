@@ -342,3 +342,17 @@ def test_public_signatures_are_the_references():
     got = {"core.%s" % n: str(inspect.signature(getattr(core, n))) for n in ("histogram", "_bincount", "_bincount_2d_vectorized")}
     got["xarray.histogram"] = str(inspect.signature(xh_xarray.histogram))
     assert got == want
+
+
+def test_range_cut_follows_numpy_promotion_per_bound():
+    """float32 data meets a Python-float bound in float32 (weak scalar) but an np.float64 / np.int64 bound in
+    float64 — the number of elements numpy's `keep` mask leaves is the number inside core._range_cut's bounds"""
+    rng = np.random.default_rng(3)
+    a = np.clip(rng.uniform(0.0, 1.2, 1000), 0.7, 1.1).astype(np.float32)
+    for r in ((0.7, 1.0), (np.float64(0.7), 1.0), (np.float32(0.7), 1.0), (0.7, np.float64(1.0)), (np.int64(0), 1.1), (np.float16(0.7), np.float32(1.1))):
+        keep = int(((a >= r[0]) & (a <= r[1])).sum())  # numpy's own compare, promotion included
+        lo, hi = core._range_cut(r, np.dtype(np.float32))
+        assert int(((a.astype(np.float64) >= lo) & (a.astype(np.float64) <= hi)).sum()) == keep, r
+    assert core._range_cut((np.float64(0.7), 1.0), np.dtype(np.float32))[0] == 0.7
+    assert core._range_cut((0.7, 1.0), np.dtype(np.float32))[0] == float(np.float32(0.7))
+    assert core._range_cut((0.7, 1.0), np.dtype(np.float64)) == (0.7, 1.0)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle_np as onp
-from xhistogram_amd import core, multigpu
+from xhistogram_amd import _native, core, multigpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -491,9 +491,20 @@ def test_launcher_rank_is_clamped_to_the_visible_gpus_and_a_lone_task_owns_the_n
     monkeypatch.setenv("SLURM_LOCALID", "0")
     monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "1")
     assert multigpu.get_devices() == [0, 1, 2, 3]
-    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "4(x2)")  # Slurm's notation for "4 tasks on each of 2 nodes"
-    assert core.launcher_local_size() == 4 and multigpu.get_devices() == [0]
     monkeypatch.delenv("SLURM_NTASKS_PER_NODE")
+    monkeypatch.setenv("SLURM_TASKS_PER_NODE", "4(x2)")  # Slurm's notation for "4 tasks on each of 2 nodes"
+    monkeypatch.setenv("SLURM_NODEID", "1")
+    assert core.launcher_local_size() == 4 and multigpu.get_devices() == [0]
+    # the list names EVERY node — this node's entry is the one at $SLURM_NODEID, not the leading integer
+    for spec, node, want in (("1,4", "0", 1), ("1,4", "1", 4), ("1(x2),4", "2", 4), ("1(x2),4", "1", 1), ("2,1", "5", None)):
+        monkeypatch.setenv("SLURM_TASKS_PER_NODE", spec)
+        monkeypatch.setenv("SLURM_NODEID", node)
+        assert core.launcher_local_size() == want, (spec, node)
+    monkeypatch.delenv("SLURM_NODEID")
+    assert core.launcher_local_size() is None  # several nodes, no node id: says nothing
+    monkeypatch.setenv("SLURM_TASKS_PER_NODE", "4")
+    assert core.launcher_local_size() == 4  # one figure is unambiguous
+    monkeypatch.delenv("SLURM_TASKS_PER_NODE")
     monkeypatch.delenv("SLURM_LOCALID")
     monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "0")
     monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "1")
@@ -539,3 +550,42 @@ def test_device_containers_pickle_through_host_memory_or_fail_loudly():
     np.testing.assert_array_equal(args[0], arr_host)
     with pytest.raises(RuntimeError):
         fn(*args)
+
+
+def test_a_failed_exchange_drops_the_communicators_and_the_next_one_rebuilds_them(monkeypatch):
+    """after a deadline `xhist_comm_wait` aborts the communicator and every later call on it fails at once; the
+    DeviceGroup of a long-lived worker must therefore drop its communicators on a RuntimeError and build new ones for the next
+    exchange — one slow peer is one failed call, not a poisoned process.  Communicator doubles; no GPU."""
+    made, closed = [], []
+
+    class CommDouble:
+        def __init__(self, device, rank, world, uid):
+            self.device, self.rank, self.world_size, self.generation = device, rank, world, len(made) // 2
+            self.aborted = False
+            made.append(self)
+
+        def wait(self, stream=0):
+            if self.aborted:
+                raise RuntimeError("XHIST_ERR_COMM: communicator was aborted earlier")
+            if self.generation == 0 and self.rank == 1:
+                self.aborted = True
+                raise RuntimeError("XHIST_ERR_COMM: deadline passed with the collective still in flight")
+
+        def close(self):
+            closed.append(self)
+
+    monkeypatch.setattr(_native, "Comm", CommDouble)
+    monkeypatch.setattr(_native, "comm_unique_id", lambda: b"\0" * 128)
+    group = multigpu.DeviceGroup([5, 6])
+    try:
+        with pytest.raises(RuntimeError, match="deadline"):
+            group.exchange(lambda comm, rank, device, item: comm.wait(0), [None, None])
+        assert group._comms is None and len(closed) == 2  # dropped and closed, not cached
+        assert group.exchange(lambda comm, rank, device, item: (comm.wait(0), comm.generation)[1], [None, None]) == [1, 1]
+        assert len(made) == 4 and group._comms is not None  # the second exchange ran on new communicators
+        # errors that are not the communicator's (a bad argument inside the caller's function) keep the communicators
+        with pytest.raises(ValueError):
+            group.exchange(lambda comm, rank, device, item: (_ for _ in ()).throw(ValueError("caller bug")), [None, None])
+        assert group._comms is not None
+    finally:
+        group.close()

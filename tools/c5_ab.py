@@ -3,7 +3,7 @@ every variant is a set of xhist_plan_set_param overrides; per variant the HIP-ev
 routing pass + adding-up pass) over `--steps` launches after `--warmup`, and a checksum of the result against the first variant.
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split (kernel names carry the workgroup size).
 
-  python tools/c5_ab.py [--n 500000000] [--dist normal|uniform|const] [--variants "route_block=512;route_block=256"]
+  python tools/c5_ab.py [--n 500000000] [--dist normal|uniform|const] [--variants "default;route_spl=4;records48=-1"]
                         [--dtype f64|f32] [--dims 1|2|3] [--rows R] [--bins B] [--unweighted]
 """
 import argparse
@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--edges", default="linspace", choices=["linspace", "jitter", "random"],
                     help="jitter: uneven edges (table lookups); random: sorted uniform draws, end points kept (BASELINE C3)")
     ap.add_argument("--rows", type=int, default=1, help="n is split into this many rows (one histogram per row)")
-    ap.add_argument("--variants", default="route_block=1024;route_block=512;route_block=256")
+    ap.add_argument("--variants", default="default;records48=-1;default")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)

@@ -9,8 +9,11 @@ tag="$1"; shift
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 state="${XHIST_CODE_STATE:-snapshot}"
 export XHIST_CODE_STATE="$state"
+out="$R/gpurun_out/$tag"; mkdir -p "$out"
+# what a kernel that only READS reaches on this box, in this call (VERDICT r4 "next" #4): one / two 8 GB streams, 16-byte nt loads
+[ -x "$R/tools/ubench/readbw" ] && (cd /tmp && timeout 300 "$R/tools/ubench/readbw" quick > "$out/bare_read_ceiling.txt" 2>&1)
 bash "$R/tools/profile_configs.sh" "$tag" "$@"
-out="$R/gpurun_out/$tag"
+[ -x "$R/tools/ubench/readbw" ] && (cd /tmp && timeout 300 "$R/tools/ubench/readbw" quick >> "$out/bare_read_ceiling.txt" 2>&1)
 python "$R/tools/pmc_traffic.py" "$out" "$state" > "$out/traffic_summary.txt" 2>&1
 cp "$R/profiles/traffic.json" "$out/traffic.json"
 cd /tmp

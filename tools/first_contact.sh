@@ -15,7 +15,7 @@ out="$(realpath -m "${1:-$R/gpurun_out/first_contact}")"
 mkdir -p "$out"
 cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-export XHIST_AMD_COMM_TIMEOUT_S="${XHIST_AMD_COMM_TIMEOUT_S:-60}"
+export XHIST_AMD_COMM_TIMEOUT_S="${XHIST_AMD_COMM_TIMEOUT_S:-60}"  # (the library's own default is 300 s; day one wants its failures sooner)
 ngpu=$(python -c "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)" 2>/dev/null || echo 0)
 # FIRST_CONTACT_DRY=1 FIRST_CONTACT_NGPU=8: print the commands of an 8-GPU run without running anything (a syntax check of the
 # branches no one-GPU box reaches; profiles/r04_d_first_contact_dry_run_8_gpus.txt)
@@ -90,6 +90,15 @@ if rows:
         print("%d | %.4g | %s | %s | %s | %s | %s | %s | %.3f" % (
             n, w, "%.2f" % (w / w1) if w1 else "-", "%.4g" % st["value"] if st else "-", "%.2f" % (st["value"] / s1) if st and s1 else "-",
             "%.0f" % ov if ov is not None else "-", "%.0f" % st["overhead_us_per_step"] if st else "-", "%.4f" % ar if ar is not None else "-", fr))
+    # one SCALE-style JSON line per N (VERDICT r4 "next" #9): what the driver's SCALE_rNN.json computes from the per-N values
+    with open(os.path.join(out, "scale_lines.jsonl"), "w") as f:
+        for n, w, st, ov, ar, fr in rows:
+            rec = {"n_gpus": n, "weak_value": w, "weak_x": (w / w1) if w1 else None, "weak_efficiency": (w / w1 / n) if w1 else None,
+                   "strong_value": st["value"] if st else None, "strong_x": (st["value"] / s1) if st and s1 else None,
+                   "allreduce_ms_alone": ar, "overhead_us_per_step": ov, "strong_overhead_us_per_step": st["overhead_us_per_step"] if st else None,
+                   "roofline_frac_rank0": fr, "unit": "samples/s"}
+            f.write(json.dumps(rec) + "\n")
+            print(json.dumps(rec))
     print("target (BASELINE.json north_star): >= 6x at 8 GPUs; the strong leg's shard at N = 8 is a 0.30 ms kernel, so it affords <= 60-100 us of overhead per step")
 else:
     print("no bench line parsed: see 5_bench_*.log")

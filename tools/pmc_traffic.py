@@ -28,6 +28,23 @@ def counters(path):
     return out
 
 
+def steady_averages(path):
+    """{kernel name: (launches, skipped, avg_us)} from the '## xhist kernels after their first' section of a rocpd_summary text"""
+    out, on = {}, False
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        if line.startswith("## xhist kernels after their first"):
+            on = True
+            continue
+        if on and line.startswith("##"):
+            break
+        if on and "|" in line:
+            f = [x.strip() for x in line.split("|")]
+            out[f[0]] = (int(f[1]), int(f[2]), float(f[3]))
+    return out
+
+
 def hist_kernels(d):
     skip = ("zero_words", "build_tables", "minmax", "buffer_add")
     return {k: v for k, v in d.items() if "xhist::" in k and not any(s in k for s in skip)}
@@ -62,7 +79,21 @@ def main():
             per_kernel[re.sub(r"\(.*", "", k)[:80]] = {"fetch_KB_avg": f_kb, "write_KB_avg": w_kb, "launches_per_step": per_step, "hbm_bytes_per_step": b}
             total += b
         alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+        # rocprofv3 --kernel-trace averages of the same command, first launches left out: summed over the histogram kernels
+        # of a step (those the counters saw); and the HIP-event mean bench.py printed INSIDE that profiled process
+        steady = hist_kernels(steady_averages(os.path.join(src, "%s_kernel_stats.txt" % name)))
+        steady = {k: v for k, v in steady.items() if "build_pack_tables" not in k and "gather_rows" not in k}
+        rocprof_avg_us = sum(v[2] for v in steady.values()) if steady else None
+        skipped = max((v[1] for v in steady.values()), default=None)
+        try:
+            under = json.load(open(os.path.join(src, "%s_bench_under_rocprof.json" % name)))["roofline"]["kernel_ms_mean"]
+        except Exception:
+            under = None
         doc["configs"][name] = {
+            "rocprof_avg_us": rocprof_avg_us,
+            "rocprof_launches_skipped": skipped,
+            "rocprof_kernels": {re.sub(r"\(.*", "", k)[:80]: {"launches": v[0], "avg_us": v[2]} for k, v in steady.items()},
+            "events_ms_under_rocprof": under,
             "kernel": bench["config"]["kernel"],
             "samples_per_launch": bench["config"]["samples_per_gpu"],
             "hbm_bytes_per_launch": total,

@@ -8,6 +8,9 @@ import sqlite3
 import sys
 
 
+SKIP = 6  # launches left out of the steady-state averages
+
+
 def short(name, n=110):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     return name if len(name) <= n else name[: n - 3] + "..."
@@ -32,6 +35,19 @@ def main(path):
             print("## launches of the dominant kernel in dispatch order, us (%d): %s" % (len(series), " ".join("%.0f" % d for d in series[:64])))
         except sqlite3.Error:
             pass
+    # every xhist histogram kernel without its first launches: after the idle gap of data generation the first ~6 launches
+    # of a burst run up to 14 % slow (clock excursion), and a --stats average over warm-up + timed launches
+    # carries them; bench.py's HIP-event mean does not (10 untimed launches first)
+    if top:
+        print("## xhist kernels after their first %d launches (name | launches | skipped | avg_us | min_us | max_us)" % SKIP)
+        for r in top:
+            try:
+                series = [d for (d,) in cur.execute("select duration/1e3 from kernels where name = ? order by start", (r[0],))]
+            except sqlite3.Error:
+                continue
+            skip = SKIP if len(series) > 2 * SKIP else 0
+            rest = series[skip:]
+            print("%-112s | %5d | %3d | %10.2f | %10.2f | %10.2f" % (short(r[0]), len(series), skip, sum(rest) / len(rest), min(rest), max(rest)))
     k = list(cur.execute(
         "select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels where name like '%xhist::%' group by name, grid_x, workgroup_x"))
     if k:

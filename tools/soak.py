@@ -116,7 +116,7 @@ def one(seed):
     if rng.random() < 0.5:
         override = [("partition", 1), ("slices", 1), ("arith", 1), ("lanes", 1), ("lanes", -1), ("force_generic", 1), ("force_global", 1),
                     ("lds_copies", 1), ("slices", -1), ("arith", -1), ("fused", -1), ("partition", 1),
-                    ("partition", 1, "route_spl", 8), ("partition", 1, "route_spl", 4), ("partition", 1, "route_block", 512)][int(rng.integers(0, 15))]
+                    ("partition", 1, "route_spl", 8), ("partition", 1, "route_spl", 4), ("partition", 1, "route_spl", 4)][int(rng.integers(0, 15))]
         try:
             dom, cedges, _ = core._compare_domain([a.dtype for a in args], edges)
             plan = core._get_plan(cedges, dom, 0)

@@ -49,11 +49,24 @@ void run(const char* name, const double* a, const double* b, long n, double* out
          name, NARR, UNROLL, (int)NT, block, grid, ms[ms.size() / 2], 8.0 * NARR * n / ms[ms.size() / 2] / 1e6);
 }
 
-int main() {
+// `readbw quick`: the handful of geometries the evidence sets carry (tools/evidence_set.sh -> <tag>_bare_read_ceiling.txt):
+// what a kernel that ONLY reads one / two 8 GB streams reaches on the box — and in the very gpurun call — the bench lines
+// of the set were measured on, so that `roofline.frac` can be read against the chip's own read ceiling, not a quoted one.
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && argv[1][0] == 'q';
   const long n = 1000000000L;
   double *a, *b, *out;
   CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&out, 8));
   CK(hipMemset(a, 0x11, n * 8)); CK(hipMemset(b, 0x22, n * 8));
+  if (quick) {
+    for (int rep = 0; rep < 2; ++rep)
+      for (int block : {256, 512})
+        for (int grid : {1024, 2048}) {
+          run<8, true, 1>("one_array", a, b, n, out, block, grid);
+          run<4, true, 2>("two_arrays", a, b, n, out, block, grid);
+        }
+    return 0;
+  }
   for (int block : {256, 512, 1024})
     for (int grid : {256, 512, 1024, 2048, 4096}) {
       run<4, true, 2>("two_arrays", a, b, n, out, block, grid);

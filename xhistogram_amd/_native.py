@@ -362,7 +362,7 @@ def comm_unique_id():
 class Comm:
     """One RCCL communicator bound to one GPU (xhist_comm): the exchange step of sharded inputs for
     hosts without torch.distributed.  ``Comm(device, rank, world_size, unique_id)`` is collective —
-    it returns once every rank has joined, or raises after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 60) when one never does.  Buffers are device pointers; calls are asynchronous on
+    it returns once every rank has joined, or raises after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 300; ``$XHIST_AMD_COMM_CREATE_TIMEOUT_S`` for this rendezvous alone) when one never does.  Buffers are device pointers; calls are asynchronous on
     ``stream`` and must be issued in the same order on every rank."""
 
     def __init__(self, device, rank, world_size, unique_id):
@@ -387,7 +387,8 @@ class Comm:
     def wait(self, stream=0):
         """block until everything enqueued on ``stream`` has completed — the host-side end of an exchange.  Unlike a bare
         stream synchronisation it watches the communicator: a peer that never entered the collective, or died in it, ends
-        in a RuntimeError after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 60) and an aborted communicator, not in a hang"""
+        in a RuntimeError after ``$XHIST_AMD_COMM_TIMEOUT_S`` seconds (default 300) and an aborted communicator, not in a hang.  An aborted communicator fails every later
+        call at once: its owner drops it and creates a new one (multigpu.DeviceGroup.exchange does)"""
         check(load().xhist_comm_wait(self._h, C.c_void_p(stream)))
 
     def close(self):

@@ -17,7 +17,7 @@
 //     non-blocking mode does not do this job here: with config.blocking = 0 the init call of RCCL 2.27.7 (ROCm 7.2) itself
 //     never returns while a peer is missing (tools/ubench/rccl_lonely.cpp, profiles/r04_c_rccl_lonely_rank.txt);
 //   the completion of a collective (xhist_comm_wait) — polls the stream and ncclCommGetAsyncError against the deadline.
-// The deadline is $XHIST_AMD_COMM_TIMEOUT_S seconds (default 60; <= 0 = wait for ever).  On expiry, or on an asynchronous
+// The deadline is $XHIST_AMD_COMM_TIMEOUT_S seconds (default 300; <= 0 = wait for ever; XHIST_AMD_COMM_CREATE_TIMEOUT_S overrides it for the rendezvous alone).  On expiry, or on an asynchronous
 // RCCL error, the communicator is torn down with ncclCommAbort (kernels of a collective in flight return), the call reports
 // XHIST_ERR_COMM with what it was waiting for, and every later call on that communicator fails at once with the same code.
 #pragma once
@@ -100,10 +100,14 @@ struct xhist_comm {
   std::mutex mu;            // one call at a time per communicator (RCCL's own rule for one communicator)
 };
 
-static double comm_timeout_s() {
-  const char* e = getenv("XHIST_AMD_COMM_TIMEOUT_S");  // read at every call: a test, or a host that knows better, may change it
+// Default 300 s (torch.distributed waits 600): long-lived workers whose peers start tens of seconds apart must not
+// lose their communicator to the deadline; a host that wants a failure sooner sets the variable.
+// XHIST_AMD_COMM_CREATE_TIMEOUT_S, when set, applies to the rendezvous of xhist_comm_create alone.
+static double comm_timeout_s(bool create = false) {
+  const char* e = create ? getenv("XHIST_AMD_COMM_CREATE_TIMEOUT_S") : nullptr;  // read at every call: a test, or a host that knows better, may change it
+  if (!e || !*e) e = getenv("XHIST_AMD_COMM_TIMEOUT_S");
   if (e && *e) return atof(e);
-  return 60.0;
+  return 300.0;
 }
 
 typedef std::chrono::steady_clock comm_clock;
@@ -202,7 +206,7 @@ extern "C" int xhist_comm_create(int device, int rank, int world_size, const voi
     job->done = true;
     job->cv.notify_all();
   }).detach();
-  const double limit = comm_timeout_s();
+  const double limit = comm_timeout_s(true);
   bool expired = false;
   {
     std::unique_lock<std::mutex> lk(job->mu);

@@ -150,14 +150,14 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
 
   if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
     if (int rrc = rec.begin(profile)) return release(rrc);
-  hipLaunchKernelGGL(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
+  XH_LAUNCH_PICKED(k_count, dim3(G), dim3(kPartBlock), lds_count, stream, kp, d_flat);
   HIPR(hipGetLastError());
   hipLaunchKernelGGL(part_prefix, dim3(1), dim3(1024), 0, stream, (const uint32_t*)d_counts, G, n_parts, grp, d_offsets, d_base);
   HIPR(hipGetLastError());
-  hipLaunchKernelGGL(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
+  XH_LAUNCH_PICKED(k_scatter, dim3(G), dim3(kPartBlock), lds_scatter, stream, (const uint32_t*)d_flat,
                      weighted ? weights->data : nullptr, n_cols, (const uint64_t*)d_base, d_codes, d_w, shift, n_parts);
   HIPR(hipGetLastError());
-  hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const void*)d_w,
+  XH_LAUNCH_PICKED(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, (const uint16_t*)d_codes, (const void*)d_w,
                      (const uint64_t*)d_offsets, out, p->n_bins, shift, n_parts);
   HIPR(hipGetLastError());
   {
@@ -184,19 +184,13 @@ static bool exact_records_env() {
 }
 
 static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool multi, int block, int spl = 4) {
-  if (spl == 8) {
-    if (block != 1024) return nullptr;
-    return sdt == XHIST_F64 ? xhist_pick_route_f64_b1024s8(wdt, D, scan, multi) : sdt == XHIST_F32 ? xhist_pick_route_f32_b1024s8(wdt, D, scan, multi) : nullptr;
-  }
+  if (block != 1024) return nullptr;
+  if (spl == 8) return sdt == XHIST_F64 ? xhist_pick_route_f64_b1024s8(wdt, D, scan, multi) : sdt == XHIST_F32 ? xhist_pick_route_f32_b1024s8(wdt, D, scan, multi) : nullptr;
   if (spl != 4) return nullptr;
-  if (sdt == XHIST_F64)
-    return block == 1024 ? xhist_pick_route_f64_b1024(wdt, D, scan, multi) : block == 512 ? xhist_pick_route_f64_b512(wdt, D, scan, multi) : nullptr;
-  if (sdt == XHIST_F32)
-    return block == 1024 ? xhist_pick_route_f32_b1024(wdt, D, scan, multi) : block == 512 ? xhist_pick_route_f32_b512(wdt, D, scan, multi) : nullptr;
-  return nullptr;
+  return sdt == XHIST_F64 ? xhist_pick_route_f64_b1024(wdt, D, scan, multi) : sdt == XHIST_F32 ? xhist_pick_route_f32_b1024(wdt, D, scan, multi) : nullptr;
 }
 
-// Geometry of the routing pass: workgroup size and samples per lane and tile ("route_block" / "route_spl" override).
+// Geometry of the routing pass: 1024-thread workgroups, 4 or 8 samples per lane and tile ("route_spl" override).
 // Long tiles — 1024 threads x 8 samples, 64 KB read per input and tile — are what the mixed read/write traffic of the pass
 // wants (tools/ubench/mixbw `mb`: 24 B read : 8 B written per sample runs at 4.8-5.6 TB/s with 32 KB bursts per workgroup and
 // at 5.7-6.0 with 64 KB and more), as long as the tile's samples and weights fit the 128 registers a lane of a 1024-thread
@@ -215,17 +209,17 @@ static kernel_fn_route route_kernel(int sdt, int wdt, int D, int scan, bool mult
 // 1024 by 2-3 % on C5 while the pass loaded its weights with the samples (3.43-3.48 -> 3.35-3.37 ms,
 // profiles/r03_c5_blocks.txt); with the weights loaded a tile later and the arithmetic digitize they lose everywhere
 // (C5 3.94 | 4.11, uniform 3.93 | 4.12, 10^6 bins 3.28 | 3.32, 8 rows x 512 x 512 bins 3.82 | 3.89; exact float64 records
-// 4.21 | 4.32) and stay behind "route_block" = 512 for A/B runs only.
+// 4.21 | 4.32): the 512-thread instantiations were removed in round 5.
 struct RouteGeom {
   int block, spl;
 };
 // Table lookups (edges that are not arithmetic) take more registers than the arithmetic digitize: 24 there.
 static RouteGeom route_geom_for(const xhist_plan* p, int sdt, int wdt /* -1: counts */, int D, int scan) {
   RouteGeom g;
-  g.block = p->route_block ? p->route_block : 1024;
-  const int bytes = D * (sdt == XHIST_F64 ? 8 : 4) + (wdt == XHIST_F64 ? 8 : wdt == XHIST_F32 ? 4 : 0);
-  g.spl = p->route_spl ? p->route_spl : (g.block == 1024 && 2 * bytes <= (scan == kScanArith ? 32 : 24) && !(sdt == XHIST_F64 && wdt == XHIST_F64) ? 8 : 4);
-  if (g.block != 1024) g.spl = 4;
+  g.block = 1024;
+  // (route_long_tile_ok, xhist_pick.hip.h: the same rule decides which long-tile kernels exist; a forced 8 without one falls to 4)
+  const bool long_ok = route_long_tile_ok(sdt == XHIST_F64 ? 8 : 4, wdt == XHIST_F64 ? 8 : wdt == XHIST_F32 ? 4 : 0, D, scan == kScanArith);
+  g.spl = p->route_spl == 4 ? 4 : (long_ok ? 8 : 4);
   return g;
 }
 
@@ -273,35 +267,23 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const size_t hist_bytes = (size_t)((1u << shift) + 1) * (weighted ? 8 : 4);
   const size_t lds_acc = ((hist_bytes + 15) & ~(size_t)15) + (size_t)kAccBatch * 8 + (size_t)(n_parts + 1) * 4 + 16;
   if (lds_route > p->lds_max || lds_acc > p->lds_max) return XHIST_ERR_UNSUPPORTED;
-  // ---- sub-batches (VERDICT r3 "next" #1): the samples of ONE long row are cut into B pieces; the routing pass of piece
-  // k + 1 runs on the caller's stream while the adding-up pass of piece k runs on a stream of the plan's own, on the compute
-  // units the routing pass's grid leaves free (the two cannot share a CU: 93-142 KB + 136 KB of LDS).  Two record pools,
-  // used in turn.  Measured: DESIGN 4.2 / profiles/r04_b_*.
-  int n_batches = 1, cus_acc = 0, route_grid = 0, acc_grid = 0;
+  // (Round 4 also ran the adding-up pass of sample sub-batch k on a second stream under the routing pass of sub-batch k + 1:
+  // 25-60 % slower, both passes scale with the compute units they get — DESIGN_HISTORY 4.2b, profiles/r04_b_*; removed in
+  // round 5.)
+  int route_grid = 0, acc_grid = 0;
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    n_batches = p->overlap;
-    cus_acc = p->overlap_cus;
     route_grid = p->route_grid;
     acc_grid = p->acc_grid;
   }
-  if (n_batches == 0) n_batches = 1;  // auto: off (see the measurements)
-  if (rows != 1 || n_cols < (int64_t)n_batches * 16 * tile * p->cus) n_batches = 1;
-  const bool overlapped = n_batches > 1;
-  if (overlapped && cus_acc == 0) cus_acc = 48;
-  // columns per piece: whole tiles, so that every piece starts as aligned as the row does
-  const int64_t cols_piece = overlapped ? (((n_cols + n_batches - 1) / n_batches + tile - 1) / tile) * tile : n_cols;
-  if (overlapped) n_batches = (int)((n_cols + cols_piece - 1) / cols_piece);
-  // (a last piece of less than a tile goes with the one before it: pools are sized for a tile more)
-  const int64_t n_piece = (cols_piece + (overlapped ? tile : 0)) * rows;  // most samples one routing pass sees
-  const int64_t n_tiles = ((cols_piece + tile - 1) / tile) * rows;
+  const int64_t n_piece = n_total;  // samples one routing pass sees
+  const int64_t n_tiles = ((n_cols + tile - 1) / tile) * rows;
   // workgroups resident per CU: by LDS — and by registers: the routing pass is held to 128 per lane (waves_per_eu 4), so a
   // CU holds 1024 of its threads.  (Sized by LDS alone, a 77 KB workgroup of 1024 threads got a grid of 2 per CU, ran it
   // in two rounds, and 10^7 float64 pairs + weights into 512 x 512 bins took 0.233 ms against 0.170 for the three-pass route.)
   const int per_cu = std::max<int>(1, std::min<int>(std::min<int>(4, 1024 / block), (int)((size_t)160 * 1024 / lds_route)));
-  const int cus_route = overlapped ? std::max(1, p->cus - cus_acc) : p->cus;
-  int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus_route * per_cu, n_tiles));
-  int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(overlapped ? cus_acc : p->cus, (n_piece + 65535) / 65536));
+  int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
+  int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_piece + 65535) / 65536));
   if (route_grid) G = (int)std::min<int64_t>(route_grid, n_tiles);
   if (acc_grid) Gb = acc_grid;
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
@@ -320,7 +302,6 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   if (p->route_pool_pct > 0 && p->route_pool_pct < 100) pool_chunks = std::max<int64_t>(1, pool_chunks * p->route_pool_pct / 100);
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
 
-  const int n_sets = overlapped ? 2 : 1;  // record pools (and their counters, lists, fills), used in turn by the pieces
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
   uint16_t* d_codes = nullptr;
   void* d_w = nullptr;
@@ -337,28 +318,14 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     hipError_t e_ = (expr);                                                                            \
     if (e_ != hipSuccess) return release(fail(XHIST_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
   } while (0)
-  const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [1] signs seen, [2 .. 2 + P) chunks filed per partition; two sets
+  const int64_t ctr_words = (2 + n_parts + 1) / 2 + 1;  // [0] pool, [1] signs seen, [2 .. 2 + P) chunks filed per partition; two sets (packed + exact)
   const size_t rec_bytes = rec_f32 ? 4 : 8;
   const size_t plist_elems = (size_t)n_parts * pool_chunks, pool_recs = ((size_t)pool_chunks << lg);
-  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8 * 2 * n_sets, stream));
-  HIPR(scratch_malloc((void**)&d_plist, plist_elems * 4 * n_sets, stream));
-  HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4 * n_sets, stream));
-  HIPR(scratch_malloc((void**)&d_codes, pool_recs * 2 * n_sets, stream));
-  if (weighted) HIPR(scratch_malloc(&d_w, pool_recs * rec_bytes * n_sets, stream));
-
-  // the plan's own stream and events (overlapped form only); one overlapped enqueue at a time per plan
-  std::unique_lock<std::mutex> side_lock(p->side_mu, std::defer_lock);
-  hipStream_t side = stream;
-  if (overlapped) {
-    side_lock.lock();
-    if (!p->side_stream) HIPR(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
-    while (p->side_events.size() < (size_t)2 * n_batches) {
-      hipEvent_t e = nullptr;
-      HIPR(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      p->side_events.push_back(e);
-    }
-    side = p->side_stream;
-  }
+  HIPR(scratch_malloc((void**)&d_ctr, (size_t)ctr_words * 8 * 2, stream));
+  HIPR(scratch_malloc((void**)&d_plist, plist_elems * 4, stream));
+  HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
+  HIPR(scratch_malloc((void**)&d_codes, pool_recs * 2, stream));
+  if (weighted) HIPR(scratch_malloc(&d_w, pool_recs * rec_bytes, stream));
 
   if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
   kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
@@ -374,25 +341,18 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   if (first)  // one timing record per execute: opened before the first row's kernels, closed after the last row's
     if (int rrc = rec.begin(profile)) return release(rrc);
   const DimTable* dims = tset.dim;
-  for (int k = 0; k < n_batches; ++k) {
-    const int set = k % n_sets;
-    const int64_t c0 = (int64_t)k * cols_piece;
-    int64_t nc = std::min<int64_t>(cols_piece, n_cols - c0);
-    if (n_cols - (c0 + nc) < tile) {  // what is left after this piece is less than a tile: it goes with this one
-      nc = n_cols - c0;
-      n_batches = k + 1;
-    }
+  {
     Params kp;
     memset(&kp, 0, sizeof kp);
     for (int d = 0; d < D; ++d) {
-      kp.s_ptr[d] = advance(samples[d].data, samples[d].dtype, c0);
+      kp.s_ptr[d] = samples[d].data;
       kp.s_rs[d] = samples[d].row_stride;
       kp.s_cs[d] = 1;
       kp.s_dt[d] = samples[d].dtype;
       kp.dim[d] = dims[d];
     }
     if (weighted) {
-      kp.w_ptr = advance(weights->data, weights->dtype, c0);
+      kp.w_ptr = weights->data;
       kp.w_rs = weights->row_stride;
       kp.w_cs = 1;
       kp.w_dt = weights->dtype;
@@ -402,22 +362,22 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     kp.table_words = table_words;
     kp.tables_in_lds = 1;
     kp.n_rows = rows;
-    kp.n_cols = nc;
+    kp.n_cols = n_cols;
     kp.n_bins = p->n_bins;
     kp.out = out;
     kp.part_shift = shift;
     kp.n_parts = n_parts;
     kp.parts_per_row = parts_per_row;
-    const int Gk = (int)std::max<int64_t>(1, std::min<int64_t>(G, ((nc + tile - 1) / tile) * rows));
+    const int Gk = G;
     kp.segs = Gk;
-    uint32_t* ctr = d_ctr + (size_t)set * ctr_words * 4;  // (two counter sets of ctr_words 8-byte words each)
+    uint32_t* ctr = d_ctr;  // (two counter sets of ctr_words 8-byte words each)
     RouteArgs ra;
     ra.pool = ctr;
     ra.pcount = ctr + 2;
-    ra.plist = d_plist + (size_t)set * plist_elems;
-    ra.cmeta = d_cmeta + (size_t)set * pool_chunks;
-    ra.codes = d_codes + (size_t)set * pool_recs;
-    ra.wrec = weighted ? static_cast<char*>(d_w) + (size_t)set * pool_recs * rec_bytes : nullptr;
+    ra.plist = d_plist;
+    ra.cmeta = d_cmeta;
+    ra.codes = d_codes;
+    ra.wrec = weighted ? d_w : nullptr;
     ra.list_cap = (uint32_t)pool_chunks;
     ra.chunk_log2 = lg;
     ra.flags = ctr + 1;
@@ -426,12 +386,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     ra.gate_mode = 0;
     ra.dry = p->mixed_hint ? p->mixed_hint + 1 : nullptr;
 
-    // this piece's pool was last read by the adding-up pass of piece k - 2
-    if (overlapped && k >= 2) HIPR(hipStreamWaitEvent(stream, p->side_events[(size_t)2 * (k - 2) + 1], 0));
     if (int zrc = zero_output(ctr, ctr_words * 2, stream)) return release(zrc);
     RouteArgs ra48 = ra;
     if (pack) {
-      hipLaunchKernelGGL(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
+      XH_LAUNCH_PICKED(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
       HIPR(hipGetLastError());
       ra48.gate = ctr + 1;
       ra48.gate_mode = 1;  // one sign: add the packed records up
@@ -443,30 +401,23 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       ra.gate_mode = 2;
       ra.hint = p->mixed_hint;
     }
-    hipLaunchKernelGGL(k_route, dim3(Gk), dim3(block), lds_route, stream, kp, ra);
+    XH_LAUNCH_PICKED(k_route, dim3(Gk), dim3(block), lds_route, stream, kp, ra);
     HIPR(hipGetLastError());
-    if (overlapped) {
-      HIPR(hipEventRecord(p->side_events[(size_t)2 * k], stream));
-      HIPR(hipStreamWaitEvent(side, p->side_events[(size_t)2 * k], 0));
-    }
     if (pack) {
-      hipLaunchKernelGGL(k_acc48, dim3(Gb), dim3(1024), lds_acc, side, ra48, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
+      XH_LAUNCH_PICKED(k_acc48, dim3(Gb), dim3(1024), lds_acc, stream, ra48, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
       HIPR(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_acc, dim3(Gb), dim3(1024), lds_acc, side, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
+    XH_LAUNCH_PICKED(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
     HIPR(hipGetLastError());
-    if (overlapped) HIPR(hipEventRecord(p->side_events[(size_t)2 * k + 1], side));
   }
-  if (overlapped) HIPR(hipStreamWaitEvent(stream, p->side_events[(size_t)2 * (n_batches - 1) + 1], 0));  // join: the stream is in order
   {
     char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s pieces=%d%s",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
-             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64", n_batches,
-             overlapped ? " (adding-up pass of piece k on a second stream, under the routing pass of piece k + 1)" : "");
+             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }
@@ -612,7 +563,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       LaunchRecord rec(p, stream);
       if (int rrc = rec.begin(profile)) return rrc;
       if (lds_flat > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flat));
-      hipLaunchKernelGGL(ff, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_flat, stream, kp, (int32_t)direct, (int32_t)R, (int32_t)flat_k_log2,
+      XH_LAUNCH_PICKED(ff, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_flat, stream, kp, (int32_t)direct, (int32_t)R, (int32_t)flat_k_log2,
                          magic, (int64_t)(n_rows * n_cols));
       HIPC(hipGetLastError());
       char desc[320];
@@ -657,7 +608,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
       LaunchRecord rec(p, stream);
       if (int rrc = rec.begin(profile)) return rrc;
       if (lds_f > 48 * 1024) HIPC(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-      hipLaunchKernelGGL(f1, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_f, stream, kp, (int32_t)direct);
+      XH_LAUNCH_PICKED(f1, dim3((unsigned)row_blocks), dim3(kLaneBlock), lds_f, stream, kp, (int32_t)direct);
       HIPC(hipGetLastError());
       char desc[384];
       snprintf(desc, sizeof desc,
@@ -784,7 +735,7 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     if (int zrc = zero_output(out, n_rows * p->n_bins, stream)) return release(zrc);
   if (row_blocks > 2147483647LL) return release(XHIST_ERR_UNSUPPORTED);
   if (lds_use > 48 * 1024) HIPL(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use));
-  hipLaunchKernelGGL(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_use, stream, kp, (int32_t)direct,
+  XH_LAUNCH_PICKED(fn, dim3((unsigned)row_blocks, (unsigned)col_segs), dim3(kLaneBlock), lds_use, stream, kp, (int32_t)direct,
                      cols_per_seg);
   HIPL(hipGetLastError());
   {
@@ -1501,7 +1452,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       for (int sl = 0; sl < n_slices; ++sl) {  // (one launch unless the histogram is built in bin slices)
         kp.slice_lo = (int64_t)sl * slice_bins;
         kp.slice_n = (int32_t)std::min<int64_t>(slice_bins, p->n_bins - kp.slice_lo);
-        hipLaunchKernelGGL(fn, grid, dim3(block), lds_bytes, stream, kp);
+        XH_LAUNCH_PICKED(fn, grid, dim3(block), lds_bytes, stream, kp);
         HIPC(hipGetLastError());
       }
       if (first_launch) {

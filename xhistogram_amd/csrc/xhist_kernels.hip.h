@@ -1030,7 +1030,6 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     }
   }
 
-#ifndef XHIST_WHATIF_NO_PACKED_FLUSH  // (development what-if: how long does the flush of 256 x 65536 counters take? WRONG results)
   if (HIST == kHistPacked) {
     __syncthreads();
     const uint32_t n = (hb + 1u) >> 1;
@@ -1042,7 +1041,6 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
         atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * (int64_t)i + 1, (unsigned long long)hi);
     }
   }
-#endif
 
   if (LDS_HIST) {
     __syncthreads();

@@ -53,12 +53,7 @@ static kernel_fn fast_pick(int hist) {
   }
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
-#ifdef XHIST_PACKED_UNROLL  // development A/B only (XHIST_BUILD_FLAGS=-DXHIST_PACKED_UNROLL=2): samples per lane and tile of the packed-counter kernels
-    constexpr int UP = XHIST_PACKED_UNROLL;
-#else
-    constexpr int UP = U;
-#endif
-    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, UP, kHistPacked, SCAN>;
+    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
     else return nullptr;
   }
   return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
@@ -99,12 +94,7 @@ static kernel_fn fast_pick_pack(int hist) {
     }
     if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
     if (hist == kHistPacked) {
-#ifdef XHIST_PACKED_UNROLL  // development A/B only, see fast_pick
-      constexpr int UP = XHIST_PACKED_UNROLL;
-#else
-      constexpr int UP = U;
-#endif
-      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, UP, kHistPacked, SCAN>;
+      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
     }
   }
   return nullptr;
@@ -209,6 +199,25 @@ static kernel_fn mixed_pick_ds(int D, int scan) {
 // arithmetic edges; up to three inputs; any of the three weight kinds
 constexpr int kWdtPacked48 = 0x100 | XHIST_F64;  // float64 weights, packed 8-byte records (xhist_route.hip.h)
 
+// Long tiles (8 samples per lane) exist only where route_geom_for (xhist_exec_device.hip.h) can pick them: the tile's samples
+// and weights — 2 x (bytes of one sample of every input + bytes of its weight) registers — fit next to the sort's state
+// (32 registers with the arithmetic digitize, 24 with table lookups), and never float64 samples with float64 weights.
+// ONE rule for the host's choice and for what is instantiated: 504 routing kernels became 239 in round 5 (the 512-thread
+// variants, reachable only through an A/B override and slower everywhere since round 3, went as well).
+constexpr bool route_long_tile_ok(int sample_bytes, int weight_bytes, int D, bool arith) {
+  return 2 * (D * sample_bytes + weight_bytes) <= (arith ? 32 : 24) && !(sample_bytes == 8 && weight_bytes == 8);
+}
+template <typename ST, typename WT, int D, int SCAN, int SPL>
+constexpr bool route_variant_exists() {
+  constexpr int wb = std::is_same<WT, NoWeight>::value ? 0 : std::is_same<WT, float>::value ? 4 : 8;
+  return SPL == 4 || route_long_tile_ok((int)sizeof(ST), wb, D, SCAN == kScanArith);
+}
+template <typename ST, typename WT, int D, int SCAN, bool MULTI, int BLOCK, int SPL>
+static kernel_fn_route route_variant() {
+  if constexpr (route_variant_exists<ST, WT, D, SCAN, SPL>()) return (kernel_fn_route)part_route<ST, WT, D, SCAN, MULTI, BLOCK, SPL>;
+  else return nullptr;
+}
+
 // (several rows per pass: uniform-style edges only — tables with one edge per bucket, or arithmetic — the shapes a census over
 // time steps has; other edges run one row per pass)
 template <typename ST, typename WT, int BLOCK, int SPL = 4>
@@ -216,15 +225,15 @@ static kernel_fn_route route_pick_ds(int D, int scan, bool multi) {
 #define XH_ROUTE_CASE(DD)                                                        \
   case DD:                                                                       \
     if (multi) {                                                                 \
-      if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, true, BLOCK, SPL>;    \
-      if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, true, BLOCK, SPL>; \
+      if (scan == 1) return route_variant<ST, WT, DD, 1, true, BLOCK, SPL>();    \
+      if (scan == kScanArith) return route_variant<ST, WT, DD, kScanArith, true, BLOCK, SPL>(); \
       return nullptr;                                                            \
     }                                                                            \
-    if (scan == 0) return (kernel_fn_route)part_route<ST, WT, DD, 0, false, BLOCK, SPL>;            \
-    if (scan == 1) return (kernel_fn_route)part_route<ST, WT, DD, 1, false, BLOCK, SPL>;            \
-    if (scan == 2) return (kernel_fn_route)part_route<ST, WT, DD, 2, false, BLOCK, SPL>;            \
-    if (scan == kScanArith) return (kernel_fn_route)part_route<ST, WT, DD, kScanArith, false, BLOCK, SPL>; \
-    if (scan == kScanPackG) return (kernel_fn_route)part_route<ST, WT, DD, kScanPackG, false, BLOCK, SPL>; \
+    if (scan == 0) return route_variant<ST, WT, DD, 0, false, BLOCK, SPL>();            \
+    if (scan == 1) return route_variant<ST, WT, DD, 1, false, BLOCK, SPL>();            \
+    if (scan == 2) return route_variant<ST, WT, DD, 2, false, BLOCK, SPL>();            \
+    if (scan == kScanArith) return route_variant<ST, WT, DD, kScanArith, false, BLOCK, SPL>(); \
+    if (scan == kScanPackG) return route_variant<ST, WT, DD, kScanPackG, false, BLOCK, SPL>(); \
     return nullptr;
   switch (D) {
     XH_ROUTE_CASE(1)
@@ -256,8 +265,8 @@ kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist);
 kernel_fn xhist_pick_mixed(bool weighted, int D, int scan);  // (xhist_pick_mixed.hip)
 typedef void (*kernel_fn_flat)(const Params, int32_t, int32_t, int32_t, uint64_t, int64_t);
 kernel_fn_flat xhist_pick_flat_rows(int sdt, int wdt, int D, int scan);  // hist_flat_rows (xhist_pick_flat.hip); nullptr: no such variant
-// (xhist_route_{f64,f32}_b{1024,512}.hip: one translation unit per sample type and workgroup size)
+// (xhist_route_{f64,f32}_b1024{,s8}.hip: one translation unit per sample type and tile length)
 #define XH_ROUTE_TU(ST, B) kernel_fn_route xhist_pick_route_##ST##_b##B(int wdt, int D, int scan, bool multi);
-XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 512) XH_ROUTE_TU(f64, 1024s8)
-XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 512) XH_ROUTE_TU(f32, 1024s8)
+XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 1024s8)
+XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 1024s8)
 #undef XH_ROUTE_TU

@@ -155,6 +155,8 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
   TableSet* ts = f32dom ? &p->ts_pk32 : &p->ts_pk;
   int& np_out = f32dom ? p->pk32_np : p->pk_np;
   np_out = 0;
+  ts->max_cnt = 0;            // (a retry with a smaller budget runs on the same TableSet: nothing of the last attempt may survive)
+  bool any_key_map = false;   // some dimension uses the float-bits map (a local, not a sentinel left in ts->max_cnt)
   std::vector<std::vector<float>> thr_all((size_t)n_inputs);
   int32_t edge_off = 0;
   int64_t max_e = 0;
@@ -269,10 +271,8 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
     t.key_pos0 = kpos0;
     t.key_gap = kgap;
     t.steps = 1;
-    ts->max_cnt = -1;  // (marks "some dimension uses the float-bits map" until the device-built table is verified below)
+    any_key_map = true;
   }
-  const bool any_key_map = ts->max_cnt == -1;
-  ts->max_cnt = 0;
   int64_t stride = 1;
   for (int d = n_inputs - 1; d >= 0; --d) {
     ts->dim[d].out_stride = stride;
@@ -577,8 +577,6 @@ extern "C" int xhist_plan_destroy(xhist_plan* p) {
     if (p->ts_pk.blob) (void)hipFree(p->ts_pk.blob);
     if (p->ts_pk32.blob) (void)hipFree(p->ts_pk32.blob);
     for (auto& e : p->ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto& e : p->side_events) (void)hipEventDestroy(e);
-    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
     if (p->mixed_hint) (void)hipHostFree(p->mixed_hint);
   }
   delete p;
@@ -606,9 +604,6 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
   } else if (!strcmp(key, "records48")) {
     p->records48_pref = value < 0 ? -1 : 0;
     if (p->mixed_hint) *p->mixed_hint = 0u;  // (setting the knob also forgets what earlier calls saw)
-  } else if (!strcmp(key, "route_block")) {
-    if (value != 0 && value != 512 && value != 1024) return fail(XHIST_ERR_INVALID, "route_block must be 0 (auto), 512 or 1024");
-    p->route_block = (int)value;
   } else if (!strcmp(key, "route_spl")) {
     if (value != 0 && value != 4 && value != 8) return fail(XHIST_ERR_INVALID, "route_spl must be 0 (auto), 4 or 8");
     p->route_spl = (int)value;
@@ -628,12 +623,6 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->lanes = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "slices")) {
     p->slices_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
-  } else if (!strcmp(key, "overlap")) {
-    if (value < 0 || value > 64) return fail(XHIST_ERR_INVALID, "overlap must be in [0, 64] (sub-batches; 0 auto, 1 off)");
-    p->overlap = (int)value;
-  } else if (!strcmp(key, "overlap_cus")) {
-    if (value < 0 || value > 128) return fail(XHIST_ERR_INVALID, "overlap_cus must be in [0, 128]");
-    p->overlap_cus = (int)value;
   } else if (!strcmp(key, "route_grid")) {
     if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "route_grid must be in [0, 4096]");
     p->route_grid = (int)value;

@@ -712,11 +712,7 @@ __global__ void __launch_bounds__(1024) part_accumulate_chunks(const RouteArgs r
   int part = 0;
   typedef uint16_t c4 __attribute__((ext_vector_type(4)));
   typedef RT w4 __attribute__((ext_vector_type(4)));
-#ifdef XHIST_ACC_GROUPS  // development A/B only: record quads per lane in flight in the adding-up pass
-  constexpr int kGroups = XHIST_ACC_GROUPS;
-#else
-  constexpr int kGroups = 2;
-#endif
+  constexpr int kGroups = 2;  // record quads per lane in flight (1 / 2 / 4: 717 / 714 / 716 us for C5, profiles/r04_*acc_groups*)
   const int qlg = lg - 2;  // quads per chunk, log2
   while (lo < hi) {
     while (part + 1 < P && offs[part + 1] <= lo) ++part;

@@ -117,6 +117,7 @@ class _NativeExchange:
         assert t.is_cuda and t.is_contiguous()
         rop = {"sum": _native.REDUCE_SUM, "min": _native.REDUCE_MIN, "max": _native.REDUCE_MAX}[op]
         self.comm.allreduce(t.data_ptr(), t.numel(), self._tag(t), rop, self._stream())
+        self.comm.wait(self._stream())  # the deadline instead of a hang in the host read that follows
 
     def all_gather(self, t):
         import torch
@@ -124,6 +125,7 @@ class _NativeExchange:
         assert t.is_cuda and t.is_contiguous()
         recv = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         self.comm.allgather(t.data_ptr(), recv.data_ptr(), t.numel(), self._tag(t), self._stream())
+        self.comm.wait(self._stream())
         return list(recv.unbind(0))
 
 

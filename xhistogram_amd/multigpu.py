@@ -247,16 +247,33 @@ class DeviceGroup:
                 self._comms = self.run(lambda rank, device, _: _native.Comm(device, rank, world, uid), [None] * world)
             return self._comms
 
+    def exchange(self, fn, items):
+        """``fn(comm, rank, device, item)`` on every GPU's thread, under the collective lock.  A RuntimeError out of it — a
+        deadline (`xhist_comm_wait` / the rendezvous), an asynchronous RCCL error — leaves ABORTED communicators behind
+        that fail every later call at once; a long-lived worker must not be poisoned by one slow peer, so
+        they are dropped here and the next exchange builds new ones."""
+        with self.collective:
+            comms = self.comms()
+            try:
+                return self.run(lambda rank, device, item: fn(comms[rank], rank, device, item), items)
+            except RuntimeError:
+                self._drop_comms()
+                raise
+
+    def _drop_comms(self):
+        with self.collective:
+            comms, self._comms = self._comms, None
+        if comms:
+            try:
+                self.run(lambda rank, device, c: c.close(), comms)
+            except Exception:  # noqa: BLE001 - best effort: an aborted communicator only needs its memory back
+                pass
+
     def close(self):
         if self._closed:
             return
         self._closed = True
-        if self._comms:
-            comms, self._comms = self._comms, None
-            try:
-                self.run(lambda rank, device, c: c.close(), comms)
-            except Exception:
-                pass
+        self._drop_comms()
         for p in self._pools:
             p.shutdown(wait=True)
 
@@ -404,14 +421,12 @@ def _allreduce_host_partials(group, parts):
 
 
 def _allreduce_host_partials_locked(group, parts, tag, shape, dtype, count):
-    comms = group.comms()
-
-    def one(rank, device, part):
+    def one(comm, rank, device, part):
         buf = _native.DeviceBuffer(device, count * 8)
         try:
             buf.upload(np.ascontiguousarray(part))
-            comms[rank].allreduce(buf.ptr, count, tag, _native.REDUCE_SUM, 0)
-            comms[rank].wait(0)  # (a deadline instead of a hang when a peer GPU never enters the collective)
+            comm.allreduce(buf.ptr, count, tag, _native.REDUCE_SUM, 0)
+            comm.wait(0)  # (a deadline instead of a hang when a peer GPU never enters the collective)
             if rank != 0:
                 return None
             out = np.empty(shape, dtype)
@@ -420,7 +435,7 @@ def _allreduce_host_partials_locked(group, parts, tag, shape, dtype, count):
         finally:
             buf.close()
 
-    return group.run(one, list(parts))[0]
+    return group.exchange(one, list(parts))[0]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -473,14 +488,12 @@ def reduce_partials(nested, drop_axes=(), out_dtype="<i8", _allreduce=None, _all
                     _allreduce(sums, count, tag)
                 else:
                     group = group_for(group_devices)
-                    with group.collective:
-                        comms = group.comms()
 
-                        def one(rank, device, acc):
-                            comms[rank].allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
-                            comms[rank].wait(0)
+                    def one(comm, rank, device, acc):
+                        comm.allreduce(acc.buf.ptr, count, tag, _native.REDUCE_SUM, 0)
+                        comm.wait(0)
 
-                        group.run(one, sums)
+                    group.exchange(one, sums)
             total = sums[0].to_numpy()  # (download waits for the NULL stream of that GPU)
         finally:
             for acc in sums:
@@ -671,20 +684,17 @@ def histogram(*args, bins=None, range=None, axis=None, weights=None, density=Fal
         for p in parts[1:]:
             counts += p.to(home)
     elif exchange == "rccl":
-        with group.collective:
-            comms = group.comms()
+        def allreduce(comm, rank, device, t):
+            torch = core._torch()
+            torch.cuda.set_device(_native.physical_device(device))
+            t = t.contiguous()
+            tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            comm.allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
+            comm.wait(stream)
+            return t
 
-            def allreduce(rank, device, t):
-                torch = core._torch()
-                torch.cuda.set_device(_native.physical_device(device))
-                t = t.contiguous()
-                tag = {torch.int64: _native.I64, torch.float64: _native.F64, torch.float32: _native.F32}[t.dtype]
-                stream = torch.cuda.current_stream(t.device).cuda_stream
-                comms[rank].allreduce(t.data_ptr(), t.numel(), tag, _native.REDUCE_SUM, stream)
-                comms[rank].wait(stream)
-                return t
-
-            counts = group.run(allreduce, parts)[0]
+        counts = group.exchange(allreduce, parts)[0]
     else:
         raise ValueError("exchange must be 'rccl' or 'p2p', got %r" % (exchange,))
 
