@@ -220,6 +220,7 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       float64 records in the same call; XHIST_AMD_EXACT_RECORDS=1 is the process-wide "never"),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
+ *       "arith32" (0 auto / 1 prefer / -1 never: float32 samples on such edges digitized in float32 arithmetic),
  *       "pack" (0 auto / 1 whenever the plan has them / -1 never: packed 16-byte bucket entries — one LDS read per sample and
  *       dimension — for float64 / float32 samples on non-uniform edges, on a linear or a float-bit-pattern (logarithmic) grid),
  *       "route_grid", "acc_grid" (workgroups of the routing / adding-up pass of the multi-pass mode; 0 auto),

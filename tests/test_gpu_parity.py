@@ -459,9 +459,12 @@ def test_f32_threshold_domain_is_exact_at_edges(xh):
     x = np.tile(pts, 300).astype(np.float32).reshape(3, -1)
     want = onp.bincount_rows([x], [edges])
     for resident in (False, True):
-        got, desc = _run(xh, [x], [edges], None, resident)
+        got, desc = _run(xh, [x], [edges], None, resident, arith32=-1)  # (left alone, np.linspace edges take the float32 arithmetic: scan=9)
         np.testing.assert_array_equal(got, want)
     assert "cmp=f32thr" in desc, desc
+    got, desc = _run(xh, [x], [edges], None, True)
+    assert "scan=9" in desc, desc
+    np.testing.assert_array_equal(got, want)
     # last edge not representable in float32: no float32 sample can equal it
     e2 = np.array([0.0, 0.1, 0.30000000000000004])
     x2 = np.array([[0.3, 0.30000001192092896, 0.29999998211860657, 0.1, 0.0]], dtype=np.float32)
@@ -1198,9 +1201,13 @@ def test_arithmetic_edges_large_1d(xh, nb, weighted, dt, want_hist):
     edges = [np.linspace(-3.7, 5.1, nb + 1)]
     x = _edge_torture(edges[0], rng, 400_000, dt)
     w = rng.uniform(-1, 2, x.shape) if weighted else None
-    got, desc = _run(xh, [x], edges, w, True)
+    got, desc = _run(xh, [x], edges, w, True, arith32=-1)
     assert "family=fast" in desc and "scan=5" in desc and want_hist in desc, desc
     assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
+    if dt == np.float32:  # left alone, float32 samples on these edges are decided in float32 arithmetic (round 5)
+        got, desc = _run(xh, [x], edges, w, True)
+        assert "family=fast" in desc and "scan=9" in desc and want_hist in desc, desc
+        assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
     got, desc = _run(xh, [x], edges, w, False)  # host route
     assert_hist_equal(got, onp.bincount_rows([x], edges, w), weighted)
 
@@ -2450,7 +2457,7 @@ def test_bin_estimators_cut_float32_data_to_the_range_in_float32(xh, name):
     t = _dev(a)
     # (NumPy float64 / int64 scalars as bounds make numpy compare in float64 — those keep their value)
     for r in ((0.7, 1.0), (0.7, 0.7), (0.3, 1.1), (np.float64(0.7), 1.0), (np.float32(0.7), np.float64(1.0)), (0.7, np.float64(1.1)),
-              (np.int64(0), np.float32(1.1))):
+              (np.float64(0.0), np.float32(1.1))):
         want = np.histogram_bin_edges(a, bins=name, range=r)
         got = xh._device_bin_edges(t, name, r, False)
         np.testing.assert_array_equal(got, want, err_msg=str((name, r)))
@@ -2588,3 +2595,90 @@ def test_partitioned_mode_routes_with_packed_bucket_entries(xh, kind, weights, d
     got, desc = _run(xh, samples, edges, w, True, partition=1, pack=-1)
     assert "scan=8" not in desc, desc
     assert_hist_equal(got, want, w is not None)
+
+
+# ---------------------------------------------------------------------------------------------
+# float32 samples on arithmetic edges, digitized in float32 arithmetic (bin_arith32_fast, scan=9; round 5)
+# ---------------------------------------------------------------------------------------------
+def _f32_boundary_torture(edges, rng, n_random):
+    """float32 samples on every float32 bin boundary (the smallest float32 >= e_j), on its float32 predecessor and successor,
+    two ulps either side, plus randoms well beyond the range and the specials"""
+    e = np.asarray(edges, dtype=np.float64)
+    b = e.astype(np.float32)
+    b = np.where(b.astype(np.float64) < e, np.nextafter(b, np.float32(np.inf)), b).astype(np.float32)
+    parts = [b]
+    for k in (1, 2):
+        lo, hi = b.copy(), b.copy()
+        for _ in range(k):
+            lo, hi = np.nextafter(lo, np.float32(-np.inf)), np.nextafter(hi, np.float32(np.inf))
+        parts += [lo, hi]
+    span = float(e[-1] - e[0])
+    parts += [rng.uniform(e[0] - 0.2 * span, e[-1] + 0.2 * span, n_random).astype(np.float32),
+              np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 3.0e38, -3.0e38, 1e-45, e[0], e[-1]], dtype=np.float32)]
+    x = np.concatenate(parts).astype(np.float32)
+    rng.shuffle(x)
+    return x.reshape(1, -1)
+
+
+@pytest.mark.parametrize("mode", ["auto", "forced", "off"])
+@pytest.mark.parametrize("lo,hi,nb", [(-4.0, 4.0, 50), (-4.0, 4.0, 100), (0.0, 1.0, 1000), (0.1, 0.7, 333), (-123.456, -123.0, 40),
+                                      (1e6, 1e6 + 64.0, 64), (-1e-3, 3e-3, 77), (-3.7, 5.1, 20000), (250.0, 330.0, 7)])
+def test_float32_arithmetic_digitize_on_and_next_to_every_boundary(xh, lo, hi, nb, mode):
+    """BASELINE C4's digitize (float32 samples, np.linspace edges): decided by one float32 fma unless the sample is within
+    delta bins of a float32 bin boundary; a sample on every boundary, on its neighbours and two ulps away must land where
+    searchsorted puts the float64 image of the sample (core.py:163-174, numpy >= 2 compare rules)"""
+    rng = np.random.default_rng(nb)
+    edges = [np.linspace(lo, hi, nb + 1)]
+    x = _f32_boundary_torture(edges[0], rng, 300_000)
+    params = {"auto": {}, "forced": {"arith32": 1}, "off": {"arith32": -1}}[mode]
+    want = onp.bincount_rows([x], edges)
+    got, desc = _run(xh, [x], edges, None, True, **params)
+    if mode == "off":
+        assert "scan=9" not in desc, desc
+    elif lo == 1e6:  # bins of 16 float32 ulps: the predecessor of a boundary sits 1/16 of a bin below it, delta = 1/8: not offered
+        assert "scan=9" not in desc, desc
+    else:
+        assert "scan=9" in desc, desc
+    np.testing.assert_array_equal(got, want, err_msg=desc)
+    w = rng.uniform(0.5, 1.5, x.shape).astype(np.float32)
+    got, desc = _run(xh, [x], edges, w, True, **params)
+    assert_hist_equal(got, onp.bincount_rows([x], edges, w), True)
+    # many rows (C4's shape in small): the long-tile variant and the row-wise geometry
+    xr = _f32_boundary_torture(edges[0], rng, 150_000)
+    cols = xr.shape[1] // 70
+    xr = np.ascontiguousarray(xr[0, : 70 * cols].reshape(70, cols))
+    got, desc = _run(xh, [xr], edges, None, True, **params)
+    np.testing.assert_array_equal(got, onp.bincount_rows([xr], edges), err_msg=desc)
+    if (lo, hi, nb) == (-4.0, 4.0, 50):  # C4's own shape class: >= 64 rows of >= 2^19 samples take 32 samples per lane and tile
+        xl = np.tile(_f32_boundary_torture(edges[0], rng, (1 << 19) + 4321), (64, 1))
+        for r in range(64):
+            xl[r] = np.roll(xl[r], 977 * r)
+        xl[5, ::3] = np.nan
+        got, desc = _run(xh, [xl], edges, None, True, **params)
+        assert "unroll=8" in desc and (mode == "off" or "scan=9" in desc), desc
+        np.testing.assert_array_equal(got, onp.bincount_rows([xl], edges), err_msg=desc)
+
+
+@pytest.mark.parametrize("weights", ["none", "f32", "f64"])
+def test_float32_arithmetic_digitize_joint_histograms(xh, weights):
+    """the same digitize per dimension of a 2-D / 3-D joint histogram of float32 samples (LDS-resident histograms)"""
+    rng = np.random.default_rng(17)
+    for dims, nbs in ((2, (50, 30)), (3, (12, 9, 7))):
+        edges = [np.linspace(-2.0 - d, 3.0 + d, nb + 1) for d, nb in enumerate(nbs)]
+        n = 200_000
+        xs = [_f32_boundary_torture(e, rng, n)[:, :n] for e in edges]
+        w = {"none": None, "f32": rng.uniform(0, 2, (1, n)).astype(np.float32), "f64": rng.standard_normal((1, n))}[weights]
+        got, desc = _run(xh, xs, edges, w, True, arith32=1)
+        assert "scan=9" in desc, desc
+        assert_hist_equal(got, onp.bincount_rows(xs, edges, w), w is not None)
+
+
+def test_float32_arithmetic_digitize_is_not_offered_for_bins_float32_cannot_resolve(xh):
+    """bins narrower than a few float32 ulps: plan creation measures delta >= 1/8 (or boundaries that coincide) and the plan
+    keeps the threshold tables / the float64 arithmetic — results stay exact"""
+    rng = np.random.default_rng(3)
+    edges = [np.linspace(1000.0, 1000.01, 401)]  # 2.5e-5 per bin at magnitude 1000: float32 ulp is 6.1e-5
+    x = _f32_boundary_torture(edges[0], rng, 100_000)
+    got, desc = _run(xh, [x], edges, None, True, arith32=1)
+    assert "scan=9" not in desc, desc
+    np.testing.assert_array_equal(got, onp.bincount_rows([x], edges))

@@ -59,7 +59,13 @@ def in_library(so):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = list(sys.argv[1:])
+    json_out = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        json_out = argv[i + 1]
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
     so, logs = args[0], args[1:]
     have = in_library(so)
     raw = set()
@@ -83,9 +89,8 @@ def main():
     if "--unused" in sys.argv:
         for n in sorted(have - used):
             print("unused:", n)
-    if "--json" in sys.argv:
-        path = sys.argv[sys.argv.index("--json") + 1]
-        json.dump({"in_library": sorted(have), "selected": sorted(used)}, open(path, "w"), indent=0)
+    if json_out:
+        json.dump({"in_library": sorted(have), "selected": sorted(used)}, open(json_out, "w"), indent=0)
 
 
 if __name__ == "__main__":

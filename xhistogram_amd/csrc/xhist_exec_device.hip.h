@@ -771,13 +771,14 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
     return XHIST_OK;
   }
 
-  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref, fused_pref, pack_pref;
+  int block_threads, grid_blocks, force_global, force_generic, lds_copies, profile, partition, lanes, arith_pref, slices_pref, fused_pref, pack_pref, arith32_pref;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     block_threads = p->block_threads; grid_blocks = p->grid_blocks; force_global = p->force_global;
     force_generic = p->force_generic; lds_copies = p->lds_copies; profile = p->profile; partition = p->partition;
     lanes = p->lanes; arith_pref = p->arith_pref; slices_pref = p->slices_pref; fused_pref = p->fused_pref;
     pack_pref = p->pack_pref;
+    arith32_pref = p->arith32_pref;
   }
 
   // ---- many short rows / leading-axis reductions: one row per lane (xhist_lanes.hip.h) --------
@@ -903,6 +904,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   //   lds:    replicated sub-histograms in LDS (one copy per lane bank), uint32 / float64
   //   packed: unweighted vector family only, uint16 counters packed two per word (exact, see kernel)
   //   global: device-scope atomics straight into the output
+  bool padded_bins = false;  // (hist_fast's PADDED layout; set before place() is asked about it)
   auto place = [&](size_t tbytes, bool vector_family) {
     hist = kHistGlobal;
     cl2 = 0;
@@ -913,7 +915,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       const size_t soft = (!weighted && D == 1 && dtype_size(samples[0].dtype) <= 4 ? 64 : 24) * 1024;
       cl2 = max_cl2;
       if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
-      auto bytes_at = [&](int c) { return (((size_t)p->n_bins << c) + 32) * (size_t)acc_size; };  // + 32 trash slots
+      // + 32 trash slots; the padded layout of the float32 arithmetic digitize (one input): a bin in front and one behind instead
+      auto bytes_at = [&](int c) { return (padded_bins ? ((size_t)p->n_bins + 2) << c : ((size_t)p->n_bins << c) + 32) * (size_t)acc_size; };
       if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
       // short rows: a workgroup zeroes and reads back every copy, which must stay small next to the
       // samples it bins (10^5 rows x 1000 f32, 50 bins: 32 copies 0.162 ms, 4 copies 0.096 ms)
@@ -941,6 +944,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   for (int attempt = (fast_ok || mixed_ok) ? 0 : 1; attempt < 2 && !fn; ++attempt) {
     fast = attempt == 0;
     mixed = fast && !fast_ok;
+    padded_bins = false;
     // float32 samples are digitized against the float32-threshold tables (exact, see Dom<2>)
     use_f32 = fast && !mixed && sdt == XHIST_F32 && p->ts[1][0].blob != nullptr;  // (mixed dtypes are consumed as float64)
     scan = 0;
@@ -977,11 +981,36 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
         hist = h0; cl2 = c0; hist_bytes = b0;
       }
     }
+    // float32 samples on arithmetic edges with an LDS histogram: the bin from float32 arithmetic, no table at all
+    // (bin_arith32_fast: 7-9 vector instructions and one LDS operation per sample against 12 and three for the threshold
+    // tables — BASELINE C4, whose dask-chunk-sized calls run while the clock of a just-woken GPU dips)
+    // ("arith" = 1 asks for the float64 arithmetic by name and keeps it; "arith" = -1 rules out both)
+    if (fast && !mixed && !two && !i64dom && sdt == XHIST_F32 && p->arith32 && arith32_pref >= 0 && arith_pref >= 0 &&
+        (arith32_pref > 0 || (arith_pref == 0 && (scan == 1 || scan == 2 || scan == kScanArith)))) {
+      const int h0 = hist, c0 = cl2;
+      const size_t b0 = hist_bytes;
+      padded_bins = D == 1;
+      place(0, true);
+      if (hist != kHistLds) {
+        padded_bins = false;
+        place(0, true);
+      }
+      if (hist == kHistLds) {
+        scan = kScanArith32;
+        use_f32 = false;
+        tset = &p->ts[0][0];  // float64-domain DimTable (e_0, e_last, step, a32_*); its tables are not read
+        table_bytes = 0;
+        tables_fit = true;
+      } else {
+        padded_bins = false;
+        hist = h0; cl2 = c0; hist_bytes = b0;
+      }
+    }
     // Non-uniform edges, float64 samples: packed 16-byte bucket entries (count_le_pack) — one LDS read per sample and
     // dimension instead of two dependent ones — where the histogram stays in LDS with them.  Measured for joint histograms
     // (C3: see DESIGN 4); 1-D histograms keep the two-level tables unless "pack" = 1.
     const int pk_np = sdt == XHIST_F64 ? p->pk_np : (sdt == XHIST_F32 && use_f32 ? p->pk32_np : 0);
-    if (fast && !mixed && !two && !i64dom && pk_np && pack_pref >= 0 && scan != kScanArith && tables_fit &&
+    if (fast && !mixed && !two && !i64dom && pk_np && pack_pref >= 0 && scan != kScanArith && scan != kScanArith32 && tables_fit &&
         (scan == 0 || scan >= 2 || pack_pref > 0) && (D >= 2 || scan == 0 || (sdt == XHIST_F32 && !weighted) || pack_pref > 0)) {
       // (scan 0: the alternative is a binary search; 1-D: measured level for float64 samples and for weighted float32 ones,
       //  0.74 -> 0.85 of 8 TB/s for float32 counts — twice the table reads per byte streamed: profiles/r04_h_*)
@@ -1027,7 +1056,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
   // 0.2838 ms (0.823 -> 0.833) and 2.228 -> 2.208 ms (0.849 -> 0.857), profiles/r03_u8_unroll8.txt.  Short rows keep their tiles
   // (the geometry rules further down were fitted to them); float64 with many rows was not measured and stays as it was.
   bool long_tiles = false;
-  if (fn && fast && !mixed && !two && !i64dom && !weighted && D == 1 && hist == kHistLds && (scan == 1 || scan == 2) && !block_threads && !grid_blocks) {
+  if (fn && fast && !mixed && !two && !i64dom && !weighted && D == 1 && hist == kHistLds && (scan == 1 || scan == 2 || scan == kScanArith32) && !block_threads && !grid_blocks) {
     kernel_fn lf = nullptr;
     // (exactly the two shape classes that were measured: one float32 row of 3*10^7 ... 10^9 samples came out 4-10 % SLOWER
     // with the long tiles in tools/size_ramp.py — its one-workgroup-per-CU geometry already has 64 KiB per CU in flight)
@@ -1437,7 +1466,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       kp.row0 = r0;
       kp.n_dims = D;
       kp.tables = tset->blob;
-      kp.table_words = scan == kScanArith ? 0 : tset->words;  // arithmetic edges: nothing to stage
+      kp.table_words = (scan == kScanArith || scan == kScanArith32) ? 0 : tset->words;  // arithmetic edges: nothing to stage
       kp.tables_in_lds = tables_in_lds ? 1 : 0;
       kp.n_rows = nr;
       kp.n_cols = nc;

@@ -33,9 +33,12 @@ static void log_picked_kernel(const void* fn) {
   static std::set<const void*> seen;
   std::lock_guard<std::mutex> lk(mu);
   if (!seen.insert(fn).second) return;
-  const char* name = hipKernelNameRefByPtr(fn, nullptr);
+  // the host stub's own symbol (`__device_stub__<kernel>`), from the dynamic symbol table: no call into the HIP runtime
+  // (hipKernelNameRefByPtr hung a process that had loaded this library before torch's bundled runtime)
+  Dl_info info;
+  const char* name = dladdr(fn, &info) && info.dli_sname ? info.dli_sname : "?";
   if (FILE* f = fopen(path, "a")) {
-    fprintf(f, "%s\n", name ? name : "?");
+    fprintf(f, "%s\n", name);
     fclose(f);
   }
 }
@@ -418,6 +421,7 @@ struct xhist_plan {
   bool uns = false;    // the int64-domain inputs hold unsigned 64-bit values (XHIST_CMP_UNSIGNED)
   bool huge = false;   // some dimension has more than 65535 edges: no bucket tables (lut_k = 0)
   bool arith = false;  // every dimension has arithmetic (numpy.linspace) edges: table-free digitize available
+  bool arith32 = false;  // ... and float32 samples can be decided in float32 arithmetic (DimTable::a32_h > 0 in every dimension)
   int64_t n_bins = 0;
   int cus = 256;
   size_t lds_max = 64 * 1024;
@@ -437,6 +441,7 @@ struct xhist_plan {
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never
   int arith_pref = 0;  // 0 auto, 1 table-free digitize whenever the edges are arithmetic, -1 never
+  int arith32_pref = 0;  // 0 auto, 1 float32 arithmetic digitize for float32 samples wherever the plan offers it, -1 never
   int lanes = 0;      // 0 auto, 1 prefer the row-per-lane kernels whenever they are legal, -1 never
   int lds_copies = 0;
   int profile = 0;

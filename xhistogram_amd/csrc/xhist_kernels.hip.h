@@ -57,6 +57,12 @@ struct DimTable {
   // the kernels' own arithmetic, doubled for margin): a sample whose position t = (x - e_0) * inv_step has a fractional
   // part with |frac - 0.5| < arith_h lies strictly inside bin floor(t) (bin_arith_fast).  0 = never decide by arithmetic.
   double arith_h;
+  // float32 SAMPLES on arithmetic edges decided in float32 arithmetic (bin_arith32_fast, SCAN = kScanArith32):
+  // t(x) = fmaf(x, a32_scale, a32_bias) is monotone in x, and plan creation has measured |t(B_j) - j| and |t(pred(B_j)) - j|
+  // <= delta32 for every float32 bin boundary B_j (the smallest float32 >= e_j; > e_last for the last one: the right-edge rule
+  // of core.py:170-173 lives in the boundary), with the same single-rounding fma.  a32_h = 0.5 - delta32; 0 = not offered.
+  float a32_scale, a32_bias, a32_h;
+  float a32_top;        // nb + 0.5: t is clamped to [-0.5, nb + 0.5] before its floor is taken (see bin_arith32_fast)
   // packed bucket entries (count_le_pack): bucket map of this dimension — 0: linear in (float)x (scale / bias above),
   // 1: the float32 BIT PATTERN of x (an order-preserving integer key, (key - key_lo) >> key_shift): uniform in log x —
   // geometric / logarithmic edges, which a linear grid piles into its first buckets
@@ -292,6 +298,40 @@ __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool&
   return inside ? g : -1;
 }
 
+// The same idea for float32 SAMPLES, in float32 arithmetic (BASELINE C4: (time, lat, lon) float32, 50 uniform bins).  The
+// table digitize of such samples costs 12 vector-ALU instructions and three LDS operations per 4-byte sample (bucket, start
+// table, threshold, compare, range test, clamp, slot) and keeps the SIMDs 60 % busy at 6.6 TB/s — too close to co-limited for
+// a kernel that dask-chunk-sized calls run in the first milliseconds after an idle GPU, while the shader clock dips
+// (0.83 of 8 TB/s in a tight loop, 0.71-0.75 cold).  Here:
+//   t = fmaf(x, scale, bias)                 one rounding; monotone non-decreasing in x (scale > 0)
+//   t = med3(t, -0.5, nb + 0.5)              NaN -> -0.5 (v_med3_f32 returns the minimum when an operand is NaN); +-inf, fill
+//                                            values like 1e20 and everything else far outside land on -0.5 / nb + 0.5:
+//                                            certainly dropped (t < -0.5 => x < B_0, t > nb + 0.5 => x >= B_nb, by the
+//                                            inequalities below) and certainly not `near` — data full of NaNs (land points)
+//                                            or sentinels never leave the fast path
+//   g = floor(t), f = t - g                  |f - 0.5| < a32_h  =>  x lies strictly inside bin g's float32 boundaries
+// Proof as for bin_arith_fast, with the float32 boundaries B_j in place of the edges: B_g <= x would fail only if
+// x <= pred(B_g), and then t(x) <= t(pred(B_g)) <= g + delta, i.e. f <= delta; x < B_{g+1} would fail only if x >= B_{g+1},
+// and then t(x) >= g + 1 - delta.  g < 0 / g >= nb are below B_0 / at or above B_nb by the same two inequalities.  Plan
+// creation measures delta over every B_j AND its float32 predecessor with fmaf (correctly rounded on the host, v_fma_f32 on
+// the device: the same number).  6.5 vector-ALU instructions (the fma and the `- 0.5` are packed two samples to an
+// instruction) and ONE LDS operation per sample.
+// Returns floor(t) in [-1, nb] as an unsigned number: [0, nb) when the sample counts, 0xFFFFFFFF (below / NaN) or nb when not.
+__device__ __forceinline__ uint32_t bin_arith32_fast(float x, const DimTable& t, bool& near) {
+  float tt = __builtin_fmaf(x, t.a32_scale, t.a32_bias);
+  tt = __builtin_amdgcn_fmed3f(tt, -0.5f, t.a32_top);
+  const float fl = __builtin_floorf(tt);
+  const float f = tt - fl;
+  near = !(__builtin_fabsf(f - 0.5f) < t.a32_h);
+  return (uint32_t)(int)fl;
+}
+// ... and the exact answer for a `near` sample, same convention: float64 compares against the recomputed edges
+__device__ __forceinline__ uint32_t bin_arith32_exact(float x, const DimTable& t) {
+  const double xd = (double)x;
+  const uint32_t c = count_le_arith(xd, t);
+  return Dom<0>::in_range(xd, t) ? min(c, (uint32_t)t.nb) - 1u : 0xffffffffu;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Packed bucket entries (SCAN = kScanPack2 / kScanPack3; float64 samples, NON-uniform edges — BASELINE C3).
 // The table digitize above costs a dimension two DEPENDENT LDS reads (uint16 `start`, then 1-4 float64 edges at
@@ -312,6 +352,9 @@ __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool&
 constexpr int kScanPack2 = 6, kScanPack3 = 7;  // linear bucket map in every dimension, at most 2 / 3 edges per bucket
 constexpr int kScanPackG = 8;                    // general: the map is chosen per dimension (DimTable::map_kind), 3 edges per bucket
 constexpr bool scan_is_pack(int scan) { return scan == kScanPack2 || scan == kScanPack3 || scan == kScanPackG; }
+constexpr int kScanArith32 = 9;  // float32 samples, arithmetic edges, float32 arithmetic (bin_arith32_fast); no tables
+// digitize forms whose per-sample result is the BIN itself (>= nb as unsigned when the sample is dropped), not a count of edges
+constexpr bool scan_gives_bin(int scan) { return scan_is_pack(scan) || scan == kScanArith32; }
 
 // Order-preserving integer key of a float32: for any a, b (not NaN)  a < b  =>  key(a) < key(b), and -0.0 / +0.0 — equal as
 // numbers — get the SAME key (the sample is canonicalised by adding +0.0 first: an edge at 0.0 and a sample -0.0 must
@@ -467,7 +510,7 @@ __device__ __forceinline__ int bin_of_sample_pack(typename Dom<CMP>::T x, const 
 // entries, the bin itself (>= nb as unsigned when dropped)
 template <int CMP, int SCAN>
 __device__ __forceinline__ int bin_from_tile_count(typename Dom<CMP>::T x, const DimTable& t, uint32_t cnt) {
-  if constexpr (scan_is_pack(SCAN)) return cnt < (uint32_t)t.nb ? (int)cnt : -1;
+  if constexpr (scan_gives_bin(SCAN)) return cnt < (uint32_t)t.nb ? (int)cnt : -1;
   else return bin_from_count<CMP>(x, t, cnt);
 }
 
@@ -649,6 +692,33 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
             for (int v = 0; v < VEC; ++v) cnt[d][u][v] = count_le_arith((double)xv[d][u][v], p.dim[d]);
       }
     }
+  } else if constexpr (SCAN == kScanArith32) {
+    // float32 samples, arithmetic edges: the bin in float32 arithmetic (bin_arith32_fast); a wavefront in which some lane met
+    // a sample next to a boundary (one in ~10^5), NaN or +-inf redoes that lane's batch in float64
+    bool near_any = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      DimTable t = p.dim[d];
+      asm volatile("" : "+s"(t.a32_scale), "+s"(t.a32_bias), "+s"(t.a32_h), "+s"(t.a32_top));  // (scalar registers: not copied into VGPRs ahead of the loop)
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          bool near;
+          cnt[d][u][v] = bin_arith32_fast((float)xv[d][u][v], t, near);
+          near_any |= near;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {
+      if (near_any) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cnt[d][u][v] = bin_arith32_exact((float)xv[d][u][v], p.dim[d]);
+      }
+    }
   } else if constexpr (scan_is_pack(SCAN) && CMP == 2) {  // float32 samples: exact in one compare per threshold
     constexpr int NP = SCAN == kScanPack2 ? 2 : 3;
     constexpr bool G = SCAN == kScanPackG;
@@ -771,6 +841,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   constexpr int CMP = I64DOM ? 1 : ((__is_same(ST, float) && SCAN != kScanArith) ? 2 : 0);
   static_assert(!I64DOM || (__is_same(ST, int64_t) && SCAN == 0), "int64 domain: int64 samples, (start, cnt) tables");
   static_assert(!scan_is_pack(SCAN) || ((__is_same(ST, double) || __is_same(ST, float)) && !MIXED && !I64DOM), "packed bucket entries: float64 / float32 samples");
+  static_assert(SCAN != kScanArith32 || (__is_same(ST, float) && !MIXED && !I64DOM), "float32 arithmetic digitize: float32 samples");
   using CT = typename Dom<CMP>::T;
   // float samples: positions past the end of a ragged tile become NaN (dropped by digitize);
   // integer samples: zero, masked by the past_end bit
@@ -796,9 +867,13 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   // samples the reference drops (out of range, NaN) still issue their LDS atomic, on one of 32 trash
   // slots picked by lane: with a single copy they would otherwise all meet on ONE address and
   // serialise (10^9 samples, 90 % out of range: 4.9 ms against 2.4)
-  const uint32_t trash = (hb << p.copies_log2) + ((uint32_t)tid & 31u);
+  // PADDED (one float32 input digitized by bin_arith32_fast, whose result is floor(t) in [-1, nb]): the replicated histogram
+  // has a bin -1 in front and a bin nb behind — the lane's own trash: the slot address is ONE shift-add of the result, no range
+  // compare, no select
+  constexpr bool PADDED = SCAN == kScanArith32 && D == 1 && LDS_HIST && !SLICED;
+  const uint32_t trash = PADDED ? mycopy : (hb << p.copies_log2) + ((uint32_t)tid & 31u);
   uint32_t* packed = reinterpret_cast<uint32_t*>(hist);
-  const uint32_t hist_elems = (hb << p.copies_log2) + 32u;  // one replicated histogram (+ trash slots)
+  const uint32_t hist_elems = PADDED ? ((hb + 2u) << p.copies_log2) : (hb << p.copies_log2) + 32u;  // one replicated histogram (+ trash slots)
   lds_t* hist2 = hist + hist_elems;                                          // W2: the second weight's
   if (LDS_HIST) {
     const uint32_t n = hist_elems * (W2 ? 2u : 1u);
@@ -838,7 +913,8 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 
   // D == 1 fast scatter (see the tile loop): this lane's copy of bin -1, and its trash slot
   const uint32_t slot_shift = (uint32_t)p.copies_log2 + (sizeof(lds_t) == 8 ? 3u : 2u);
-  unsigned char* slot_base = reinterpret_cast<unsigned char*>(hist + mycopy) - ((size_t)1 << slot_shift);
+  unsigned char* slot_base0 = reinterpret_cast<unsigned char*>(hist + mycopy) + (PADDED ? ((size_t)1 << slot_shift) : 0);  // this lane's copy of bin 0
+  unsigned char* slot_base = slot_base0 - ((size_t)1 << slot_shift);             // ... of "bin -1": addressed by edge counts
   lds_t* trash_slot = hist + trash;
   auto scatter = [&](bool ok, uint32_t flat, double w, double w2) {
     if (LDS_HIST) {
@@ -972,16 +1048,27 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
+          if constexpr (PADDED) {
+            lds_t* slot = reinterpret_cast<lds_t*>(slot_base0 + (cnt[0][u][v] << slot_shift));  // [-1, nb] -> the pad bins catch the dropped
+            if (kWeighted) {
+              unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
+              if constexpr (W2) unsafeAtomicAdd(reinterpret_cast<double*>(slot) + hist_elems, (double)wv2[u][v]);
+            } else {
+              atomicAdd(reinterpret_cast<uint32_t*>(slot), 1u);
+            }
+            continue;
+          }
           if constexpr (D == 1 && LDS_HIST && !SLICED) {
             // one input, LDS histogram: the slot address comes straight from the edge count
             //   bin = min(cnt, nb) - 1  ->  byte offset (min(cnt, nb) << sh) from a base moved back
             //   by one bin; out-of-range / NaN / past-the-end samples go to the lane's trash slot
             // (packed entries: what count_le_tile returns is the bin, >= nb for dropped samples; slot_base sits one bin back)
-            const bool ok1 = scan_is_pack(SCAN) ? (cnt[0][u][v] < (uint32_t)p.dim[0].nb)
+            const bool ok1 = scan_gives_bin(SCAN) ? (cnt[0][u][v] < (uint32_t)p.dim[0].nb)
                                                 : (Dom<CMP>::in_range((CT)xv[0][u][v], p.dim[0]) &
                                                    (kFloatSamples || !((past_end >> (u * VEC + v)) & 1u)));
-            const uint32_t off = (scan_is_pack(SCAN) ? cnt[0][u][v] + 1u : min(cnt[0][u][v], (uint32_t)p.dim[0].nb)) << slot_shift;
-            lds_t* slot = ok1 ? reinterpret_cast<lds_t*>(slot_base + off) : trash_slot;
+            // (bins: the base of bin 0 itself — `+ 1` on the bin is an instruction per sample the variable shift does not fold)
+            const uint32_t off = (scan_gives_bin(SCAN) ? cnt[0][u][v] : min(cnt[0][u][v], (uint32_t)p.dim[0].nb)) << slot_shift;
+            lds_t* slot = ok1 ? reinterpret_cast<lds_t*>((scan_gives_bin(SCAN) ? slot_base0 : slot_base) + off) : trash_slot;
             if (kWeighted) {
               unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
               if constexpr (W2) unsafeAtomicAdd(reinterpret_cast<double*>(slot) + hist_elems, (double)wv2[u][v]);
@@ -997,7 +1084,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
           for (int d = 0; d < D; ++d) {
             uint32_t b;
-            if constexpr (scan_is_pack(SCAN)) {
+            if constexpr (scan_gives_bin(SCAN)) {
               b = cnt[d][u][v];  // the bin itself, >= nb (unsigned) when dropped
               ok &= b < (uint32_t)p.dim[d].nb;
             } else {
@@ -1047,7 +1134,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     const uint32_t copies = 1u << p.copies_log2;
     for (uint32_t b = tid; b < hb; b += blockDim.x) {
       typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
-      for (uint32_t c = 0; c < copies; ++c) sum += hist[(b << p.copies_log2) + ((c + tid) & cmask)];
+      for (uint32_t c = 0; c < copies; ++c) sum += hist[((b + (PADDED ? 1u : 0u)) << p.copies_log2) + ((c + tid) & cmask)];
       if (p.direct_store) out[b] = (out_t)sum;  // the only workgroup of this row: plain store, zeros included
       else if (sum != 0) A::out_add(out, (int64_t)b, sum);
       if constexpr (W2) {

@@ -100,10 +100,24 @@ static kernel_fn fast_pick_pack(int hist) {
   return nullptr;
 }
 
+// float32 samples on arithmetic edges, digitized in float32 arithmetic (bin_arith32_fast): LDS histograms
+template <typename ST, typename WT, int D>
+static kernel_fn fast_pick_arith32(int hist) {
+  if constexpr (std::is_same<ST, float>::value) {
+    constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
+    constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
+    constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
+    constexpr int U = unroll_for(D, VEC, 1);
+    if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith32>;
+  }
+  return nullptr;
+}
+
 template <typename ST, typename WT, int D>
 static kernel_fn fast_pick_s(int scan, int hist) {
   switch (scan) {
     case kScanArith: return fast_pick_arith<ST, WT, D>(hist);
+    case kScanArith32: return fast_pick_arith32<ST, WT, D>(hist);
     case kScanPack2: return fast_pick_pack<ST, WT, D, kScanPack2>(hist);
     case kScanPack3: return fast_pick_pack<ST, WT, D, kScanPack3>(hist);
     case kScanPackG: return fast_pick_pack<ST, WT, D, kScanPackG>(hist);

@@ -15,5 +15,6 @@ kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist) {
 kernel_fn xhist_pick_f32_long(int scan) {
   if (scan == 1) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, 1>;
   if (scan == 2) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, 2>;
+  if (scan == kScanArith32) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, kScanArith32>;
   return nullptr;
 }

@@ -484,7 +484,7 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
   // two roundings kept apart (volatile product: no fma contraction), and only when bins are well
   // resolved (step >= 4 ulp of the largest magnitude) — the bound count_le_arith's guess relies on.
   if (cmp_domain == XHIST_CMP_F64) {
-    bool all = true;
+    bool all = true, all32 = true;
     for (int d = 0; d < n_inputs && all; ++d) {
       const double* e = static_cast<const double*>(edges[d]);
       const int nb = (int)n_edges[d] - 1;
@@ -517,15 +517,47 @@ extern "C" int xhist_plan_create(int device, int n_inputs, const void* const* ed
         delta = 2.0 * delta + 0x1p-40;
         if (delta < 0x1p-10) arith_h = 0.5 - delta;
       }
+      // float32 samples on these edges, decided in float32 arithmetic (bin_arith32_fast): delta32 over every float32 bin
+      // boundary B_j and its float32 predecessor, measured with fmaf — one rounding, the device's v_fma_f32.  Offered when
+      // the boundaries are distinct (bins at least a few float32 ulps wide) and delta32 stays below 1/8.
+      float a32_scale = 0.0f, a32_bias = 0.0f, a32_h = 0.0f;
+      if (ok && std::fabs(e[0]) < 3.0e38 && std::fabs(e[nb]) < 3.0e38) {
+        const double inv = 1.0 / step;
+        const float sc = (float)inv, bi = (float)(-e[0] * inv);
+        bool ok32 = std::isfinite(sc) && sc > 0.0f && std::isfinite(bi) && nb < (1 << 22);
+        double delta = 0.0;
+        float prev = -INFINITY;
+        for (int j = 0; j <= nb && ok32; ++j) {
+          float b = (float)e[j];  // boundary: the smallest float32 >= e_j; for the last edge the smallest float32 > e_last
+          if (j < nb ? (double)b < e[j] : (double)b <= e[j]) b = std::nextafterf(b, INFINITY);
+          ok32 = std::isfinite(b) && b > prev;
+          prev = b;
+          const float t1 = std::fmaf(b, sc, bi), t0 = std::fmaf(std::nextafterf(b, -INFINITY), sc, bi);
+          delta = std::max(delta, std::max(std::fabs((double)t1 - (double)j), std::fabs((double)t0 - (double)j)));
+        }
+        delta = 2.0 * delta + 0x1p-18;  // doubled, plus the rounding of f = t - floor(t) and of f - 0.5 in float32
+        if (ok32 && delta < 0.125) {
+          a32_scale = sc;
+          a32_bias = bi;
+          a32_h = (float)(0.5 - delta);
+          if ((double)a32_h > 0.5 - delta) a32_h = std::nextafterf(a32_h, 0.0f);
+        }
+      }
       if (ok)
         for (auto& dom : p->ts[0]) {
           dom.dim[d].step = step;
           dom.dim[d].inv_step = 1.0 / step;
           dom.dim[d].arith = 1;
           dom.dim[d].arith_h = arith_h;
+          dom.dim[d].a32_scale = a32_scale;
+          dom.dim[d].a32_bias = a32_bias;
+          dom.dim[d].a32_h = a32_h;
+          dom.dim[d].a32_top = (float)nb + 0.5f;
         }
+      all32 = all32 && ok && a32_h > 0.0f;
     }
     p->arith = all;
+    p->arith32 = all && all32;
   }
   // (not for arithmetic edges — bins=int, np.linspace: their digitize is one compare per bucket or table-free, the packed
   //  entries would never be picked, and every plan would pay their construction)
@@ -633,6 +665,8 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     p->pack_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "arith")) {
     p->arith_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
+  } else if (!strcmp(key, "arith32")) {
+    p->arith32_pref = value > 0 ? 1 : (value < 0 ? -1 : 0);
   } else if (!strcmp(key, "lds_copies")) {
     if (value != 0 && (value < 1 || value > 32 || (value & (value - 1)))) return fail(XHIST_ERR_INVALID, "lds_copies must be a power of two in [1, 32]");
     p->lds_copies = (int)value;
