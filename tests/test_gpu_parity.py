@@ -2458,7 +2458,11 @@ def test_bin_estimators_cut_float32_data_to_the_range_in_float32(xh, name):
     # (NumPy float64 / int64 scalars as bounds make numpy compare in float64 — those keep their value)
     for r in ((0.7, 1.0), (0.7, 0.7), (0.3, 1.1), (np.float64(0.7), 1.0), (np.float32(0.7), np.float64(1.0)), (0.7, np.float64(1.1)),
               (np.float64(0.0), np.float32(1.1))):
-        want = np.histogram_bin_edges(a, bins=name, range=r)
+        try:
+            want = np.histogram_bin_edges(a, bins=name, range=r)
+        except ValueError:  # numpy's own "stone" trips over elements its float32 keep-mask lets in below a float64 first edge
+            assert name == "stone"
+            continue
         got = xh._device_bin_edges(t, name, r, False)
         np.testing.assert_array_equal(got, want, err_msg=str((name, r)))
 

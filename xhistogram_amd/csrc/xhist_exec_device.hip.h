@@ -916,7 +916,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       cl2 = max_cl2;
       if (lds_copies) { cl2 = 0; while ((1 << cl2) < lds_copies) ++cl2; cl2 = std::min(cl2, max_cl2); }
       // + 32 trash slots; the padded layout of the float32 arithmetic digitize (one input): a bin in front and one behind instead
-      auto bytes_at = [&](int c) { return (padded_bins ? ((size_t)p->n_bins + 2) << c : ((size_t)p->n_bins << c) + 32) * (size_t)acc_size; };
+      // (2 x max(1, 32 >> c) bins of 2^c copies: 64 slots for every c <= 5)
+      auto bytes_at = [&](int c) { return (((size_t)p->n_bins << c) + (padded_bins ? (size_t)std::max(64, 2 << c) : 32)) * (size_t)acc_size; };
       if (!lds_copies) while (cl2 > 0 && bytes_at(cl2) > soft) --cl2;
       // short rows: a workgroup zeroes and reads back every copy, which must stay small next to the
       // samples it bins (10^5 rows x 1000 f32, 50 bins: 32 copies 0.162 ms, 4 copies 0.096 ms)

@@ -316,10 +316,14 @@ __device__ __forceinline__ int bin_arith_fast(double x, const DimTable& t, bool&
 // creation measures delta over every B_j AND its float32 predecessor with fmaf (correctly rounded on the host, v_fma_f32 on
 // the device: the same number).  6.5 vector-ALU instructions (the fma and the `- 0.5` are packed two samples to an
 // instruction) and ONE LDS operation per sample.
-// Returns floor(t) in [-1, nb] as an unsigned number: [0, nb) when the sample counts, 0xFFFFFFFF (below / NaN) or nb when not.
-__device__ __forceinline__ uint32_t bin_arith32_fast(float x, const DimTable& t, bool& near) {
+// Returns floor(t) in [-1 - pad_k, nb + pad_k] as an unsigned number: [0, nb) when the sample counts, outside when it does not.
+// pad_k (0 ... 31, a per-lane constant of the PADDED histogram layout of hist_fast): the clamp is widened to
+// [-0.5 - pad_k, nb + 0.5 + pad_k], so that what a lane drops lands in pad bin -1 - pad_k / nb + pad_k — dropped samples of a
+// wavefront spread over 32 LDS slots whatever the number of histogram copies (NaN-heavy data, the NaN padding of a ragged
+// tile: with ONE copy and one pad bin they met on one address between scattered adds, 3*10^6 samples 12 -> 19 us).
+__device__ __forceinline__ uint32_t bin_arith32_fast(float x, const DimTable& t, bool& near, float pad_k = 0.0f) {
   float tt = __builtin_fmaf(x, t.a32_scale, t.a32_bias);
-  tt = __builtin_amdgcn_fmed3f(tt, -0.5f, t.a32_top);
+  tt = __builtin_amdgcn_fmed3f(tt, -0.5f - pad_k, t.a32_top + pad_k);
   const float fl = __builtin_floorf(tt);
   const float f = tt - fl;
   near = !(__builtin_fabsf(f - 0.5f) < t.a32_h);
@@ -665,7 +669,7 @@ __device__ __forceinline__ int dt_size(int32_t dt) {
 // vector kernel (hist_fast, part_count).
 template <int CMP, int SCAN, int D, int UNROLL, int VEC, typename XV, typename TabPtr>
 __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const Params& p, TabPtr tab, int max_steps,
-                                               uint32_t (&cnt)[D][UNROLL][VEC]) {
+                                               uint32_t (&cnt)[D][UNROLL][VEC], float pad_k = 0.0f) {
   using CT = typename Dom<CMP>::T;
   if constexpr (SCAN == kScanArith) {
     // arithmetic edges: the bin by arithmetic alone for every sample that is not within delta bins of an edge
@@ -705,18 +709,30 @@ __device__ __forceinline__ void count_le_tile(const XV (&xv)[D][UNROLL], const P
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           bool near;
-          cnt[d][u][v] = bin_arith32_fast((float)xv[d][u][v], t, near);
+          cnt[d][u][v] = bin_arith32_fast((float)xv[d][u][v], t, near, pad_k);
           near_any |= near;
         }
     }
+    // The redo is per SAMPLE SLOT, behind a wave-uniform branch each: with 1000 bins a sample is `near` with probability
+    // 6e-4, so every second wavefront-batch of 1024-2048 samples holds one — redoing the whole batch of its lane in float64
+    // (16-32 samples x ~40 instructions) doubled the time of launch-bound calls (3*10^6 samples: 14 -> 28 us); finding the
+    // slot again costs 5 float32 instructions per slot, and the float64 compares run for the one or two slots that need them.
     if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {
-      if (near_any) {
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+      for (int d = 0; d < D; ++d) {
+        DimTable t = p.dim[d];
+        asm volatile("" : "+s"(t.a32_scale), "+s"(t.a32_bias), "+s"(t.a32_h), "+s"(t.a32_top));
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u)
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) cnt[d][u][v] = bin_arith32_exact((float)xv[d][u][v], p.dim[d]);
+          for (int v = 0; v < VEC; ++v) {
+            bool near;
+            (void)bin_arith32_fast((float)xv[d][u][v], t, near, pad_k);
+            if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+              const uint32_t e = bin_arith32_exact((float)xv[d][u][v], p.dim[d]);
+              cnt[d][u][v] = near ? e : cnt[d][u][v];
+            }
+          }
       }
     }
   } else if constexpr (scan_is_pack(SCAN) && CMP == 2) {  // float32 samples: exact in one compare per threshold
@@ -867,13 +883,16 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
   // samples the reference drops (out of range, NaN) still issue their LDS atomic, on one of 32 trash
   // slots picked by lane: with a single copy they would otherwise all meet on ONE address and
   // serialise (10^9 samples, 90 % out of range: 4.9 ms against 2.4)
-  // PADDED (one float32 input digitized by bin_arith32_fast, whose result is floor(t) in [-1, nb]): the replicated histogram
-  // has a bin -1 in front and a bin nb behind — the lane's own trash: the slot address is ONE shift-add of the result, no range
-  // compare, no select
+  // PADDED (one float32 input digitized by bin_arith32_fast, whose result is floor(t) clamped to [-pad, nb + pad)): the
+  // replicated histogram has `pad` = max(1, 32 / copies) bins in front and as many behind — 32 slots each way, the trash —
+  // so the slot address is ONE shift-add of the result: no range compare, no select.  A lane's clamp is widened by
+  // pad_k = (lane mod 32) / copies bins, which spreads what a wavefront drops over all 32 slots.
   constexpr bool PADDED = SCAN == kScanArith32 && D == 1 && LDS_HIST && !SLICED;
+  const uint32_t pad_bins = PADDED ? max(1u, 32u >> p.copies_log2) : 0u;
+  const float pad_k = PADDED ? (float)(((uint32_t)tid & 31u) >> p.copies_log2) : 0.0f;
   const uint32_t trash = PADDED ? mycopy : (hb << p.copies_log2) + ((uint32_t)tid & 31u);
   uint32_t* packed = reinterpret_cast<uint32_t*>(hist);
-  const uint32_t hist_elems = PADDED ? ((hb + 2u) << p.copies_log2) : (hb << p.copies_log2) + 32u;  // one replicated histogram (+ trash slots)
+  const uint32_t hist_elems = PADDED ? ((hb + 2u * pad_bins) << p.copies_log2) : (hb << p.copies_log2) + 32u;  // one replicated histogram (+ trash slots)
   lds_t* hist2 = hist + hist_elems;                                          // W2: the second weight's
   if (LDS_HIST) {
     const uint32_t n = hist_elems * (W2 ? 2u : 1u);
@@ -913,7 +932,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 
   // D == 1 fast scatter (see the tile loop): this lane's copy of bin -1, and its trash slot
   const uint32_t slot_shift = (uint32_t)p.copies_log2 + (sizeof(lds_t) == 8 ? 3u : 2u);
-  unsigned char* slot_base0 = reinterpret_cast<unsigned char*>(hist + mycopy) + (PADDED ? ((size_t)1 << slot_shift) : 0);  // this lane's copy of bin 0
+  unsigned char* slot_base0 = reinterpret_cast<unsigned char*>(hist + mycopy) + ((size_t)pad_bins << slot_shift);  // this lane's copy of bin 0
   unsigned char* slot_base = slot_base0 - ((size_t)1 << slot_shift);             // ... of "bin -1": addressed by edge counts
   lds_t* trash_slot = hist + trash;
   auto scatter = [&](bool ok, uint32_t flat, double w, double w2) {
@@ -1041,7 +1060,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     }
     {
       uint32_t cnt[D][UNROLL][VEC];  // #{edges <= x} per sample and dimension
-      count_le_tile<CMP, SCAN, D, UNROLL, VEC>(xv, p, tab, max_steps, cnt);
+      count_le_tile<CMP, SCAN, D, UNROLL, VEC>(xv, p, tab, max_steps, cnt, pad_k);
       bool okv[UNROLL][VEC];
       uint32_t flatv[UNROLL][VEC], oldv[UNROLL][VEC];
 #pragma unroll
@@ -1049,7 +1068,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           if constexpr (PADDED) {
-            lds_t* slot = reinterpret_cast<lds_t*>(slot_base0 + (cnt[0][u][v] << slot_shift));  // [-1, nb] -> the pad bins catch the dropped
+            lds_t* slot = reinterpret_cast<lds_t*>(slot_base0 + (cnt[0][u][v] << slot_shift));  // [-pad, nb + pad) -> the pad bins catch the dropped
             if (kWeighted) {
               unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
               if constexpr (W2) unsafeAtomicAdd(reinterpret_cast<double*>(slot) + hist_elems, (double)wv2[u][v]);
@@ -1134,7 +1153,7 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
     const uint32_t copies = 1u << p.copies_log2;
     for (uint32_t b = tid; b < hb; b += blockDim.x) {
       typename std::conditional<kWeighted, double, unsigned long long>::type sum = 0;
-      for (uint32_t c = 0; c < copies; ++c) sum += hist[((b + (PADDED ? 1u : 0u)) << p.copies_log2) + ((c + tid) & cmask)];
+      for (uint32_t c = 0; c < copies; ++c) sum += hist[((b + pad_bins) << p.copies_log2) + ((c + tid) & cmask)];
       if (p.direct_store) out[b] = (out_t)sum;  // the only workgroup of this row: plain store, zeros included
       else if (sum != 0) A::out_add(out, (int64_t)b, sum);
       if constexpr (W2) {

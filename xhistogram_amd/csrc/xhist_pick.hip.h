@@ -28,6 +28,7 @@ typedef void (*kernel_fn_acc_chunks)(const RouteArgs, void*, int64_t, int, int, 
 // SCAN edge values in VGPRs, and 1024-thread workgroups leave 128 VGPRs per lane.
 constexpr int unroll_for(int D, int vec, int scan) {
   if (scan_is_pack(scan)) scan = 2;  // packed bucket entries: one 16-byte entry per sample and dimension, as the two-edge scan
+  if (scan == kScanArith32) scan = 1;  // float32 arithmetic: lighter than the one-edge scan (the host sizes tiles and grids by this too)
   int cap = D == 1 ? 16 : (D == 2 ? 8 : 4);
   if (D >= 2 && scan >= 3) cap /= 2;
   if (D == 1 && scan >= 3 && vec == 4) cap = 8;
@@ -107,7 +108,7 @@ static kernel_fn fast_pick_arith32(int hist) {
     constexpr bool unweighted = std::is_same<WT, NoWeight>::value;
     constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
     constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
-    constexpr int U = unroll_for(D, VEC, 1);
+    constexpr int U = unroll_for(D, VEC, kScanArith32);
     if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith32>;
   }
   return nullptr;

@@ -318,24 +318,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         w[u] = __builtin_nontemporal_load(reinterpret_cast<const w4*>(reinterpret_cast<const char*>(wp + row * p.w_rs + origin) + e * (uint32_t)sizeof(wscalar)));
     }
   };
-  // EARLY (off): issuing the loads of tile k + 1 at the TOP of iteration k, into registers of their own, keeps them in
-  // flight through digitize and rank as well — and is SLOWER, twice over.  First form: 3.35 -> 3.46 ms (C5 shard, 512-thread
-  // workgroups), because with tile 0 still pending at the loop header the compiler had to place a wait at the top of the loop
-  // that on the way round meant "the stores of the last tile have completed" (gfx950 counts loads and stores with one
-  // in-order counter).  With the first tile drained ahead of the loop (the empty asm below) that wait is gone and the pass
-  // still takes 3.47 ms against 3.35-3.37 (1024 threads: 3.56 against 3.43-3.48; gpurun r03_e / r03_p): like the bare-traffic
-  // sweeps (profiles/r03_a_*, r03_d_*: the best geometries keep 24-48 KB per CU in flight, not more), this chip moves a
-  // read-write mix FASTER with fewer bytes in flight.  The late prefetch below has a tile's loads in flight during scan and
-  // sort only.  Kept as a switch.
-  constexpr bool EARLY = false;
+  // (Issuing the loads of tile k + 1 at the TOP of iteration k, into registers of their own, was tried and is slower — 3.35 ->
+  // 3.46 ms for a C5 shard: this chip moves a read-write mix faster with FEWER bytes in flight, HISTORY 4.3.  The late prefetch
+  // below has a tile's loads in flight during scan and sort only.)
   // WSPLIT: the weights of a tile are not needed before its records are sorted, so they are loaded at the top of the tile's
   // OWN iteration (and waited for ahead of the sort) instead of with the samples of the tile a whole iteration earlier:
   // the loads of a workgroup come in two smaller bursts, and the registers of the second weight buffer are free
-  constexpr bool WSPLIT = kWeighted && !EARLY;
-  s4 xv[D][U], xn[EARLY ? D : 1][U];
+  constexpr bool WSPLIT = kWeighted;
+  s4 xv[D][U];
   w4 w[U], wn[U];
   load_tile(tile_base(0), tile_row(0), xv, w, true, !WSPLIT);
-  if constexpr (EARLY || WSPLIT) {  // (tile 0 has arrived before the loop is entered: see EARLY)
+  if constexpr (WSPLIT) {  // (tile 0 has arrived before the loop is entered)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (kWeighted && !WSPLIT) asm volatile("" : "+v"(w[u]));
@@ -344,18 +337,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
   int cur_set = 0;
-#ifdef XHIST_ROUTE_TIMING  // development build only: where a workgroup's cycles go, phase by phase (wave 0's clock)
-  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define XH_T(i) do { const long long now_ = clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
-  long long tlast = clock64();
-#else
-#define XH_T(i) do { } while (0)
-#endif
   for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
-    if constexpr (EARLY) {
-      const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
-      load_tile(tile_base(kn), tile_row(kn), xn, wn);
-    }
     if constexpr (WSPLIT) load_tile(tile_base(k), tile_row(k), xv, w, false, true);
     const int64_t base = tile_base(k);
     const uint32_t row_off = (uint32_t)tile_row(k) * ((uint32_t)p.parts_per_row << shift);  // this row's first partition, as a flat index
@@ -429,7 +411,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         flat[u][v] = ok ? fl + row_off : 0xffffffffu;
       }
     }
-    XH_T(0);  // wait for the tile's loads + digitize
     uint32_t rank[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -437,13 +418,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int v = 0; v < 4; ++v) rank[u][v] = (flat[u][v] != 0xffffffffu) ? atomicAdd(cnt + (flat[u][v] >> shift), 1u) : 0u;
     // the next tile's loads (the tile after the last one is the last one again: one redundant load per
     // workgroup instead of a branch around loads); waited for just before this tile's stores go out
-    if constexpr (!EARLY) {
+    {
       const int64_t kn = k + 1 < my_tiles ? k + 1 : k;
       load_tile(tile_base(kn), tile_row(kn), xv, wn, true, !WSPLIT);
     }
-    XH_T(1);  // rank atomics issued (+ next tile's loads issued)
     __syncthreads();
-    XH_T(2);  // barrier 1 (waits for every wave's digitize + ranks)
     // ---- block layout (as in part_scatter) + record space of every partition's block: LDS only -------
     if (tid < ((P + 63) & ~63)) {
       const int lane = tid & 63;
@@ -496,9 +475,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       }
     }
     if (tid < 256) cnt2[((cur_set ^ 1) << 8) + tid] = 0u;
-    XH_T(3);  // scan / block layout (wave 0 works, the others wait)
     __syncthreads();
-    XH_T(4);  // barrier 2
     // ---- the tile, sorted by partition, into LDS -----------------------------------------------------
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -541,13 +518,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
       }
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        if constexpr (EARLY) xv[d][u] = xn[d][u];
         asm volatile("" : "+v"(xv[d][u]));
       }
     }
-    XH_T(5);  // sort into LDS (+ wait for the weights, + the prefetch's arrival)
     __syncthreads();
-    XH_T(6);  // barrier 3
     const uint32_t total = misc[0];
     // ---- records out: one lane per group of 8 codes / per 16 bytes of weights -------------------------
     for (uint32_t g0 = (uint32_t)tid * GRP; g0 < total; g0 += BLOCK * GRP) {
@@ -617,18 +591,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     // no barrier here: the next tile's ranking touches only the other counter set, and nobody passes
     // that tile's first barrier before every lane has finished this write-out
-    XH_T(7);  // records out (stores issued) + id stock
   }
-#ifdef XHIST_ROUTE_TIMING
-  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255)) {
-    long long tot = 0;
-    for (int i = 0; i < 8; ++i) tot += tph[i];
-    printf("route_timing wg %d tiles %lld cycles/tile %lld : load+digitize %lld | rank %lld | bar1 %lld | scan %lld | bar2 %lld | sort %lld | bar3 %lld | out %lld\n",
-           (int)blockIdx.x, (long long)my_tiles, tot / my_tiles, tph[0] / my_tiles, tph[1] / my_tiles, tph[2] / my_tiles, tph[3] / my_tiles, tph[4] / my_tiles,
-           tph[5] / my_tiles, tph[6] / my_tiles, tph[7] / my_tiles);
-  }
-#endif
-#undef XH_T
   __syncthreads();
   // the last group of each partition (carried records padded with neutral ones), the fill of the chunk in use,
   // and this workgroup's chunk lists handed over to the partitions' global lists
