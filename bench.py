@@ -508,7 +508,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     main_leg = args.scaling
     # sub-millisecond kernels (the C4 shard): the first launches after an idle GPU are reported next to the steady rate
     cold = 20 if (args.config == "c4" and not args.full and not args.selftest and not args.profiler_pass) else 0
-    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold, time_first=not as_extra)
+    legs[main_leg] = run_leg(cols_weak if main_leg == "weak" else cols_strong, args.steps, args.warmup, cold=cold, time_first=not as_extra and not args.profiler_pass)
     # the headline's 8 B/sample variant — north_star's target sentence is the 1-D 10^9-sample f64 histogram WITHOUT weights
     # (BASELINE.md section 3 "headline unweighted variant") — rides along on the same samples: `"unweighted": {...}`
     unweighted_leg = None

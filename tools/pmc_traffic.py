@@ -74,7 +74,8 @@ def main():
         total, per_kernel = 0.0, {}
         for k, (nd, f_kb) in fetch.items():
             w_kb = write.get(k, (0, 0.0))[1]
-            per_step = nd / float(bench["steps"] + bench["warmup"])  # launches of this kernel per step
+            # launches of this kernel per step (a line with "first_call_ms" timed one more launch ahead of the warm-up)
+            per_step = nd / float(bench["steps"] + bench["warmup"] + (1 if "first_call_ms" in bench else 0))
             b = (2.0 * f_kb + w_kb) * 1024.0 * per_step
             per_kernel[re.sub(r"\(.*", "", k)[:80]] = {"fetch_KB_avg": f_kb, "write_KB_avg": w_kb, "launches_per_step": per_step, "hbm_bytes_per_step": b}
             total += b
