@@ -223,8 +223,7 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       "arith32" (0 auto / 1 prefer / -1 never: float32 samples on such edges digitized in float32 arithmetic),
  *       "pack" (0 auto / 1 whenever the plan has them / -1 never: packed 16-byte bucket entries — one LDS read per sample and
  *       dimension — for float64 / float32 samples on non-uniform edges, on a linear or a float-bit-pattern (logarithmic) grid),
- *       "route_grid", "acc_grid" (workgroups of the routing / adding-up pass of the multi-pass mode; 0 auto), "route_lean" (0 auto / -1: never
- *       the two-workgroups-per-CU routing kernel of float64 samples with packed records),
+ *       "route_grid", "acc_grid" (workgroups of the routing / adding-up pass of the multi-pass mode; 0 auto),
  *       "slices" (0 auto / 1 prefer / -1 never: histograms of a few times the LDS capacity in bin slices),
  *       "route_spl" (0 auto / 4: never the long 8-samples-per-lane tile) and "min_parts"
  *       (0 auto = 16 / 1 = as few as the histogram's size asks for / up to 128: partitions per row) shape the routing pass of

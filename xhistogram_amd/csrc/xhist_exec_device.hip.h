@@ -270,18 +270,12 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   // (Round 4 also ran the adding-up pass of sample sub-batch k on a second stream under the routing pass of sub-batch k + 1:
   // 25-60 % slower, both passes scale with the compute units they get — DESIGN_HISTORY 4.2b, profiles/r04_b_*; removed in
   // round 5.)
-  int route_grid = 0, acc_grid = 0, lean_pref = 0;
+  int route_grid = 0, acc_grid = 0;
   {
     std::lock_guard<std::mutex> lk(p->mu);
     route_grid = p->route_grid;
     acc_grid = p->acc_grid;
-    lean_pref = p->route_lean;
   }
-  // float64 samples, packed records, arithmetic edges, one row: the routing pass that fits a CU twice (part_route_lean)
-  kernel_fn_route k_lean = (pack && sdt == XHIST_F64 && scan == kScanArith && rows == 1 && n_parts <= kLeanParts && spl == 4 && lean_pref >= 0)
-                               ? xhist_pick_route_lean(D) : nullptr;
-  const size_t lds_lean = part_route_lean_lds(n_parts);
-  if (k_lean && lds_lean > (size_t)80 * 1024) k_lean = nullptr;
   const int64_t n_piece = n_total;  // samples one routing pass sees
   const int64_t n_tiles = ((n_cols + tile - 1) / tile) * rows;
   // workgroups resident per CU: by LDS — and by registers: the routing pass is held to 128 per lane (waves_per_eu 4), so a
@@ -290,29 +284,20 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   const int per_cu = std::max<int>(1, std::min<int>(std::min<int>(4, 1024 / block), (int)((size_t)160 * 1024 / lds_route)));
   int G = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * per_cu, n_tiles));
   int Gb = (int)std::max<int64_t>(1, std::min<int64_t>(p->cus, (n_piece + 65535) / 65536));
-  int G_lean = k_lean ? (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)p->cus * 2, n_tiles)) : 0;
-  if (route_grid) {
-    G = (int)std::min<int64_t>(route_grid, n_tiles);
-    if (k_lean) G_lean = G;
-  }
+  if (route_grid) G = (int)std::min<int64_t>(route_grid, n_tiles);
   if (acc_grid) Gb = acc_grid;
-  const int G_pool = std::max(G, G_lean);  // the routing grid the chunk pool has to serve
   // chunk size: a workgroup files at most kRouteListCap chunks (its list lives in LDS), 2^10 .. 2^14 records each
   int lg = 10;
-  while (lg < 14 && (((n_piece / std::min(G, G_lean ? G_lean : G)) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
+  while (lg < 14 && (((n_piece / G) + tile) >> lg) + n_parts + 16 > route_list_cap(block)) ++lg;
   static const int lg_env = [] { const char* e = getenv("XHIST_AMD_ROUTE_CHUNK_LOG2"); return e && *e ? atoi(e) : 0; }();  // A/B runs only
   if (lg_env >= 10 && lg_env <= 14 && lg_env > lg) lg = lg_env;
-  const int64_t GP = (int64_t)G_pool * n_parts;
-  // ... and few enough chunks for every workgroup of the adding-up pass to stage its share of the chunk lists in ONE batch
-  // (a second, nearly empty batch costs a round trip to the lists and two barriers: with the 512 routing workgroups of
-  // part_route_lean the C5 shard has 276 000 chunks of 2048 records for 256 x 1024 list slots, 0.71 -> 0.75 ms)
-  while (lg < 14 && ((n_piece + 7 * GP) >> lg) + GP > (int64_t)Gb * kAccBatch) ++lg;
+  const int64_t GP = (int64_t)G * n_parts;
   // Chunks that hold records: every chunk but the one in use by its (workgroup, partition) owner is full, and at most 7
   // padding records are added per owner.  Ids taken from the pool but never used: a workgroup's stock drops fewer ids than
   // its largest request whenever a range of `batch` ids runs out (batch >= 8 x that request: < 1/7 of the ids it served),
   // and ends with at most two ranges in hand.
   const int64_t used = ((n_piece + 7 * GP) >> lg) + GP;
-  int64_t pool_chunks = used + used / 6 + (int64_t)G_pool * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
+  int64_t pool_chunks = used + used / 6 + (int64_t)G * (2 * route_batch(n_parts, lg, tile) + 2 * route_max_need(lg, tile)) + 64;
   // "route_pool_pct" < 100 (tests): a pool too small on purpose — what finds no chunk goes straight into the output
   if (p->route_pool_pct > 0 && p->route_pool_pct < 100) pool_chunks = std::max<int64_t>(1, pool_chunks * p->route_pool_pct / 100);
   if (pool_chunks >= ((int64_t)1 << 31) || (pool_chunks << lg) >= ((int64_t)1 << 44)) return XHIST_ERR_UNSUPPORTED;
@@ -348,7 +333,6 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
                                         : (kernel_fn_acc_chunks)part_accumulate_chunks<false, double>;
   if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
   kernel_fn_acc_chunks k_acc48 = (kernel_fn_acc_chunks)part_accumulate_chunks<true, double, true>;
-  if (k_lean && lds_lean > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
   if (pack) {
     if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
     if (lds_acc > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_acc48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
@@ -405,8 +389,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     if (int zrc = zero_output(ctr, ctr_words * 2, stream)) return release(zrc);
     RouteArgs ra48 = ra;
     if (pack) {
-      if (k_lean) XH_LAUNCH_PICKED(k_lean, dim3(G_lean), dim3(block), lds_lean, stream, kp, ra);  // packed records, two workgroups per CU
-      else XH_LAUNCH_PICKED(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
+      XH_LAUNCH_PICKED(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
       HIPR(hipGetLastError());
       ra48.gate = ctr + 1;
       ra48.gate_mode = 1;  // one sign: add the packed records up
@@ -431,10 +414,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s lean=%d",
-             rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, k_lean ? G_lean : G, Gb, k_lean ? lds_lean : lds_route, lds_acc, scan,
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
+             rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
-             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64", k_lean ? 1 : 0);
+             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }
@@ -1217,10 +1200,7 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
           const int t4 = route_tile(geom.block, geom.spl);
           const size_t lds_tab = part_route_lds((size_t)tset->words * 8, (int)n_parts, weighted, t4, geom.block),
                        lds_notab = part_route_lds(0, (int)n_parts, weighted, t4, geom.block);
-          // (the two-per-CU routing kernel of float64 samples with packed float64 records digitizes by arithmetic only)
-          const bool lean_wanted = sdt == XHIST_F64 && w_tag == XHIST_F64 && D <= 2 && n_parts <= kLeanParts && p->route_lean >= 0 &&
-                                   p->records48_pref >= 0 && !exact_records_env();
-          if (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab || lean_wanted) {
+          if (lds_tab > p->lds_max || (size_t)160 * 1024 / lds_notab > (size_t)160 * 1024 / lds_tab) {
             r_scan = kScanArith;
             r_tset = &p->ts[0][0];
             r_f32 = false;

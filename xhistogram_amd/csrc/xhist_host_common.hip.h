@@ -437,7 +437,6 @@ struct xhist_plan {
   int route_spl = 0;       // routing pass: samples per lane and tile (0 auto; 4; 8 = auto: the long tile exists only where auto picks it)
   int flat_rows = 0;       // dense short rows streamed flat (hist_flat_rows): -1 off, 0 auto, 1 for any row length below 65536
   int min_parts = 0;       // partitioned mode: bins are cut finer until a pass has this many partitions (0 auto = 16; 1 = never)
-  int route_lean = 0;  // routing pass of float64 samples with packed records on arithmetic edges: 0 two workgroups per CU (part_route_lean), -1 the general kernel
   int route_grid = 0, acc_grid = 0;  // workgroups of the routing / adding-up pass of execute_partitioned_fused (0 auto) — scaling runs
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never

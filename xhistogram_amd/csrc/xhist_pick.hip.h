@@ -285,4 +285,3 @@ kernel_fn_flat xhist_pick_flat_rows(int sdt, int wdt, int D, int scan);  // hist
 XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 1024s8)
 XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 1024s8)
 #undef XH_ROUTE_TU
-kernel_fn_route xhist_pick_route_lean(int D);  // part_route_lean<D> (xhist_route_f64_b1024.hip); nullptr: no such variant

@@ -658,8 +658,6 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
   } else if (!strcmp(key, "route_grid")) {
     if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "route_grid must be in [0, 4096]");
     p->route_grid = (int)value;
-  } else if (!strcmp(key, "route_lean")) {
-    p->route_lean = value < 0 ? -1 : 0;
   } else if (!strcmp(key, "acc_grid")) {
     if (value < 0 || value > 4096) return fail(XHIST_ERR_INVALID, "acc_grid must be in [0, 4096]");
     p->acc_grid = (int)value;

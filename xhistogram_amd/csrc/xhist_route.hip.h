@@ -642,315 +642,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// part_route_lean — the routing pass of BASELINE C5's case (float64 samples on arithmetic edges, float64 weights as packed
-// 48-bit records, one row) cut down until TWO 1024-thread workgroups fit a CU: <= 64 registers a lane, <= 80 KB of LDS
-// (VERDICT r4 "next" #1).  What went: the second sort array (a packed record carries its code; the partition of a GROUP of
-// 8 slots is one byte), control arrays sized for 256 partitions (128 here), the register prefetch of the next tile — the
-// other workgroup's phases are what runs under a tile's loads now, so a tile's samples are loaded at the top of its own
-// iteration and its weights after the digitize has freed the samples' registers.  Chunk lists, carries and the id stock are
-// those of part_route.  DESIGN 4.2 has what the bare-traffic sweeps let one expect from this (2-6 %) and what it measured.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kLeanParts = 128;
-__host__ __device__ constexpr int route_lean_ctl() { return 10 * 1024 + 2 * 4 * kRouteBlock; }  // control arrays below + chunk lists
-__host__ __device__ constexpr size_t part_route_lean_lds(int P) {
-  const size_t S = (size_t)part_route_slots(P, route_tile(kRouteBlock, 4));
-  return (size_t)route_lean_ctl() + (size_t)P * kRouteGrp * 8 + S * 8 + ((S / kRouteGrp + 15) & ~(size_t)15) + 64;
-}
-
-template <int D>
-__global__ void __launch_bounds__(kRouteBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) part_route_lean(const Params p, const RouteArgs ra) {
-  constexpr int BLOCK = kRouteBlock, kTile = route_tile(BLOCK, 4), GRP = kRouteGrp, PM = kLeanParts;
-  constexpr uint32_t kGm = GRP - 1;
-  typedef double s4 __attribute__((ext_vector_type(4), aligned(8)));
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  if (route_gate_closed(ra)) return;
-  const int tid = threadIdx.x;
-  const int P = p.n_parts, shift = p.part_shift, lg = ra.chunk_log2;
-  const uint32_t CH = 1u << lg;
-  const int64_t n = p.n_cols;
-  bool any_neg = false, any_pos = false;  // signs of the weights this lane read: lane masks in scalar registers, no VGPR
-  unsigned char* ctl = xhist_smem;
-  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(ctl);             // [2][PM] rank counters, alternating per tile
-  uint32_t* cin2 = cnt2 + 2 * PM;                                 // [2][PM] carried records per partition
-  uint64_t* delta = reinterpret_cast<uint64_t*>(ctl + 2048);      // [PM]
-  uint64_t* delta2 = delta + PM;                                  // [PM]
-  uint32_t* first = reinterpret_cast<uint32_t*>(ctl + 4096);      // [PM]
-  uint32_t* endw = first + PM;
-  uint32_t* enda = endw + PM;
-  uint32_t* split = enda + PM;
-  uint64_t* o_cur = reinterpret_cast<uint64_t*>(ctl + 6144);      // [PM]
-  uint64_t* o_cend = o_cur + PM;                                  // [PM]
-  uint32_t* head = reinterpret_cast<uint32_t*>(ctl + 8192);       // [PM]
-  uint32_t* ccnt = head + PM;                                     // [PM]
-  uint32_t* misc = ccnt + PM;                                     // [16]  (ctl + 9216)
-  uint32_t* cl_id = reinterpret_cast<uint32_t*>(ctl + 10240);     // [BLOCK] chunk ids filed by this workgroup ...
-  uint32_t* cl_prev = cl_id + BLOCK;                              // ... chained per partition
-  uint32_t* stock = misc + 4;
-  unsigned char* dyn = ctl + route_lean_ctl();
-  double* carry_w = reinterpret_cast<double*>(dyn);               // [P][GRP] packed records carried to the next tile
-  dyn += (size_t)P * GRP * 8;
-  const int S = part_route_slots(P, kTile);
-  double* sw = reinterpret_cast<double*>(dyn);                    // [S] the tile's packed records, sorted by partition
-  dyn += (size_t)S * 8;
-  unsigned char* gq = dyn;                                        // [S / GRP] partition of every group of 8 slots
-  double* __restrict__ wrec = static_cast<double*>(ra.wrec);
-  const double* wp = reinterpret_cast<const double*>(p.w_ptr);
-  const double* sp[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) sp[d] = reinterpret_cast<const double*>(p.s_ptr[d]);
-  const uint32_t code_mask = (1u << shift) - 1u;
-  const uint32_t batch = (uint32_t)route_batch(P, lg, kTile), max_need = (uint32_t)route_max_need(lg, kTile);
-  for (int i = tid; i < PM; i += BLOCK) {
-    cnt2[i] = 0u;
-    cnt2[PM + i] = 0u;
-    cin2[i] = 0u;
-    cin2[PM + i] = 0u;
-    o_cur[i] = 0;
-    o_cend[i] = 0;
-    head[i] = 0xffffffffu;
-    ccnt[i] = 0u;
-  }
-  if (tid == 0) {
-    const uint32_t b = atomicAdd(ra.pool, 2u * batch);
-    stock[0] = b;
-    stock[1] = b + batch;
-    stock[2] = b + batch;
-    stock[3] = b + 2u * batch;
-    misc[1] = 0u;
-  }
-  bool refill_pending = false;
-  uint32_t refill_ids = 0;
-  __syncthreads();
-  auto file_chunk = [&](int q, uint32_t id) {
-    const uint32_t e = atomicAdd(misc + 1, 1u);
-    if (e < (uint32_t)BLOCK) {
-      cl_id[e] = id;
-      cl_prev[e] = head[q];
-      head[q] = e;
-      ccnt[q] += 1u;
-    } else {
-      ra.plist[(size_t)q * ra.list_cap + atomicAdd(ra.pcount + q, 1u)] = id;
-    }
-  };
-  const int64_t n_tiles = (n + kTile - 1) / kTile;
-  const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  int cur_set = 0;
-  for (int64_t k = 0; k < my_tiles; ++k, cur_set ^= 1) {
-    const int64_t base = ((int64_t)blockIdx.x + k * gridDim.x) * kTile;
-    const bool ragged = base + kTile > n;
-    const int64_t origin = min(base, n - 4);
-    const uint32_t last = (uint32_t)min(n - 4 - origin, (int64_t)kTile);
-    const uint32_t e_off = min((uint32_t)tid * 4u, last) * 8u;  // byte offset of this lane's quad inside the tile
-    const int sh = ragged ? (int)min(base + (int64_t)tid * 4 - min(base + (int64_t)tid * 4, n - 4), (int64_t)4) : 0;
-    uint32_t* cnt = cnt2 + cur_set * PM;
-    const uint32_t* cin = cin2 + cur_set * PM;
-    // ---- this tile's samples -> flat bin index per sample (0xFFFFFFFF = dropped) ---------------------------------
-    uint32_t flat[4];
-    {
-      s4 xv[D];
-#pragma unroll
-      for (int d = 0; d < D; ++d)
-        xv[d] = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(sp[d] + origin) + e_off));
-      if (ragged) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) xv[d] = pulled_back(xv[d], sh, (double)__builtin_nanf(""));
-      }
-      int bins[D][4];
-      bool near_any = false;
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        DimTable t = p.dim[d];
-        asm volatile("" : "+s"(t.e0_f), "+s"(t.inv_step), "+s"(t.arith_h), "+s"(t.nb));
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          bool near;
-          bins[d][v] = bin_arith_fast(xv[d][v], t, near);
-          near_any |= near;
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(near_any) != 0ull) {
-        if (near_any) {
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            DimTable t = p.dim[d];
-            asm volatile("" : "+s"(t.e0_f), "+s"(t.eL_f), "+s"(t.step), "+s"(t.inv_step), "+s"(t.nb));
-#pragma unroll
-            for (int v = 0; v < 4; ++v) bins[d][v] = bin_from_count<0>(xv[d][v], t, count_le_arith(xv[d][v], t));
-          }
-        }
-      }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        bool ok = true;
-        uint32_t fl = 0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const int b = bins[d][v];
-          ok &= (b >= 0);
-          fl = (d == 0) ? (uint32_t)b : fl * (uint32_t)p.dim[d].nb + (uint32_t)b;
-        }
-        flat[v] = ok ? fl : 0xffffffffu;
-      }
-    }
-    // ---- the weights: in flight through ranking, barrier and block layout -----------------------------------------
-    s4 wv = __builtin_nontemporal_load(reinterpret_cast<const s4*>(reinterpret_cast<const char*>(wp + origin) + e_off));
-    uint32_t rank[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) rank[v] = (flat[v] != 0xffffffffu) ? atomicAdd(cnt + (flat[v] >> shift), 1u) : 0u;
-    __syncthreads();
-    // ---- block layout + record space of every partition's block (as in part_route) ------------------------------
-    if (tid < ((P + 63) & ~63)) {
-      const int lane = tid & 63;
-      const uint32_t c_in = tid < P ? cin[tid] : 0u;
-      const uint32_t T = c_in + (tid < P ? cnt[tid] : 0u);
-      const uint32_t block = (T + kGm) & ~kGm;
-      const uint32_t x = wave_inclusive_scan_u32(block);
-      uint32_t before = 0;
-      if (__builtin_amdgcn_readfirstlane(tid) >= 64) {
-        for (int q = lane; q < (tid & ~63); q += 64) before += (cin[q] + cnt[q] + kGm) & ~kGm;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-      }
-      const uint32_t B = before + x - block;
-      if (tid < P) {
-        const uint32_t whole = T & ~kGm;
-        first[tid] = B + c_in;
-        endw[tid] = B + whole;
-        enda[tid] = B + T;
-        uint64_t cur = o_cur[tid];
-        const uint64_t cend = o_cend[tid];
-        delta[tid] = cur - B;
-        const uint64_t room = cend - cur;
-        if (whole <= room) {
-          split[tid] = 0xffffffffu;
-          o_cur[tid] = cur + whole;
-        } else {
-          const uint32_t n1 = (uint32_t)room, rest = whole - n1;
-          const uint32_t need = (rest + CH - 1) >> lg;
-          if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
-          uint32_t id0 = route_take_ids(stock, need);
-          if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, need);
-          split[tid] = B + n1;
-          if ((uint64_t)id0 + need <= ra.list_cap) {
-            for (uint32_t i = 0; i < need; ++i) file_chunk(tid, id0 + i);
-            for (uint32_t i = 0; i + 1 < need; ++i) ra.cmeta[id0 + i] = ((uint32_t)tid << 20) | CH;
-            const uint64_t nb = (uint64_t)id0 << lg;
-            delta2[tid] = nb - (B + n1);
-            o_cur[tid] = nb + rest;
-            o_cend[tid] = nb + ((uint64_t)need << lg);
-          } else {  // the pool is dry: packed records report "both signs", the exact pass queued behind redoes the call
-            delta2[tid] = kRouteDirect;
-            o_cur[tid] = cend;
-            if (ra.dry) *ra.dry = 1u;
-            atomicOr(ra.flags, 3u);
-          }
-        }
-        cin2[(cur_set ^ 1) * PM + tid] = T - whole;
-        if (tid == P - 1) misc[0] = B + block;
-      }
-    }
-    if (tid < PM) cnt2[(cur_set ^ 1) * PM + tid] = 0u;
-    __syncthreads();
-    // ---- the tile's packed records, sorted by partition, into LDS ------------------------------------------------
-    if (ragged) wv = pulled_back(wv, sh, 0.0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (flat[v] != 0xffffffffu) {
-        const uint32_t part = flat[v] >> shift;
-        const uint32_t slot = first[part] + rank[v];
-        sw[slot] = pack48(wv[v], flat[v] & code_mask);
-        gq[slot >> 3] = (unsigned char)part;  // (every slot of a group writes the same byte: blocks are whole groups)
-      }
-      any_neg |= wv[v] < 0.0;
-      any_pos |= wv[v] > 0.0;
-    }
-    for (int t = tid; t < P * GRP; t += BLOCK) {  // the carried records go to the head of their block
-      const int q = t / GRP, i = t % GRP;
-      const uint32_t c = cin[q];
-      if ((uint32_t)i < c) {
-        const uint32_t slot = first[q] - c + (uint32_t)i;
-        sw[slot] = carry_w[t];
-        gq[slot >> 3] = (unsigned char)q;
-      }
-    }
-    __syncthreads();
-    const uint32_t total = misc[0];
-    // ---- records out: one lane per 16 bytes --------------------------------------------------------------------
-    for (uint32_t t0 = (uint32_t)tid * 2u; t0 < total; t0 += BLOCK * 2u) {
-      const uint32_t g0 = t0 & ~kGm;
-      const uint32_t q = gq[g0 >> 3];
-      if (g0 + GRP <= endw[q]) {
-        const uint64_t dlt = g0 < split[q] ? delta[q] : delta2[q];
-        if (dlt == kRouteDirect) continue;
-        const d2 wq = *reinterpret_cast<const d2*>(sw + t0);
-        __builtin_nontemporal_store(wq, reinterpret_cast<d2*>(wrec + dlt + t0));
-      } else if (t0 == g0) {
-        const uint32_t left = enda[q] - g0;  // 1 .. GRP-1 records: the carry
-        for (uint32_t i = 0; i < left; ++i) carry_w[q * GRP + i] = sw[g0 + i];
-      }
-    }
-    if (tid == 0) {
-      if (refill_pending) {
-        if (stock[2] >= stock[3]) {
-          stock[2] = refill_ids;
-          stock[3] = refill_ids + batch;
-        }
-        refill_pending = false;
-      }
-      if (stock[0] + max_need > stock[1] && stock[2] < stock[3]) {
-        stock[0] = stock[2];
-        stock[1] = stock[3];
-        stock[2] = stock[3] = 0u;
-      }
-      if (stock[2] >= stock[3]) {
-        refill_ids = atomicAdd(ra.pool, batch);
-        refill_pending = true;
-      }
-    }
-    // no barrier here (as in part_route): the next tile's ranking touches only the other counter set, and nobody passes
-    // that tile's first barrier before every lane has finished this write-out
-  }
-  __syncthreads();
-  if (tid < P) {
-    const uint32_t my_carry = cin2[cur_set * PM + tid];
-    uint64_t cur = o_cur[tid], cend = o_cend[tid];
-    if (my_carry != 0u) {
-      bool dry = false;
-      if (cur == cend) {
-        if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | CH;
-        uint32_t id0 = route_take_ids(stock, 1u);
-        if (id0 == 0xffffffffu) id0 = atomicAdd(ra.pool, 1u);
-        if ((uint64_t)id0 + 1u <= ra.list_cap) {
-          file_chunk(tid, id0);
-          cur = (uint64_t)id0 << lg;
-          cend = cur + CH;
-        } else {
-          dry = true;
-          if (ra.dry) *ra.dry = 1u;
-          atomicOr(ra.flags, 3u);
-        }
-      }
-      if (!dry) {
-        for (int i = 0; i < GRP; ++i) wrec[cur + i] = (uint32_t)i < my_carry ? carry_w[tid * GRP + i] : 0.0;  // (+0.0 for bin 0: neutral)
-        cur += GRP;
-      }
-    }
-    if (cend != 0) ra.cmeta[(uint32_t)((cend - 1) >> lg)] = ((uint32_t)tid << 20) | (uint32_t)(cur - (cend - CH));
-    const uint32_t mine = ccnt[tid];
-    if (mine != 0u) {
-      const uint32_t pos0 = atomicAdd(ra.pcount + tid, mine);
-      uint32_t e = head[tid];
-      for (uint32_t j = 0; j < mine; ++j) {
-        ra.plist[(size_t)tid * ra.list_cap + pos0 + j] = cl_id[e];
-        e = cl_prev[e];
-      }
-    }
-  }
-  const uint32_t signs = (__ballot(any_neg) ? 1u : 0u) | (__ballot(any_pos) ? 2u : 0u);
-  if ((tid & 63) == 0 && signs) atomicOr(ra.flags, signs);
-}
-
 // The adding-up pass over chunk lists.  Chunk k of the concatenation of all partitions' lists belongs to the
 // partition whose offset range holds k; every workgroup takes an equal range of k.  Chunks hold whole
 // groups of 8 records and start 2^chunk_log2-aligned, so every load is an aligned quad.

@@ -2,10 +2,3 @@
 #include "xhist_pick.hip.h"
 
 kernel_fn_route xhist_pick_route_f64_b1024(int wdt, int D, int scan, bool multi) { return route_pick<double, 1024>(wdt, D, scan, multi); }
-
-// the two-per-CU routing pass of float64 samples with packed float64 records on arithmetic edges (BASELINE C5; xhist_route.hip.h)
-kernel_fn_route xhist_pick_route_lean(int D) {
-  if (D == 1) return (kernel_fn_route)part_route_lean<1>;
-  if (D == 2) return (kernel_fn_route)part_route_lean<2>;
-  return nullptr;
-}
