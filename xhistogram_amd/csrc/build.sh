@@ -9,7 +9,7 @@ obj="$(mktemp -d)"
 trap 'rm -rf "$obj"' EXIT
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${XHIST_BUILD_FLAGS:-})
 pids=()
-tus=(xhist_capi xhist_pick_f64 xhist_pick_f32 xhist_pick_mixed xhist_pick_flat xhist_route_f64_b1024 xhist_route_f64_b1024s8 xhist_route_f32_b1024 xhist_route_f32_b1024s8)
+tus=(xhist_capi xhist_pick_f64 xhist_pick_f32 xhist_pick_mixed xhist_pick_flat xhist_route_f64_b1024 xhist_route_f64_b1024s8 xhist_route_f32_b1024 xhist_route_f32_b1024s8 xhist_exchange)
 for tu in "${tus[@]}"; do
   "$HIPCC" "${flags[@]}" -c -o "$obj/$tu.o" "$here/$tu.hip" &
   pids+=($!)

@@ -253,7 +253,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->mixed_hint) {
       uint32_t* h = nullptr;
-      if (hipHostMalloc((void**)&h, 64, hipHostMallocDefault) == hipSuccess) { h[0] = h[1] = 0u; p->mixed_hint = h; }
+      if (hipHostMalloc((void**)&h, 64, hipHostMallocDefault) == hipSuccess) { memset(h, 0, 64); p->mixed_hint = h; }
       else (void)hipGetLastError();
     }
   }
@@ -305,7 +305,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
   uint16_t* d_codes = nullptr;
   void* d_w = nullptr;
+  void *x_ctl = nullptr, *x_rings = nullptr, *x_part = nullptr, *x_side = nullptr, *x_words = nullptr;  // the exchange mode's scratch
   auto release = [&](int rc) {
+    for (void* q : {x_ctl, x_rings, x_part, x_side, x_words})
+      if (q) (void)scratch_free(q, stream);
     if (d_ctr) (void)scratch_free(d_ctr, stream);
     if (d_plist) (void)scratch_free(d_plist, stream);
     if (d_cmeta) (void)scratch_free(d_cmeta, stream);
@@ -326,6 +329,53 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   HIPR(scratch_malloc((void**)&d_cmeta, (size_t)pool_chunks * 4, stream));
   HIPR(scratch_malloc((void**)&d_codes, pool_recs * 2, stream));
   if (weighted) HIPR(scratch_malloc(&d_w, pool_recs * rec_bytes, stream));
+
+  // The exchange mode (xhist_exchange.hip.h): packed records that never go through HBM — one persistent workgroup per compute
+  // unit keeps rows of a WINDOW of the histogram in LDS, records travel through rings inside each XCD.  Offered for float64
+  // samples + float64 weights on arithmetic edges, one row, on the 8 x 32-CU chip; whether a call takes it is decided on the
+  // GPU by the probe (the window must hold >= 88 % of the samples) — the classic packed kernels below are queued all the same
+  // and return at once when it does.  "exchange" = -1 / 1: never / whenever it can run (any size, any coverage: tests).
+  ExchArgs xa;
+  memset(&xa, 0, sizeof xa);
+  bool xch = false, xch_probe = false;
+  kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
+  size_t lds_xch = 0;
+  if (pack && rows == 1 && p->exchange_pref >= 0 && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
+      p->n_bins <= ((int64_t)1 << 28) && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
+    const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
+    const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
+    const int64_t units = (hist_rows + kExchUnitRows - 1) / kExchUnitRows;
+    const int64_t rows_per = L <= kExchMaxLocal ? std::min<int64_t>(kExchMaxLocal / L, units) : 0;
+    k_xch = xhist_pick_exchange(D);
+    k_xprobe = xhist_pick_exchange_probe(D);
+    lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
+    if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max) {
+      xch = true;
+      xch_probe = units > rows_per;  // (a histogram that fits the window needs no probe)
+      xa.row_len = L;
+      xa.n_hist_rows = hist_rows;
+      xa.rows_per = (int32_t)rows_per;
+      xa.local_bins = (int32_t)(rows_per * L);
+      xa.n_units = (int32_t)units;
+      xa.force = p->exchange_pref > 0 ? 1 : 0;
+      xa.min_ppm = 880000;
+      xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 2000) * 100000;
+      const size_t words_bytes = ((size_t)(units + 1 + 8) * 4 + 7) & ~(size_t)7;
+      HIPR(scratch_malloc(&x_ctl, sizeof(ExchCtl) * kExchXcds, stream));
+      HIPR(scratch_malloc(&x_rings, (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8, stream));
+      HIPR(scratch_malloc(&x_part, (size_t)kExchXcds * kExchRings * (size_t)xa.local_bins * 8, stream));
+      HIPR(scratch_malloc(&x_side, (size_t)p->n_bins * 8, stream));
+      HIPR(scratch_malloc(&x_words, words_bytes, stream));
+      xa.ctl = static_cast<ExchCtl*>(x_ctl);
+      xa.rings = static_cast<uint64_t*>(x_rings);
+      xa.part = static_cast<double*>(x_part);
+      xa.side = static_cast<double*>(x_side);
+      xa.win = static_cast<uint32_t*>(x_words);
+      xa.counts = xa.win + 8;
+      xa.note = p->mixed_hint;
+      if (lds_xch > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_xch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xch));
+    }
+  }
 
   if (lds_route > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_route));
   kernel_fn_acc_chunks k_acc = weighted ? (rec_f32 ? (kernel_fn_acc_chunks)part_accumulate_chunks<true, float>
@@ -387,6 +437,35 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     ra.dry = p->mixed_hint ? p->mixed_hint + 1 : nullptr;
 
     if (int zrc = zero_output(ctr, ctr_words * 2, stream)) return release(zrc);
+    ra.xgate = nullptr;
+    if (xch) {
+      xa.flags = ctr + 1;
+      if (int zrc = zero_output(x_ctl, (int64_t)(sizeof(ExchCtl) * kExchXcds / 8), stream)) return release(zrc);
+      if (int zrc = zero_output(x_rings, (int64_t)kExchXcds * kExchRings * kExchRings * kExchCap, stream)) return release(zrc);
+      if (int zrc = zero_output(x_side, p->n_bins, stream)) return release(zrc);
+      if (int zrc = zero_output(x_words, (int64_t)((xa.n_units + 1 + 8) * 4 + 7) / 8, stream)) return release(zrc);
+      for (int d = 0; d < D; ++d) {  // (the arithmetic-edge constants of the float64 table set, whatever the classic routing pass digitizes with)
+        const DimTable& t = p->ts[0][0].dim[d];
+        xa.s_ptr[d] = static_cast<const double*>(samples[d].data);
+        xa.dim[d].e0 = t.e0_f;
+        xa.dim[d].eL = t.eL_f;
+        xa.dim[d].step = t.step;
+        xa.dim[d].inv_step = t.inv_step;
+        xa.dim[d].arith_h = t.arith_h;
+        xa.dim[d].nb = t.nb;
+      }
+      xa.w_ptr = static_cast<const double*>(weights->data);
+      xa.n = n_cols;
+      if (xch_probe) {
+        XH_LAUNCH_PICKED(k_xprobe, dim3(256), dim3(256), 0, stream, xa);
+        HIPR(hipGetLastError());
+      }
+      XH_LAUNCH_PICKED(xhist_pick_exchange_pick(), dim3(1), dim3(64), 0, stream, xa);
+      HIPR(hipGetLastError());
+      XH_LAUNCH_PICKED(k_xch, dim3(kExchXcds * kExchRings), dim3(kExchBlock), lds_xch, stream, xa);
+      HIPR(hipGetLastError());
+      ra.xgate = xa.win + 1;  // the classic packed kernels below return at once when the mode took the call
+    }
     RouteArgs ra48 = ra;
     if (pack) {
       XH_LAUNCH_PICKED(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
@@ -400,6 +479,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       ra.gate = ctr + 1;
       ra.gate_mode = 2;
       ra.hint = p->mixed_hint;
+      ra.xgate = nullptr;  // (the exact passes redo the call whenever the sign word says so, exchange mode or not)
     }
     XH_LAUNCH_PICKED(k_route, dim3(Gk), dim3(block), lds_route, stream, kp, ra);
     HIPR(hipGetLastError());
@@ -409,15 +489,20 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     }
     XH_LAUNCH_PICKED(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
     HIPR(hipGetLastError());
+    if (xch) {  // (runs when the mode was on and the weights had one sign: exactly when none of the four kernels above did)
+      XH_LAUNCH_PICKED(xhist_pick_exchange_merge(), dim3((unsigned)((p->n_bins + 255) / 256)), dim3(256), 0, stream, xa, static_cast<double*>(out), p->n_bins);
+      HIPR(hipGetLastError());
+    }
   }
   {
     char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
-             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64");
+             !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64",
+             !xch ? "no" : xa.force ? "forced" : xch_probe ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }

@@ -438,6 +438,8 @@ struct xhist_plan {
   int flat_rows = 0;       // dense short rows streamed flat (hist_flat_rows): -1 off, 0 auto, 1 for any row length below 65536
   int min_parts = 0;       // partitioned mode: bins are cut finer until a pass has this many partitions (0 auto = 16; 1 = never)
   int route_grid = 0, acc_grid = 0;  // workgroups of the routing / adding-up pass of execute_partitioned_fused (0 auto) — scaling runs
+  int exchange_pref = 0;   // exchange mode of the partitioned path (xhist_exchange.hip.h): -1 never, 0 where eligible and the probe's window holds enough samples, 1 whenever the kernel can run (tests)
+  int exchange_budget_ms = 0;  // deadline of a workgroup's waits in that mode: 0 = 2000 ms; -1: every wait gives up at once (tests of the fallback)
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never
   int arith_pref = 0;  // 0 auto, 1 table-free digitize whenever the edges are arithmetic, -1 never

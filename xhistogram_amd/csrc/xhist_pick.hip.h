@@ -7,6 +7,7 @@
 #include "xhist_kernels.hip.h"
 #include "xhist_partition.hip.h"
 #include "xhist_route.hip.h"
+#include "xhist_exchange.hip.h"
 #include "xhist_lanes.hip.h"
 
 #include <type_traits>
@@ -285,3 +286,13 @@ kernel_fn_flat xhist_pick_flat_rows(int sdt, int wdt, int D, int scan);  // hist
 XH_ROUTE_TU(f64, 1024) XH_ROUTE_TU(f64, 1024s8)
 XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 1024s8)
 #undef XH_ROUTE_TU
+
+// the exchange mode of the partitioned path (xhist_exchange.hip.h; translation unit xhist_exchange.hip): float64 samples,
+// float64 weights as packed records, arithmetic edges, 1-3 inputs
+typedef void (*kernel_fn_exch)(const ExchArgs);
+kernel_fn_exch xhist_pick_exchange(int D);
+kernel_fn_exch xhist_pick_exchange_probe(int D);
+typedef void (*kernel_fn_exch_pick)(const ExchArgs);
+typedef void (*kernel_fn_exch_merge)(const ExchArgs, double*, int64_t);
+kernel_fn_exch_pick xhist_pick_exchange_pick();
+kernel_fn_exch_merge xhist_pick_exchange_merge();

@@ -115,9 +115,13 @@ struct RouteArgs {
   uint32_t* hint;
   int32_t gate_mode;
   uint32_t* dry;        // host memory (may be NULL): set to 1 when the chunk pool ran dry and records went straight to the output
+  // the exchange mode (xhist_exchange.hip.h) took this call when *xgate != 0: the classic PACKED kernels queued behind it return
+  // at once (the exact ones do not look here: they redo the call whenever the sign word says so)
+  const uint32_t* xgate;
 };
 
 __device__ __forceinline__ bool route_gate_closed(const RouteArgs& ra) {
+  if (ra.xgate && __builtin_nontemporal_load(ra.xgate) != 0u) return true;
   if (ra.gate_mode == 0) return false;
   const bool mixed = (__builtin_nontemporal_load(ra.gate) & 3u) == 3u;
   return (ra.gate_mode == 2) != mixed;
