@@ -142,8 +142,16 @@ def test_exchange_mode_deadline_falls_back_to_exact_records(xh):
     want = onp.bincount_rows([x, y], edges, w)
     got, _ = _exchange(xh, [x, y], edges, w, exchange_budget_ms=-1, records48=0)
     assert_hist_equal(got, want, True)
+    # the next call notices the abort, forgets the "both signs" note the redo left and keeps the plan off the mode ...
+    again, desc = _run(xh, [x, y], edges, w, True, partition=1)
+    assert "exchange=no" in desc and "records=packed48" in desc, desc
+    assert_hist_equal(again, want, True)
+    # ... until the knob is touched
     plan = _plan_for(xh, [_dev(x), _dev(y)], edges)
-    plan.set_param("records48", 0)  # (forget the note the fallback left)
+    plan.set_param("exchange", 0)
+    again, desc = _run(xh, [x, y], edges, w, True, partition=1, exchange=1)
+    assert "exchange=forced" in desc, desc
+    assert_hist_equal(again, want, True)
 
 
 def test_exchange_mode_is_chosen_by_the_probe(xh):
@@ -166,6 +174,12 @@ def test_exchange_mode_is_chosen_by_the_probe(xh):
         plan.set_param("partition", 1)
         try:
             auto = xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)
+            torch.cuda.synchronize()
+            xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)  # (its description carries what the GPU reported for the call before)
+            desc = plan.describe()
+            assert "exchange=if the probe" in desc, desc
+            ppm = int(desc.split("exchange_window_ppm_before=")[1].split()[0])
+            assert (ppm >= 880_000) == (dist == "normal"), (dist, ppm)
             plan.set_param("exchange", -1)
             classic = xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)
         finally:

@@ -63,6 +63,17 @@ struct ExchDim {
   int32_t nb, pad;
 };
 
+// what only the rare paths of part_exchange need (the exact redo of a sample next to an edge, an abort, the epilogue), kept in
+// device memory: as kernel arguments these values sat in scalar registers through the whole tile loop, and the loop spilled
+// 88 of them into vector-register lanes — 140 v_readlane per tile.  exchange_pick copies them here from the arguments.
+struct ExchCold {
+  double eL[3], step[3];
+  long long budget_ticks;
+  uint32_t* flags;
+  uint32_t* note;
+  double* part;
+};
+
 struct ExchArgs {
   const double* s_ptr[3];    // the inputs (one row, unit stride) and their weights
   const double* w_ptr;
@@ -73,6 +84,7 @@ struct ExchArgs {
   double* part;              // [xcd][owner][local_bins]: the XCD partials of the window
   double* side;              // [n_bins], zeroed per call: samples outside the window
   uint32_t* win;             // device words: [0] first row of the window, [1] mode on, [2] coverage in ppm (exchange_pick writes them)
+  ExchCold* cold;            // device copy of the rarely needed arguments (exchange_pick writes it)
   uint32_t* counts;          // [n_units + 1] rows of the probe's samples per unit of 32 rows, zeroed per call
   uint32_t* flags;           // the packed pass's sign word: 1 negative, 2 positive weights seen; 3 also stands for "redo exactly"
   uint32_t* note;            // pinned host words (may be NULL): [2] += 1 per abort, [3] coverage ppm of the last pick
@@ -128,7 +140,7 @@ __device__ __forceinline__ uint32_t exch_count_le(double x, const ExchDim& t) {
 // (9 float64 operations per sample and input; "inside" stays a compare mask), and for a wavefront in which some lane met a
 // sample on / next to an edge, a NaN or an infinity, that lane's samples again with the exact compares.
 template <int D, int N>
-__device__ __forceinline__ void exch_digitize(const double (&x)[D][N], const ExchArgs& xa, uint32_t (&g)[D][N], bool (&ins)[N]) {
+__device__ __forceinline__ void exch_digitize(const double (&x)[D][N], const ExchArgs& xa, uint32_t (&g)[D][N], bool (&ins)[N], const volatile ExchCold* cold = nullptr) {
   bool near_any = false;
 #pragma unroll
   for (int v = 0; v < N; ++v) ins[v] = true;
@@ -155,7 +167,11 @@ __device__ __forceinline__ void exch_digitize(const double (&x)[D][N], const Exc
       for (int v = 0; v < N; ++v) ins[v] = true;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const ExchDim t = xa.dim[d];
+        ExchDim t = xa.dim[d];
+        if (cold) {  // (the two constants only this path needs come from memory, not from registers held through the caller's loop)
+          t.eL = cold->eL[d];
+          t.step = cold->step[d];
+        }
 #pragma unroll
         for (int v = 0; v < N; ++v) {
           g[d][v] = (uint32_t)min((int)exch_count_le(x[d][v], t) - 1, t.nb - 1);  // (x == e_last counts E edges: last bin)
@@ -234,6 +250,14 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
   xa.win[1] = (xa.force || wu >= nu || ppm >= (uint32_t)xa.min_ppm) ? 1u : 0u;
   xa.win[2] = ppm;
   if (xa.note) xa.note[3] = ppm;
+  for (int d = 0; d < 3; ++d) {
+    xa.cold->eL[d] = xa.dim[d].eL;
+    xa.cold->step[d] = xa.dim[d].step;
+  }
+  xa.cold->budget_ticks = xa.budget_ticks;
+  xa.cold->flags = xa.flags;
+  xa.cold->note = xa.note;
+  xa.cold->part = xa.part;
 }
 
 template <int D>
@@ -257,7 +281,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   uint32_t* sent = c + 352;    // [32] ... and that have been written
   uint32_t* wadj = c + 384;    // [32] wbase[d] - off[d]: ring position = wadj[d] + staged slot
   uint32_t* misc = c + 416;    // [0] XCD [1] place [3] runs not written out yet [4] abort
-  const long long t_start = wall_clock64();
+  const volatile ExchCold* cold = xa.cold;
 
   for (int i = tid; i < xa.local_bins; i += BLOCK) hist[i] = 0.0;
   if (tid < 128) cnt2[tid] = 0u;
@@ -268,6 +292,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     misc[1] = atomicAdd(&xa.ctl[xc].nreg, 1u);
     misc[3] = 0u;
     misc[4] = 0u;
+    *reinterpret_cast<long long*>(misc + 6) = wall_clock64();  // when this workgroup started: its waits give up budget_ticks later
   }
   __syncthreads();
   const uint32_t xcd = misc[0], me = misc[1];
@@ -275,8 +300,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   if (me >= (uint32_t)NS) {  // not 32 workgroups on this XCD: no ring ends here — everybody leaves, the exact passes redo the call
     if (tid == 0) {
       exch_st(g_abort, 1u);
-      atomicOr(xa.flags, 3u);
-      if (xa.note) atomicAdd(xa.note + 2, 1u);
+      atomicOr(cold->flags, 3u);
+      if (cold->note) atomicAdd(cold->note + 2, 1u);
     }
     return;
   }
@@ -384,7 +409,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     }
     return pre;
   };
-  auto deadline = [&]() { return wall_clock64() - t_start > xa.budget_ticks; };
+  auto deadline = [&]() { return wall_clock64() - *reinterpret_cast<const long long*>(misc + 6) > cold->budget_ticks; };
 
   uint64_t s_neg = 0, s_pos = 0;  // lanes that read a negative / positive weight (pack48 rounds: only one sign may travel packed) — scalar registers
   uint32_t cred_next = 0;
@@ -405,7 +430,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         for (int s4 = 0; s4 < 4; ++s4) xs[d][s4] = xv[d][s4 >> 1][s4 & 1];
       uint32_t g[D][4];
       bool ins[4];
-      exch_digitize<D, 4>(xs, xa, g, ins);
+      exch_digitize<D, 4>(xs, xa, g, ins, cold);
       bool special_any = false;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -540,16 +565,16 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   if (aborted) {
     if (tid == 0) {
       exch_st(g_abort, 1u);
-      atomicOr(xa.flags, 3u);
-      if (xa.note) atomicAdd(xa.note + 2, 1u);
+      atomicOr(cold->flags, 3u);
+      if (cold->note) atomicAdd(cold->note + 2, 1u);
     }
     return;
   }
   __syncthreads();
-  double* po = xa.part + ((size_t)xcd * NS + me) * (size_t)xa.local_bins;
+  double* po = cold->part + ((size_t)xcd * NS + me) * (size_t)xa.local_bins;
   for (int i = tid; i < xa.local_bins; i += BLOCK) po[i] = hist[i];
   const uint32_t signs = (s_neg ? 1u : 0u) | (s_pos ? 2u : 0u);
-  if ((tid & 63) == 0 && signs) atomicOr(xa.flags, signs);
+  if ((tid & 63) == 0 && signs) atomicOr(cold->flags, signs);
 }
 
 // out += side + (inside the window) the eight XCD partials.  Runs when the mode was on and the weights had one sign;

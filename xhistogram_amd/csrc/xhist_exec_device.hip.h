@@ -257,6 +257,15 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       else (void)hipGetLastError();
     }
   }
+  if (p->mixed_hint && p->mixed_hint[2] != p->exchange_aborts_seen) {
+    // an exchange kernel of an earlier call gave up (workgroups not all resident — another stream's kernel held compute units —
+    // or not 32 per XCD) and the exact passes redid that call: not a property of the weights, so the plan forgets the "both
+    // signs" note that redo left, and stays away from the mode (a second hang would cost its deadline again)
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->exchange_aborts_seen = p->mixed_hint[2];
+    p->exchange_disabled = true;
+    p->mixed_hint[0] = 0u;
+  }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
@@ -340,7 +349,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   bool xch = false, xch_probe = false;
   kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
   size_t lds_xch = 0;
-  if (pack && rows == 1 && p->exchange_pref >= 0 && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
+  if (pack && rows == 1 && p->exchange_pref >= 0 && (!p->exchange_disabled || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
       p->n_bins <= ((int64_t)1 << 28) && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
     const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
     const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
@@ -360,7 +369,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.force = p->exchange_pref > 0 ? 1 : 0;
       xa.min_ppm = 880000;
       xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 2000) * 100000;
-      const size_t words_bytes = ((size_t)(units + 1 + 8) * 4 + 7) & ~(size_t)7;
+      const size_t words_bytes = ((size_t)(units + 1 + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts
       HIPR(scratch_malloc(&x_ctl, sizeof(ExchCtl) * kExchXcds, stream));
       HIPR(scratch_malloc(&x_rings, (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8, stream));
       HIPR(scratch_malloc(&x_part, (size_t)kExchXcds * kExchRings * (size_t)xa.local_bins * 8, stream));
@@ -371,7 +380,9 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.part = static_cast<double*>(x_part);
       xa.side = static_cast<double*>(x_side);
       xa.win = static_cast<uint32_t*>(x_words);
-      xa.counts = xa.win + 8;
+      xa.cold = reinterpret_cast<ExchCold*>(xa.win + 8);
+      static_assert(sizeof(ExchCold) <= 32 * 4, "the cold arguments fit their 32 words");
+      xa.counts = xa.win + 8 + 32;
       xa.note = p->mixed_hint;
       if (lds_xch > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_xch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xch));
     }
@@ -443,7 +454,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       if (int zrc = zero_output(x_ctl, (int64_t)(sizeof(ExchCtl) * kExchXcds / 8), stream)) return release(zrc);
       if (int zrc = zero_output(x_rings, (int64_t)kExchXcds * kExchRings * kExchRings * kExchCap, stream)) return release(zrc);
       if (int zrc = zero_output(x_side, p->n_bins, stream)) return release(zrc);
-      if (int zrc = zero_output(x_words, (int64_t)((xa.n_units + 1 + 8) * 4 + 7) / 8, stream)) return release(zrc);
+      if (int zrc = zero_output(x_words, (int64_t)((xa.n_units + 1 + 8 + 32) * 4 + 7) / 8, stream)) return release(zrc);
       for (int d = 0; d < D; ++d) {  // (the arithmetic-edge constants of the float64 table set, whatever the classic routing pass digitizes with)
         const DimTable& t = p->ts[0][0].dim[d];
         xa.s_ptr[d] = static_cast<const double*>(samples[d].data);
@@ -498,11 +509,12 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64",
-             !xch ? "no" : xa.force ? "forced" : xch_probe ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window");
+             !xch ? "no" : xa.force ? "forced" : xch_probe ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window",
+             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u);  // (what the GPU has reported so far: the calls before this one)
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }
