@@ -46,6 +46,9 @@
 #ifndef XSAME
 #define XSAME 0
 #endif
+#ifndef XSTEAL
+#define XSTEAL 0
+#endif
 #ifndef XEXACT
 #define XEXACT 0
 #endif
@@ -122,6 +125,8 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
     misc[1] = atomicAdd(&ctl[xc & 7].nreg, 1u);
     misc[3] = 0u;
     misc[4] = 0u;
+    misc[8] = 0u;
+    misc[9] = 0u;
   }
   __syncthreads();
   const uint32_t xcd = misc[0] & 7u, me = misc[1];
@@ -200,6 +205,45 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
     return pre;
   };
 
+
+  // XSTEAL: whoever has issued its loads takes ring pairs by ticket until none is left (the wavefronts whose loads were
+  // accepted first otherwise just wait at the barrier for the last one).  Measured SLOWER (3.49 against 3.25 ms): ring loads
+  // issued behind a wavefront's own prefetch wait for that prefetch (the memory counter counts in order), and under load the
+  // first wavefront's samples arrive no earlier than the last wavefront's loads are accepted.
+  auto take_by_ticket = [&](uint32_t* ticket) {
+    for (;;) {
+      uint32_t t = 0;
+      if ((tid & 63) == 0) t = atomicAdd(ticket, 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= 16u) break;
+      const uint32_t ring = 2u * t + (((uint32_t)tid >> 5) & 1u);
+      const uint32_t h = chead[ring];
+      uint64_t q[CL];
+#pragma unroll
+      for (int j = 0; j < CL; ++j) q[j] = ld_l2(myring + (size_t)ring * CAP + ((h + l + 32u * j) & (uint32_t)(CAP - 1)));
+      uint32_t pre = 0;
+      bool cont = true;
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        const uint32_t pos = h + l + 32u * j;
+        const bool valid = (((uint32_t)q[j] >> 14) & 3u) == (((pos >> CAP_LOG2) + 1u) & 3u);
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
+        const uint32_t m = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        if (cont) {
+          if (m == 0xffffffffu) pre += 32u;
+          else { pre += (uint32_t)__builtin_ctz(~m); cont = false; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CL; ++j)
+        if (l + 32u * j < pre) unsafeAtomicAdd(hist + ((uint32_t)q[j] & 0x3fffu), __longlong_as_double((long long)(q[j] & ~0xffffull)));
+      if (l == 0 && pre) {
+        chead[ring] = h + pre;
+        st_l2(&C.head[ring][me], h + pre);
+        taken_total += pre;
+      }
+    }
+  };
   uint32_t cred_next = 0;
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
 #define PH(i) do { if (XTIME) { const long long t_ = clock64(); ph[i] += t_ - tc; tc = t_; } } while (0)
@@ -255,7 +299,7 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
     if (XEXACT && __builtin_amdgcn_ballot_w64(near_any) != 0ull) { if (near_any) atomicAdd(status + 5, 1u); }
     PH(0);
     if (!XPRE && MODE == 0) {
-      issue_ring_loads();
+      if (!XSTEAL) issue_ring_loads();
       if (tid < 32) cred_next = ld_l2(&C.head[me][tid]);
     }
     // samples outside the window: straight to the output (registers are free before the prefetch)
@@ -266,7 +310,8 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
     uint32_t rank[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) rank[s] = dest[s] < 32u ? atomicAdd(cnt + dest[s], 1u) : 0u;
-    if (XPRE && MODE == 0) take_ring_records();
+    if (XSTEAL && MODE == 0) take_by_ticket(misc + 8 + buf);
+    if (!XSTEAL && XPRE && MODE == 0) take_ring_records();
     PH(1);
     __syncthreads();
     PH(5);
@@ -298,7 +343,8 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
       }
       cnt2[(buf ^ 1) * 64 + tid] = 0u;
     }
-    if (!XPRE && MODE == 0) take_ring_records();
+    if (!XSTEAL && !XPRE && MODE == 0) take_ring_records();
+    if (XSTEAL && tid == 0) misc[8 + (buf ^ 1)] = 0u;
     PH(6);
     __syncthreads();
     PH(7);
