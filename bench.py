@@ -339,7 +339,7 @@ def main():
                     # the leg above moves float64 weights between its two passes as 48-bit records (36 mantissa bits, 2^-37
                     # relative per weight; one sign only, decided on the GPU) — narrower than the reference's float64 adds
                     # (core.py:81) though inside the 1e-6 contract.  The same call with FULL float64 records beside it:
-                    out[cfg]["records"] = "packed48 (float64 weights rounded to 36 mantissa bits between the two passes; exact_records = full float64)"
+                    out[cfg]["records"] = "packed48 (float64 weights rounded to 36 mantissa bits on their way from the workgroup that read them to the one that adds them; exact_records = full float64)"
                     plan2.set_param("records48", -1)
                     try:
                         a.steps, a.warmup = 10, 5
@@ -347,6 +347,24 @@ def main():
                         out[cfg]["exact_records"] = {k: ex[k] for k in ("steps", "warmup", "value", "ms_per_step", "kernel_ms_mean", "kernel_ms_min", "achieved_GBps", "frac", "kernel", "verified")}
                     finally:
                         plan2.set_param("records48", 0)
+                    # The packed leg above ran in the exchange mode if its description says so: N(0,1) samples put
+                    # 94 % of the records into the window the probe picks.  Beside it: the same call on the classic pair of
+                    # passes (the mode switched off), and the same shape with UNIFORM samples, which the probe refuses
+                    # (47 % in the window) — what a call that cannot take the mode costs, and that the default does not misfire.
+                    keys = ("steps", "warmup", "value", "ms_per_step", "kernel_ms_mean", "kernel_ms_min", "achieved_GBps", "frac", "kernel", "verified")
+                    plan2.set_param("exchange", -1)
+                    try:
+                        a.steps, a.warmup = 10, 5
+                        cl = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+                        out[cfg]["classic_passes"] = {k: cl[k] for k in keys}
+                    finally:
+                        plan2.set_param("exchange", 0)
+                    if time.perf_counter() - t_start < budget_s + 15.0:
+                        for t in wl2["arrays"]:
+                            t.uniform_(-4.0, 4.0)
+                        a.steps, a.warmup = 5, 3
+                        un = measure_and_report(a, torch, dist, _native, core, wl2, plan2, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream, as_extra=True)
+                        out[cfg]["uniform_samples"] = {k: un[k] for k in keys}
             except Exception as e:  # noqa: BLE001
                 out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             del wl2

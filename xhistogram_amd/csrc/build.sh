@@ -1,6 +1,6 @@
 #!/bin/bash
-# Build libxhist_amd.so in-tree for gfx950 (cross-compiles without a GPU).  Eight translation units,
-# compiled in parallel: seven that instantiate the float64 / float32 / mixed-dtype vector and routing kernels, and the rest.
+# Build libxhist_amd.so in-tree for gfx950 (cross-compiles without a GPU).  Ten translation units,
+# compiled in parallel: nine that instantiate the float64 / float32 / mixed-dtype vector, routing and exchange kernels, and the rest.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${XHIST_BUILD_OUT:-$here/../libxhist_amd.so}"  # (development: XHIST_BUILD_OUT / XHIST_BUILD_FLAGS build an A/B variant next to the library)

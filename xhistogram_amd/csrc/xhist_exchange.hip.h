@@ -22,7 +22,7 @@
 //     until the owner has caught up (every workgroup is resident, so this always ends; a deadline turns a hang into the
 //     exact fallback below).  Plain stores and agent-scope (L1-bypassing) loads are enough INSIDE one XCD: both sides
 //     go through the same L2.  Across XCDs they are not (measured: stale for ever), and write-through stores cost
-//     3.97 against 3.29 ms — which is why the window is per XCD and not 8 x larger.
+//     3.97 against 3.29 ms in the stand-alone kernel — which is why the window is per XCD and not 8 x larger.
 //   * Samples outside the window go to a side copy of the output with memory-side atomics (2.4*10^10 per second: fine for
 //     ~10 % of the samples, hopeless for half of them), so WHERE the window lies decides whether the mode pays:
 //     exchange_probe histograms the rows of 2.6*10^5 samples spread over the input, exchange_pick takes the best window and
@@ -32,9 +32,13 @@
 //     "both signs" in the flags word of the packed routing pass, so the exact routing + adding-up passes queued behind it
 //     redo the whole call from the (untouched) output — this kernel and exchange_merge write only scratch until the merge.
 //
-// Traffic per C5 sample: 24 B read, 8 B written to the rings and 8 B read from them, but the ring bytes never leave the
-// Infinity Cache (33 MB of rings, rewritten every few microseconds): HBM sees the samples only.  Measured by the
-// development benchmark this kernel grew from (tools/ubench/xchg.hip, profiles/r05_x_*): 3.13-3.2 ms against 3.95-4.1.
+// Traffic per C5 sample: 24 B read, 8 B written to the rings and 8 B read from them.  The counters say every ring read
+// misses the L2 (the sample stream evicts the rings: FETCH 15.8 GB per 5*10^8 samples = 12.0 of samples + 3.74 of records;
+// WRITE 5.07 GB = 3.76 of records + 1.3 of side atomics; with no stream beside them the reads do hit), so as many bytes cross
+// the far side of the L2 as in the classic pair — but the 33 MB of rings are rewritten every few microseconds and need
+// never reach HBM, the only bytes that must come from there are the samples', and there is no second kernel.  Measured
+// (tools/ubench/xchg.hip is the kernel as a stand-alone program, profiles/r05_x_*): C5 shard 3.26-3.34 ms
+// against 3.95-4.1; the producing half alone 2.5 ms.
 #pragma once
 
 #include "xhist_route.hip.h"
