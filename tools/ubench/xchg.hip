@@ -46,6 +46,9 @@
 #ifndef XSAME
 #define XSAME 0
 #endif
+#ifndef XCOLW
+#define XCOLW 0
+#endif
 #ifndef XSTEAL
 #define XSTEAL 0
 #endif
@@ -70,7 +73,8 @@
 constexpr int BLOCK = 1024, SPL = XSPL, TILE = BLOCK * SPL, U = SPL / 2;
 constexpr int NX = 8, NS = 32;              // XCDs; workgroups (= ring ends) per XCD
 constexpr int NBY = 1024, NBX = 1024;
-constexpr int ROWS_PER_PART = 15, PART_BINS = ROWS_PER_PART * NBY, WIN_ROWS = ROWS_PER_PART * NS;  // 480 rows in the window
+constexpr int ROWS_PER_PART = XCOLW ? 20 : 15, COL0 = XCOLW ? 128 : 0, COLW = XCOLW ? 768 : 1024;
+constexpr int ROWS_PER_PART_UNUSED = 15, PART_BINS = ROWS_PER_PART * COLW, WIN_ROWS = ROWS_PER_PART * NS;  // 480 rows in the window
 constexpr int CAP_LOG2 = XCAP_LOG2, CAP = 1 << CAP_LOG2;  // records per ring
 constexpr int CL = XCL;                       // ring records a lane looks at per step (32 lanes per ring: 192 records)
 constexpr int PART_BYTES = PART_BINS * 8;
@@ -290,9 +294,9 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
         const int xb = ok ? (int)tx : 0, yb = ok ? (int)ty : 0;
 #endif
         const uint32_t r = (uint32_t)(xb - row0);
-        const bool in_win = ok & (r < (uint32_t)WIN_ROWS) & (MODE != 1);
+        const bool in_win = ok & (r < (uint32_t)WIN_ROWS) & ((uint32_t)(yb - COL0) < (uint32_t)COLW) & (MODE != 1);
         dest[s] = !ok ? 33u : (in_win ? (r & 31u) : 32u);
-        const uint32_t local = ((r >> 5) << 10) | (uint32_t)yb;
+        const uint32_t local = (r >> 5) * (uint32_t)COLW + (uint32_t)(yb - COL0);
         rec[s] = ((uint64_t)__double_as_longlong(wv[u][v]) & ~0xffffull) | (in_win ? local : 0u);
         flat[s] = (uint32_t)xb * NBY + (uint32_t)yb;
       }
@@ -443,7 +447,8 @@ __global__ void merge(const double* part_out, double* out, int row0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over WIN_ROWS * NBY
   if (i >= WIN_ROWS * NBY) return;
   const int r = i / NBY, col = i % NBY;
-  const int d = r & 31, local = ((r >> 5) << 10) | col;
+  const int d = r & 31, local = (r >> 5) * COLW + (col - COL0);
+  if ((unsigned)(col - COL0) >= (unsigned)COLW) return;
   double s = 0.0;
   for (int xc = 0; xc < NX; ++xc) s += part_out[((size_t)xc * NS + d) * PART_BINS + local];
   out[(size_t)(row0 + r) * NBY + col] += s;
