@@ -195,3 +195,37 @@ def torch_gen(seed):
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     return g
+
+
+def test_exchange_mode_keeps_its_kernels_from_meeting_on_two_streams(xh):
+    """the exchange kernel wants every compute unit (256 persistent workgroups that wait for one another): a second call on
+    ANOTHER stream while the first one's kernel is still running takes the classic passes instead of sharing the chip with it"""
+    import torch
+
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    n = 1 << 27
+    g = torch_gen(17)
+    x = torch.empty((1, n), dtype=torch.float64, device="cuda").normal_(generator=g)
+    y = torch.empty((1, n), dtype=torch.float64, device="cuda").normal_(generator=g)
+    w = torch.empty((1, n), dtype=torch.float64, device="cuda").uniform_(generator=g)
+    plan = _plan_for(xh, [x, y], edges)
+    plan.set_param("partition", 1)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    try:
+        for s in (s1, s2, s1, s2):  # (both streams have their scratch memory before the pair that counts: a fresh hipMalloc waits for the GPU)
+            with torch.cuda.stream(s):
+                xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)
+            torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            a = xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)
+            d1 = plan.describe()
+        with torch.cuda.stream(s2):
+            b = xh._bincount_2d_vectorized(x, y, bins=edges, weights=w)
+            d2 = plan.describe()
+        torch.cuda.synchronize()
+    finally:
+        plan.set_param("partition", 0)
+    assert "exchange=if the probe" in d1, d1
+    assert "exchange=no" in d2, d2
+    torch.testing.assert_close(a, b, rtol=2.0 ** -34, atol=0)

@@ -178,6 +178,22 @@ static int execute_partitioned(xhist_plan* p, const xhist_array* samples, const 
 // part_accumulate_chunks, all on `stream`.  Returns XHIST_ERR_UNSUPPORTED (nothing launched) for what only
 // the multi-pass form takes: more than 128 partitions, tables that do not fit LDS next to the sort buffers,
 // in-bucket scans of 3 or 4 edges, integer samples.
+// The exchange mode's kernel wants every compute unit for itself (256 persistent workgroups that wait for one another): two
+// of them running on two streams of one GPU would each hold part of the chip and wait for the rest until their deadlines.
+// So a call whose stream is not the one the last exchange kernel of this device went to looks at that kernel's event first
+// and takes the classic passes when it has not finished.  (Other people's kernels on other streams can still hold compute
+// units back; that costs the deadline once and takes the plan off the mode — execute_partitioned_fused.)
+struct ExchInFlight {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  hipStream_t stream = nullptr;
+  bool armed = false;
+};
+static ExchInFlight& exch_in_flight(int device) {
+  static ExchInFlight slots[64];
+  return slots[device & 63];
+}
+
 static bool exact_records_env() {
   static const bool v = [] { const char* e = getenv("XHIST_AMD_EXACT_RECORDS"); return e && *e && *e != '0'; }();
   return v;
@@ -358,7 +374,14 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     k_xch = xhist_pick_exchange(D);
     k_xprobe = xhist_pick_exchange_probe(D);
     lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
-    if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max) {
+    bool other_stream_busy = false;
+    {
+      ExchInFlight& fl = exch_in_flight(p->device);
+      std::lock_guard<std::mutex> lk(fl.mu);
+      if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
+      (void)hipGetLastError();
+    }
+    if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max && !other_stream_busy) {
       xch = true;
       xch_probe = units > rows_per;  // (a histogram that fits the window needs no probe)
       xa.row_len = L;
@@ -368,7 +391,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.n_units = (int32_t)units;
       xa.force = p->exchange_pref > 0 ? 1 : 0;
       xa.min_ppm = 880000;
-      xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 2000) * 100000;
+      xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 500) * 100000;
       const size_t words_bytes = ((size_t)(units + 1 + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts
       HIPR(scratch_malloc(&x_ctl, sizeof(ExchCtl) * kExchXcds, stream));
       HIPR(scratch_malloc(&x_rings, (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8, stream));
@@ -475,6 +498,13 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       HIPR(hipGetLastError());
       XH_LAUNCH_PICKED(k_xch, dim3(kExchXcds * kExchRings), dim3(kExchBlock), lds_xch, stream, xa);
       HIPR(hipGetLastError());
+      {
+        ExchInFlight& fl = exch_in_flight(p->device);
+        std::lock_guard<std::mutex> lk(fl.mu);
+        if (!fl.ev && hipEventCreateWithFlags(&fl.ev, hipEventDisableTiming) != hipSuccess) { fl.ev = nullptr; (void)hipGetLastError(); }
+        if (fl.ev && hipEventRecord(fl.ev, stream) == hipSuccess) { fl.stream = stream; fl.armed = true; }
+        else { fl.armed = false; (void)hipGetLastError(); }
+      }
       ra.xgate = xa.win + 1;  // the classic packed kernels below return at once when the mode took the call
     }
     RouteArgs ra48 = ra;
