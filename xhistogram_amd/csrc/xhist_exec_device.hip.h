@@ -330,9 +330,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   uint32_t *d_ctr = nullptr, *d_plist = nullptr, *d_cmeta = nullptr;
   uint16_t* d_codes = nullptr;
   void* d_w = nullptr;
-  void *x_ctl = nullptr, *x_rings = nullptr, *x_part = nullptr, *x_side = nullptr, *x_words = nullptr;  // the exchange mode's scratch
+  void *x_ctl = nullptr, *x_part = nullptr;  // the exchange mode's scratch: what is zeroed per call (one block), and the XCD partials
+  int64_t x_zero_words = 0;
   auto release = [&](int rc) {
-    for (void* q : {x_ctl, x_rings, x_part, x_side, x_words})
+    for (void* q : {x_ctl, x_part})
       if (q) (void)scratch_free(q, stream);
     if (d_ctr) (void)scratch_free(d_ctr, stream);
     if (d_plist) (void)scratch_free(d_plist, stream);
@@ -393,16 +394,18 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.min_ppm = 880000;
       xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 500) * 100000;
       const size_t words_bytes = ((size_t)(units + 1 + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts
-      HIPR(scratch_malloc(&x_ctl, sizeof(ExchCtl) * kExchXcds, stream));
-      HIPR(scratch_malloc(&x_rings, (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8, stream));
+      // one block for everything that is zeroed per call (one launch): control words | window, cold arguments, probe counts | side copy | rings
+      const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)p->n_bins * 8;
+      const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8;
+      static_assert(sizeof(ExchCtl) % 8 == 0, "the block's parts stay 8-byte aligned");
+      x_zero_words = (int64_t)((ctl_bytes + words_bytes + side_bytes + rings_bytes) / 8);
+      HIPR(scratch_malloc(&x_ctl, ctl_bytes + words_bytes + side_bytes + rings_bytes, stream));
       HIPR(scratch_malloc(&x_part, (size_t)kExchXcds * kExchRings * (size_t)xa.local_bins * 8, stream));
-      HIPR(scratch_malloc(&x_side, (size_t)p->n_bins * 8, stream));
-      HIPR(scratch_malloc(&x_words, words_bytes, stream));
       xa.ctl = static_cast<ExchCtl*>(x_ctl);
-      xa.rings = static_cast<uint64_t*>(x_rings);
+      xa.win = reinterpret_cast<uint32_t*>(static_cast<char*>(x_ctl) + ctl_bytes);
+      xa.side = reinterpret_cast<double*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes);
+      xa.rings = reinterpret_cast<uint64_t*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes + side_bytes);
       xa.part = static_cast<double*>(x_part);
-      xa.side = static_cast<double*>(x_side);
-      xa.win = static_cast<uint32_t*>(x_words);
       xa.cold = reinterpret_cast<ExchCold*>(xa.win + 8);
       static_assert(sizeof(ExchCold) <= 32 * 4, "the cold arguments fit their 32 words");
       xa.counts = xa.win + 8 + 32;
@@ -474,10 +477,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     ra.xgate = nullptr;
     if (xch) {
       xa.flags = ctr + 1;
-      if (int zrc = zero_output(x_ctl, (int64_t)(sizeof(ExchCtl) * kExchXcds / 8), stream)) return release(zrc);
-      if (int zrc = zero_output(x_rings, (int64_t)kExchXcds * kExchRings * kExchRings * kExchCap, stream)) return release(zrc);
-      if (int zrc = zero_output(x_side, p->n_bins, stream)) return release(zrc);
-      if (int zrc = zero_output(x_words, (int64_t)((xa.n_units + 1 + 8 + 32) * 4 + 7) / 8, stream)) return release(zrc);
+      if (int zrc = zero_output(x_ctl, x_zero_words, stream)) return release(zrc);
       for (int d = 0; d < D; ++d) {  // (the arithmetic-edge constants of the float64 table set, whatever the classic routing pass digitizes with)
         const DimTable& t = p->ts[0][0].dim[d];
         xa.s_ptr[d] = static_cast<const double*>(samples[d].data);
