@@ -46,6 +46,9 @@
 #ifndef XSAME
 #define XSAME 0
 #endif
+#ifndef XHINT
+#define XHINT 0
+#endif
 #ifndef XCOLW
 #define XCOLW 0
 #endif
@@ -85,6 +88,7 @@ struct Ctl {                 // one per XCD
   uint32_t pad[31];
   uint32_t head[NS][NS];     // [producer p][consumer d]: records of ring (p -> d) the consumer has taken
   uint32_t fin[NS][NS];      // [producer p][consumer d]: final record count of the ring (0xFFFFFFFF while p produces)
+  uint32_t tailpub[NS][NS];  // [producer p][consumer d]: XHINT — records p has written (or is writing) into the ring: a hint of how far to look
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -173,10 +177,15 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
   const uint32_t psub = (uint32_t)tid >> 5, l = (uint32_t)tid & 31u;
   uint64_t rr[CL];
   uint32_t rh = 0;  // head the loads in rr were issued at
+  uint32_t hint = 0;  // XHINT: the ring's published tail as of the end of the tile before
   auto issue_ring_loads = [&]() {
     rh = chead[psub];
 #pragma unroll
-    for (int j = 0; j < CL; ++j) rr[j] = ld_l2(myring + (size_t)psub * CAP + ((rh + l + 32u * j) & (uint32_t)(CAP - 1)));
+    for (int j = 0; j < CL; ++j) {
+      const uint32_t pos = rh + l + 32u * j;
+      if (!XHINT || (int32_t)(hint - pos) > 0) rr[j] = ld_l2(myring + (size_t)psub * CAP + (pos & (uint32_t)(CAP - 1)));
+      else rr[j] = ~0ull ^ ((uint64_t)((((pos >> CAP_LOG2) + 1u) & 3u)) << 14);  // (a tag that is certainly not the expected one)
+    }
   };
   uint32_t taken_total = 0;
   auto take_ring_records = [&]() -> uint32_t {  // adds the valid prefix of what was loaded; returns its length (per ring)
@@ -355,6 +364,7 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
     // ---- a ring without room: keep taking (so that nobody waits for this workgroup) until the consumers caught up --
     while (MODE == 0 && misc[3]) {
       ++stalls;
+      if (XHINT) hint = ld_l2(&C.tailpub[psub][me]);
       issue_ring_loads();
       take_ring_records();
       if (tid < 32) credit[tid] = ld_l2(&C.head[me][tid]);
@@ -405,6 +415,10 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
       }
       PH(4);
     }
+    if (XHINT && MODE == 0) {
+      if (tid < 32) st_l2(&C.tailpub[me][tid], tail[tid]);
+      hint = ld_l2(&C.tailpub[psub][me]);
+    }
   }
   __syncthreads();
   if (aborted) {
@@ -415,6 +429,7 @@ __global__ void __launch_bounds__(BLOCK) xchg(const double* __restrict__ x, cons
   if (tid < 32) st_l2(&C.fin[me][tid], tail[tid]);
   if (MODE == 0) {
     for (;;) {
+      if (XHINT) hint = ld_l2(&C.tailpub[psub][me]);
       issue_ring_loads();
       const uint32_t pre = take_ring_records();
       bool done = false;

@@ -367,7 +367,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
   size_t lds_xch = 0;
   if (pack && rows == 1 && p->exchange_pref >= 0 && (!p->exchange_disabled || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
-      p->n_bins <= ((int64_t)1 << 28) && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
+      p->n_bins <= ((int64_t)1 << 23) /* (the side copy is zeroed per call) */ && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
     const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
     const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
     const int64_t units = (hist_rows + kExchUnitRows - 1) / kExchUnitRows;
