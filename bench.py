@@ -260,7 +260,7 @@ def build_workload(cfg, args, torch, dev, rank):
     w = torch.empty(n, dtype=f64, device=dev).uniform_(generator=g)
     return dict(
         arrays=[x, y], weights=w, edges=[np.linspace(-4.0, 4.0, 1025)] * 2, rows=1, cols=n, reduce="allreduce",
-        density=True,
+        density=True, wants_whole_gpu=True,
         metric="samples/s binned (2 x f64 + f64 weights), 2D weighted density, 1024x1024 bins, %s samples per GPU" % ("4*10^9" if args.full else "5*10^8"),
         workload="C5: 2-D weighted density histogram, %d samples per GPU (4*10^9 over 8), 1024x1024 uniform bins (beyond LDS: "
                  "partitioned multi-pass); density epilogue (core.py:444-462) on the reduced result of every step" % n,
@@ -446,6 +446,11 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             k = counter[0] & 1
             counter[0] += 1
             finish(k)  # the reduction that last used this buffer must be done
+            if reduce_partials and wl.get("wants_whole_gpu"):
+                # C5's exchange-mode kernel is 256 persistent workgroups that wait for one another: an RCCL
+                # kernel that holds a few compute units while ITS peers are busy would hold part of this kernel back for as
+                # long.  So step k + 1 starts when the all-reduce of step k is done (a stream-side wait, 8 MiB over xGMI)
+                finish(k ^ 1)
             out = outs[k]
             launch[k]()
             if reduce_partials:
@@ -630,7 +635,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 "weighted": weighted,
                 "kernel": m["desc"],
                 "parallelism": ("sample-axis shards, one per GPU" if wl["reduce"] == "allreduce" else "kept-axis (time) shards, one per GPU, disjoint output rows")
-                + ("; all-reduce(sum) of the partial histogram over RCCL each step, overlapped with the next step's kernel" if reduce_partials else ""),
+                + (("; all-reduce(sum) of the partial histogram over RCCL each step, " + ("finished before the next step's kernel starts (it wants every compute unit)" if wl.get("wants_whole_gpu") else "overlapped with the next step's kernel")) if reduce_partials else ""),
             },
             "roofline": roof,
             "kernel_ms_per_rank": m["kernel_ms_per_rank"],
