@@ -285,6 +285,13 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
+  bool other_stream_busy = false;  // an exchange kernel of ANOTHER stream may still hold the GPU (looked at before the scratch allocations below)
+  if (pack && p->exchange_pref >= 0) {
+    ExchInFlight& fl = exch_in_flight(p->device);
+    std::lock_guard<std::mutex> lk(fl.mu);
+    if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
+    (void)hipGetLastError();
+  }
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
   const int tile = route_tile(block, spl);
   const size_t lds_route = part_route_lds((size_t)table_words * 8, n_parts, weighted, tile, block);
@@ -375,13 +382,6 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     k_xch = xhist_pick_exchange(D);
     k_xprobe = xhist_pick_exchange_probe(D);
     lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
-    bool other_stream_busy = false;
-    {
-      ExchInFlight& fl = exch_in_flight(p->device);
-      std::lock_guard<std::mutex> lk(fl.mu);
-      if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
-      (void)hipGetLastError();
-    }
     if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max && !other_stream_busy) {
       xch = true;
       xch_probe = units > rows_per;  // (a histogram that fits the window needs no probe)
