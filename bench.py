@@ -263,7 +263,7 @@ def build_workload(cfg, args, torch, dev, rank):
         density=True, wants_whole_gpu=True,
         metric="samples/s binned (2 x f64 + f64 weights), 2D weighted density, 1024x1024 bins, %s samples per GPU" % ("4*10^9" if args.full else "5*10^8"),
         workload="C5: 2-D weighted density histogram, %d samples per GPU (4*10^9 over 8), 1024x1024 uniform bins (beyond LDS: "
-                 "partitioned multi-pass); density epilogue (core.py:444-462) on the reduced result of every step" % n,
+                 "the exchange mode where the samples are concentrated, else the partitioned passes, DESIGN 4.2 / 4.2b); density epilogue (core.py:444-462) on the reduced result of every step" % n,
         dtype="f64", data="synthetic (two N(0,1) arrays + U[0,1) weights, generated on device)")
 
 
