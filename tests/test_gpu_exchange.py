@@ -229,76 +229,3 @@ def test_exchange_mode_keeps_its_kernels_from_meeting_on_two_streams(xh):
     assert "exchange=if the probe" in d1, d1
     assert "exchange=no" in d2, d2
     torch.testing.assert_close(a, b, rtol=2.0 ** -34, atol=0)
-
-
-# ---- counts (no weights): 4-byte records into uint32 LDS rows — twice the bins per workgroup, 1024 x 1024 fits the window whole ----
-@pytest.mark.parametrize("dist", ["normal", "uniform"])
-@pytest.mark.parametrize("n", [4, 4097, 2_000_003])
-def test_exchange_mode_counts_c5_shape(xh, n, dist):
-    """unweighted joint counts into 1024 x 1024 bins: the whole histogram is the window (32 rows of 1024 uint32 counters per
-    workgroup), so uniform samples take the mode as well as concentrated ones; int64 counts identical to the oracle's"""
-    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
-    rng = np.random.default_rng(700 + n % 89)
-    if dist == "normal":
-        x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
-    else:
-        x, y = rng.uniform(-4.2, 4.2, (1, n)), rng.uniform(-4, 4, (1, n))
-    x[0, ::97] = np.nan
-    y[0, 5::89] = 4.0  # the right edge counts
-    want = onp.bincount_rows([x, y], edges)
-    got, desc = _exchange(xh, [x, y], edges, None)
-    assert got.dtype == want.dtype
-    np.testing.assert_array_equal(got, want)
-    classic, desc = _run(xh, [x, y], edges, None, True, partition=1, exchange=-1)
-    assert "exchange=no" in desc, desc
-    np.testing.assert_array_equal(classic, want)
-
-
-@pytest.mark.parametrize("case", ["1d", "3d", "beyond_the_window", "one_row"])
-def test_exchange_mode_counts_other_shapes(xh, case):
-    rng = np.random.default_rng(21)
-    n = 1_200_011
-    if case == "1d":
-        edges = [np.linspace(-5, 5, 600_001)]
-        samples = [rng.standard_normal((1, n)) * 2.0]
-    elif case == "3d":
-        edges = [np.linspace(-3, 3, 65), np.linspace(-3, 3, 49), np.linspace(0, 1, 401)]
-        samples = [rng.standard_normal((1, n)), rng.standard_normal((1, n)), rng.uniform(-0.05, 1.05, (1, n))]
-    elif case == "beyond_the_window":  # 4*10^6 bins: 16 rows of 2000 per workgroup = 512 of 2000 rows; the rest by memory-side atomics
-        edges = [np.linspace(-3, 3, 2001), np.linspace(-3, 3, 2001)]
-        samples = [rng.standard_normal((1, n)), rng.standard_normal((1, n))]
-    else:  # every record to one owner
-        edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
-        samples = [np.full((1, n), 1.2345), rng.standard_normal((1, n))]
-    want = onp.bincount_rows(samples, edges)
-    got, _ = _exchange(xh, samples, edges, None)
-    np.testing.assert_array_equal(got, want)
-
-
-def test_exchange_mode_counts_by_default_whatever_the_distribution(xh):
-    """default settings, 2^25 uniform pairs into 1024 x 1024 bins: no probe is needed (the histogram fits the window), the mode
-    takes the call; and a deadline that has passed hands the call to the classic passes"""
-    import torch
-
-    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
-    n = 1 << 25
-    g = torch_gen(18)
-    x = torch.empty((1, n), dtype=torch.float64, device="cuda").uniform_(-4, 4, generator=g)
-    y = torch.empty((1, n), dtype=torch.float64, device="cuda").uniform_(-4, 4, generator=g)
-    plan = _plan_for(xh, [x, y], edges)
-    plan.set_param("partition", 1)
-    try:
-        auto = xh._bincount_2d_vectorized(x, y, bins=edges)
-        assert "exchange=whole histogram in the window" in plan.describe(), plan.describe()
-        plan.set_param("exchange_budget_ms", -1)
-        late = xh._bincount_2d_vectorized(x, y, bins=edges)
-        plan.set_param("exchange_budget_ms", 0)
-        plan.set_param("exchange", -1)
-        classic = xh._bincount_2d_vectorized(x, y, bins=edges)
-    finally:
-        plan.set_param("exchange_budget_ms", 0)
-        plan.set_param("exchange", 0)
-        plan.set_param("partition", 0)
-    assert int(auto.sum()) == n
-    assert torch.equal(auto, classic)
-    assert torch.equal(late, classic)

@@ -2,7 +2,7 @@
 passes of the same library, both on the GPU (development tool; the classic passes are held to the oracle by the test-suite and
 by tools/soak.py).  Random shapes: 1-3 inputs, bins per input, np.linspace ranges, sample distributions (normal, uniform, a
 constant, heavy NaN / infinity mixes, samples ON edges), weights of one sign (either), both signs now and then (the exact
-fallback), no weights at all (counts, compared exactly), sizes around the 4096-sample tile and up to a few million.
+fallback), sizes around the 4096-sample tile and up to a few million.
 
     python tools/soak_exchange.py [seconds] [seed]
 """
@@ -64,9 +64,8 @@ def one(seed):
     if rng.random() < 0.1:
         w[rng.integers(0, n, 3)] = np.nan
     w = w[None, :]
-    unweighted = rng.random() < 0.4
     dev = [torch.as_tensor(np.ascontiguousarray(s)).cuda() for s in samples]
-    wd = None if unweighted else torch.as_tensor(np.ascontiguousarray(w)).cuda()
+    wd = torch.as_tensor(np.ascontiguousarray(w)).cuda()
     plan = core._get_plan(edges, _native.CMP_F64, 0)
     out = {}
     for mode in (-1, 1):
@@ -83,8 +82,8 @@ def one(seed):
             return ("skipped", desc[-80:])
     a, b = out[-1], out[1]
     scale = float(np.nanmax(np.abs(w))) if np.isfinite(np.nanmax(np.abs(w))) else 1.0
-    ok = np.array_equal(a, b) if unweighted else np.allclose(a, b, rtol=1e-9, atol=1e-9 * scale * max(1, n) ** 0.5, equal_nan=True)
-    return ("ok" if ok else "MISMATCH", dict(seed=seed, d=d, nbs=nbs, n=n, sign=float(sign), unweighted=bool(unweighted), worst=float(np.nanmax(np.abs(a - b))) if not ok else 0.0))
+    ok = np.allclose(a, b, rtol=1e-9, atol=1e-9 * scale * max(1, n) ** 0.5, equal_nan=True)
+    return ("ok" if ok else "MISMATCH", dict(seed=seed, d=d, nbs=nbs, n=n, sign=float(sign), worst=float(np.nanmax(np.abs(a - b))) if not ok else 0.0))
 
 
 def main():

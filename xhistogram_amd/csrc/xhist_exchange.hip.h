@@ -28,9 +28,10 @@
 //     exchange_probe histograms the rows of 2.6*10^5 samples spread over the input, exchange_pick takes the best window and
 //     switches the mode on when it holds >= 88 % of them — both on the GPU, every call, no host synchronisation; classic
 //     kernels queued behind return at once when the mode is on, these return at once when it is off.
-//   * Weights of both signs, a workgroup placement other than 32 per XCD, or a deadline that expires: the kernel reports
-//     "both signs" in the flags word of the packed routing pass, so the exact routing + adding-up passes queued behind it
-//     redo the whole call from the (untouched) output — this kernel and exchange_merge write only scratch until the merge.
+//   * Weights of both signs: the kernel reports them in the flags word of the packed routing pass, its merge does not run, and
+//     the exact routing + adding-up passes queued behind redo the whole call from the (untouched) output — this kernel and
+//     exchange_merge write only scratch until the merge.  A workgroup placement other than 32 per XCD, or a wait that outlives
+//     its deadline: the mode is switched off for the call, and the classic packed passes queued behind take it.
 //
 // Traffic per C5 sample: 24 B read, 8 B written to the rings and 8 B read from them.  The counters say every ring read
 // misses the L2 (the sample stream evicts the rings: FETCH 15.8 GB per 5*10^8 samples = 12.0 of samples + 3.74 of records;
@@ -50,7 +51,6 @@ constexpr int kExchXcds = 8, kExchRings = 32;            // XCDs of the chip; wo
 constexpr int kExchCapLog2 = 9, kExchCap = 1 << kExchCapLog2;  // records per ring (256: producers wait for credits half the time, 4.04 against 3.3 ms)
 constexpr int kExchTake = 4;                             // ring records a lane looks at per tile (6: 3.34 against 3.15 ms — what it finds not yet written is traffic too)
 constexpr int kExchMaxLocal = 15360;                     // bins a workgroup keeps: 120 KB of float64 next to the tile's 36 KB
-constexpr int kExchMaxLocalCounts = 32768;               // ... of uint32 counters (unweighted): 128 KB next to the tile's 20 KB; a record's 15 code bits
 constexpr int kExchCtlBytes = 2048;
 constexpr uint32_t kExchUnitRows = 32;                   // the probe counts rows in units of 32; a window starts on a unit
 
@@ -76,7 +76,7 @@ struct ExchCold {
   long long budget_ticks;
   uint32_t* flags;
   uint32_t* note;
-  void* part;
+  double* part;
 };
 
 struct ExchArgs {
@@ -85,9 +85,9 @@ struct ExchArgs {
   int64_t n;                 // samples
   ExchDim dim[3];
   ExchCtl* ctl;              // [kExchXcds], zeroed per call
-  void* rings;               // [xcd][owner][producer][kExchCap] records (8 bytes; 4 for counts), zeroed per call (tag 0 = never written)
-  void* part;                // [xcd][owner][local_bins]: the XCD partials of the window (float64 sums / uint32 counts)
-  void* side;                // [n_bins] float64 / uint64, zeroed per call: samples outside the window
+  uint64_t* rings;           // [xcd][owner][producer][kExchCap], zeroed per call (tag 0 = never written)
+  double* part;              // [xcd][owner][local_bins]: the XCD partials of the window
+  double* side;              // [n_bins], zeroed per call: samples outside the window
   uint32_t* win;             // device words: [0] first row of the window, [1] mode on, [2] coverage in ppm (exchange_pick writes them)
   ExchCold* cold;            // device copy of the rarely needed arguments (exchange_pick writes it)
   uint32_t* counts;          // [n_units + 1] rows of the probe's samples per unit of 32 rows, zeroed per call
@@ -103,8 +103,8 @@ struct ExchArgs {
   long long budget_ticks;    // deadline of a workgroup's waits, in ticks of the 100 MHz clock
 };
 
-__host__ __device__ constexpr size_t exchange_lds(int local_bins, bool weighted = true) {
-  return (((size_t)local_bins * (weighted ? 8 : 4) + 15) & ~(size_t)15) + (size_t)kExchTile * (weighted ? 8 : 4) + kExchTile + kExchCtlBytes;
+__host__ __device__ constexpr size_t exchange_lds(int local_bins) {
+  return (((size_t)local_bins * 8 + 15) & ~(size_t)15) + (size_t)kExchTile * 8 + kExchTile + kExchCtlBytes;
 }
 
 __device__ __forceinline__ uint32_t exch_xcc_id() {
@@ -265,22 +265,16 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
   xa.cold->part = xa.part;
 }
 
-// W: float64 weights as packed 8-byte records into float64 LDS rows; !W: counts — 4-byte records {15-bit bin, 2-bit lap tag} into
-// uint32 LDS rows (twice the bins per workgroup: 32 rows of 1024 — the whole 1024 x 1024 histogram is the window)
-template <int D, bool W = true>
+template <int D>
 __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   constexpr int BLOCK = kExchBlock, TILE = kExchTile, NS = kExchRings, CAP = kExchCap, CAPL = kExchCapLog2, CL = kExchTake;
-  using rec_t = typename std::conditional<W, uint64_t, uint32_t>::type;
-  using acc_t = typename std::conditional<W, double, uint32_t>::type;
-  constexpr int TAGSH = W ? 14 : 15;                       // where the lap tag sits in a record
-  constexpr uint32_t CODEM = W ? 0x3fffu : 0x7fffu;        // ... and the bin inside the owner's rows
   typedef double d2 __attribute__((ext_vector_type(2)));
   if (__builtin_nontemporal_load(xa.win + 1) == 0u) return;  // the window does not hold enough of this call's samples
   const int tid = threadIdx.x;
-  const size_t hist_bytes = ((size_t)xa.local_bins * sizeof(acc_t) + 15) & ~(size_t)15;
-  acc_t* hist = reinterpret_cast<acc_t*>(xhist_smem);
-  rec_t* srec = reinterpret_cast<rec_t*>(xhist_smem + hist_bytes);         // [TILE] the tile's ring records, by owner
-  uint8_t* sd = xhist_smem + hist_bytes + (size_t)TILE * sizeof(rec_t);                 // [TILE] owner of every staged record
+  const size_t hist_bytes = ((size_t)xa.local_bins * 8 + 15) & ~(size_t)15;
+  double* hist = reinterpret_cast<double*>(xhist_smem);
+  uint64_t* srec = reinterpret_cast<uint64_t*>(xhist_smem + hist_bytes);   // [TILE] the tile's ring records, by owner
+  uint8_t* sd = xhist_smem + hist_bytes + (size_t)TILE * 8;                 // [TILE] owner of every staged record
   uint32_t* c = reinterpret_cast<uint32_t*>(sd + TILE);
   uint32_t* cnt2 = c;          // [2][64] records per owner of the tile, alternating per tile
   uint32_t* off = c + 128;     // [64] first staged slot of every owner; [32] = records staged
@@ -294,7 +288,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   uint32_t* misc = c + 416;    // [0] XCD [1] place [3] runs not written out yet [4] abort
   const volatile ExchCold* cold = xa.cold;
 
-  for (int i = tid; i < xa.local_bins; i += BLOCK) hist[i] = (acc_t)0;
+  for (int i = tid; i < xa.local_bins; i += BLOCK) hist[i] = 0.0;
   if (tid < 128) cnt2[tid] = 0u;
   if (tid < NS) { tail[tid] = 0u; credit[tid] = 0u; chead[tid] = 0u; }
   if (tid == 0) {
@@ -311,19 +305,19 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   if (me >= (uint32_t)NS) {  // not 32 workgroups on this XCD: no ring ends here — everybody leaves, the exact passes redo the call
     if (tid == 0) {
       exch_st(g_abort, 1u);
-      exch_st(xa.win + 1, 0u);  // the mode is off for this call after all: the classic kernels queued behind take it
+      exch_st(xa.win + 1, 0u);  // the mode is off for this call after all: the classic packed passes queued behind take it
       if (cold->note) atomicAdd(cold->note + 2, 1u);
     }
     return;
   }
   ExchCtl& C = xa.ctl[xcd];
-  rec_t* xring = static_cast<rec_t*>(xa.rings) + (size_t)xcd * NS * NS * CAP;   // [owner][producer][CAP]
-  const rec_t* myring = xring + (size_t)me * NS * CAP;                           // the rings that end here
+  uint64_t* xring = xa.rings + (size_t)xcd * NS * NS * CAP;        // [owner][producer][CAP]
+  const uint64_t* myring = xring + (size_t)me * NS * CAP;          // the rings that end here
   const uint32_t r0 = __builtin_nontemporal_load(xa.win + 0);
   const uint32_t win_rows = (uint32_t)NS * (uint32_t)xa.rows_per;
   const uint32_t L = (uint32_t)xa.row_len;
   const int64_t n = xa.n;
-  acc_t* side_w = static_cast<acc_t*>(xa.side);  // (counts: uint64 words, see the add below)
+  double* side = xa.side;
 
   const int64_t n_tiles = (n + TILE - 1) / TILE;
   const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
@@ -337,7 +331,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     return t;
   };
   // a lane's samples of a tile: two pairs, 2048 samples apart (16-byte lane loads, dense across the wavefront)
-  d2 xv[D][2], wv[W ? 2 : 1];
+  d2 xv[D][2], wv[2];
   auto load_tile = [&](int64_t base) {
     if (base + TILE <= n) {
 #pragma unroll
@@ -345,7 +339,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         const uint32_t e = (lane_now() * 2u + (uint32_t)u * 2u * BLOCK) * 8u;
 #pragma unroll
         for (int d = 0; d < D; ++d) xv[d][u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(reinterpret_cast<const char*>(xa.s_ptr[d] + base) + e));
-        if constexpr (W) wv[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(reinterpret_cast<const char*>(xa.w_ptr + base) + e));
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(reinterpret_cast<const char*>(xa.w_ptr + base) + e));
       }
     } else {  // the tile that holds the end of the input (once per call): positions past the end are NaN samples, dropped
 #pragma unroll
@@ -355,20 +349,20 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
           const int64_t i = base + (int64_t)tid * 2 + (int64_t)u * 2 * BLOCK + v;
 #pragma unroll
           for (int d = 0; d < D; ++d) xv[d][u][v] = i < n ? xa.s_ptr[d][i] : (double)__builtin_nanf("");
-          if constexpr (W) wv[u][v] = i < n ? xa.w_ptr[i] : 0.0;
+          wv[u][v] = i < n ? xa.w_ptr[i] : 0.0;
         }
     }
   };
   // ---- the consumer side: 32 lanes per ring, CL records each ---------------------------------------------------
   const uint32_t psub = (uint32_t)tid >> 5, l = (uint32_t)tid & 31u;
-  rec_t rr[CL];
+  uint64_t rr[CL];
   uint32_t rh = 0;
   auto issue_ring_loads = [&]() {
     const uint32_t t = lane_now(), ps = t >> 5, ll = t & 31u;
     rh = chead[ps];
 #pragma unroll
     for (int j = 0; j < CL; ++j)
-      rr[j] = exch_ld(reinterpret_cast<const rec_t*>(reinterpret_cast<const char*>(myring) + ((ps << CAPL) + ((rh + ll + 32u * j) & (uint32_t)(CAP - 1))) * (uint32_t)sizeof(rec_t)));
+      rr[j] = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + ((ps << CAPL) + ((rh + ll + 32u * j) & (uint32_t)(CAP - 1))) * 8u));
   };
   auto take_ring_records = [&]() {  // adds the valid prefix of what was loaded
     const uint32_t tid = lane_now(), psub = tid >> 5, l = tid & 31u;
@@ -378,7 +372,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     for (int j = 0; j < CL; ++j) {
       const uint32_t pos = rh + l + 32u * j;
       const uint32_t expect = ((pos >> CAPL) + 1u) & 3u;
-      const bool valid = (((uint32_t)rr[j] >> TAGSH) & 3u) == expect;
+      const bool valid = (((uint32_t)rr[j] >> 14) & 3u) == expect;
       const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
       const uint32_t m = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
       if (cont) {
@@ -389,9 +383,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
 #pragma unroll
     for (int j = 0; j < CL; ++j)
       if (l + 32u * j < pre) {
-        const rec_t r = rr[j];
-        if constexpr (W) unsafeAtomicAdd(hist + ((uint32_t)r & CODEM), __longlong_as_double((long long)(r & ~0xffffull)));
-        else atomicAdd(hist + ((uint32_t)r & CODEM), 1u);
+        const uint64_t r = rr[j];
+        unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)(r & ~0xffffull)));
       }
     if (l == 0 && pre) {
       chead[psub] = rh + pre;
@@ -406,15 +399,12 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
 #pragma unroll 1
     for (int j = 0; j < CL; ++j) {
       const uint32_t pos = h + l + 32u * j;
-      const rec_t r = exch_ld(reinterpret_cast<const rec_t*>(reinterpret_cast<const char*>(myring) + ((psub << CAPL) + (pos & (uint32_t)(CAP - 1))) * (uint32_t)sizeof(rec_t)));
-      const bool valid = (((uint32_t)r >> TAGSH) & 3u) == (((pos >> CAPL) + 1u) & 3u);
+      const uint64_t r = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + ((psub << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u));
+      const bool valid = (((uint32_t)r >> 14) & 3u) == (((pos >> CAPL) + 1u) & 3u);
       const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
       const uint32_t m = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
       const uint32_t kk = !cont ? 0u : (m == 0xffffffffu ? 32u : (uint32_t)__builtin_ctz(~m));
-      if (l < kk) {
-        if constexpr (W) unsafeAtomicAdd(hist + ((uint32_t)r & CODEM), __longlong_as_double((long long)(r & ~0xffffull)));
-        else atomicAdd(hist + ((uint32_t)r & CODEM), 1u);
-      }
+      if (l < kk) unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)(r & ~0xffffull)));
       pre += kk;
       cont = cont && kk == 32u;
     }
@@ -436,7 +426,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     // ---- digitize; owner and record of every sample; what lies outside the window goes straight to the side copy of the
     // output, with the weight as it was read -------------------------------------------------------------------------
     uint32_t dest[4];  // owner (32: outside the window, 33: dropped)
-    rec_t rec[4];
+    uint64_t rec[4];
     {
       double xs[D][4];
 #pragma unroll
@@ -455,26 +445,18 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         exch_row_col<D>(gg, xa, row, col);
         const uint32_t r = row - r0;
         const bool in_win = ins[s4] & (r < win_rows);
+        const double wq = wv[s4 >> 1][s4 & 1];
+        bool special;
+        rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
+        special_any |= special;
         dest[s4] = in_win ? (r & 31u) : (ins[s4] ? 32u : 33u);
-        const uint32_t flat_off = ((D == 1) ? gg[0] : row * L + col) * 8u;
-        if constexpr (W) {
-          const double wq = wv[s4 >> 1][s4 & 1];
-          bool special;
-          rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
-          special_any |= special;
-          if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side_w) + flat_off), wq);
-          s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
-          s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
-        } else {
-          rec[s4] = (r >> 5) * L + col;
-          if (ins[s4] & !in_win) atomicAdd(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(side_w) + flat_off), 1ull);
-        }
+        if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side) + ((D == 1) ? gg[0] : row * L + col) * 8u), wq);
+        s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
+        s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
       }
-      if constexpr (W) {
-        if (__builtin_amdgcn_ballot_w64(special_any) != 0ull) {  // NaN / infinite / top-binade weights: the careful rounding
+      if (__builtin_amdgcn_ballot_w64(special_any) != 0ull) {  // NaN / infinite / top-binade weights: the careful rounding
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) rec[s4] = (uint64_t)__double_as_longlong(pack48(wv[s4 >> 1][s4 & 1], (uint32_t)rec[s4] & 0x3fffu));
-        }
+        for (int s4 = 0; s4 < 4; ++s4) rec[s4] = (uint64_t)__double_as_longlong(pack48(wv[s4 >> 1][s4 & 1], (uint32_t)rec[s4] & 0x3fffu));
       }
     }
     // ---- ring loads first (older), then the next tile's samples (newer): waiting for the former leaves the latter in flight
@@ -525,8 +507,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
           const uint32_t d = sd[i];
           const uint32_t pos = wadj[d] + i;
           const uint32_t tag = ((pos >> CAPL) + 1u) & 3u;
-          *reinterpret_cast<rec_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * (uint32_t)sizeof(rec_t)) =
-              (srec[i] & ~((rec_t)3 << TAGSH)) | ((rec_t)tag << TAGSH);
+          *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u) =
+              (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
         }
       }
     } else {
@@ -540,8 +522,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
             if (j >= sent[d] && j < lim[d]) {
               const uint32_t pos = wadj[d] + i;
               const uint32_t tag = ((pos >> CAPL) + 1u) & 3u;
-              *reinterpret_cast<rec_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * (uint32_t)sizeof(rec_t)) =
-                  (srec[i] & ~((rec_t)3 << TAGSH)) | ((rec_t)tag << TAGSH);
+              *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u) =
+                  (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
             }
           }
         }
@@ -588,40 +570,36 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   if (aborted) {
     if (tid == 0) {
       exch_st(g_abort, 1u);
-      exch_st(xa.win + 1, 0u);  // the mode is off for this call after all: the classic kernels queued behind take it
+      exch_st(xa.win + 1, 0u);  // the mode is off for this call after all: the classic packed passes queued behind take it
       if (cold->note) atomicAdd(cold->note + 2, 1u);
     }
     return;
   }
   __syncthreads();
-  acc_t* po = static_cast<acc_t*>(cold->part) + ((size_t)xcd * NS + me) * (size_t)xa.local_bins;
+  double* po = cold->part + ((size_t)xcd * NS + me) * (size_t)xa.local_bins;
   for (int i = tid; i < xa.local_bins; i += BLOCK) po[i] = hist[i];
-  if constexpr (W) {
-    const uint32_t signs = (s_neg ? 1u : 0u) | (s_pos ? 2u : 0u);
-    if ((tid & 63) == 0 && signs) atomicOr(cold->flags, signs);
-  }
+  const uint32_t signs = (s_neg ? 1u : 0u) | (s_pos ? 2u : 0u);
+  if ((tid & 63) == 0 && signs) atomicOr(cold->flags, signs);
 }
 
-// out += side + (inside the window) the eight XCD partials.  Runs when the mode was on (and stayed on: an aborted exchange
-// switches it off) and — weighted — the weights had one sign; otherwise the classic / exact passes queued behind fill the output.
-template <bool W>
-__global__ void __launch_bounds__(256) exchange_merge(const ExchArgs xa, void* out_v, int64_t n_bins) {
-  using acc_t = typename std::conditional<W, double, uint32_t>::type;
-  using out_t = typename std::conditional<W, double, unsigned long long>::type;
+// out += side + (inside the window) the eight XCD partials.  Runs when the mode was on and the weights had one sign;
+// otherwise the exact passes queued behind fill the output.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) exchange_merge(const ExchArgs xa, double* out, int64_t n_bins) {
   if (__builtin_nontemporal_load(xa.win + 1) == 0u) return;
-  if (W && (__builtin_nontemporal_load(xa.flags) & 3u) == 3u) return;
+  if ((__builtin_nontemporal_load(xa.flags) & 3u) == 3u) return;
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= n_bins) return;
   const uint32_t L = (uint32_t)xa.row_len;
   const uint32_t row = (uint32_t)(f / L), col = (uint32_t)(f - (int64_t)row * L);
   const uint32_t r = row - __builtin_nontemporal_load(xa.win + 0);
-  out_t s = static_cast<const out_t*>(xa.side)[f];
+  double s = xa.side[f];
   if (r < (uint32_t)kExchRings * (uint32_t)xa.rows_per) {
     const uint32_t d = r & 31u, local = (r >> 5) * L + col;
 #pragma unroll
-    for (int xc = 0; xc < kExchXcds; ++xc) s += (out_t)static_cast<const acc_t*>(xa.part)[((size_t)xc * kExchRings + d) * (size_t)xa.local_bins + local];
+    for (int xc = 0; xc < kExchXcds; ++xc) s += xa.part[((size_t)xc * kExchRings + d) * (size_t)xa.local_bins + local];
   }
-  if (s != (out_t)0) static_cast<out_t*>(out_v)[f] += s;
+  if (s != 0.0) out[f] += s;
 }
 
 }  // namespace xhist

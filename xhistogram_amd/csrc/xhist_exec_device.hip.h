@@ -286,7 +286,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
   bool other_stream_busy = false;  // an exchange kernel of ANOTHER stream may still hold the GPU (looked at before the scratch allocations below)
-  if ((pack || !weighted) && p->exchange_pref >= 0) {
+  if (pack && p->exchange_pref >= 0) {
     ExchInFlight& fl = exch_in_flight(p->device);
     std::lock_guard<std::mutex> lk(fl.mu);
     if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
@@ -373,16 +373,15 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   bool xch = false, xch_probe = false;
   kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
   size_t lds_xch = 0;
-  if ((pack || !weighted) && rows == 1 && p->exchange_pref >= 0 && (!p->exchange_disabled || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
+  if (pack && rows == 1 && p->exchange_pref >= 0 && (!p->exchange_disabled || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
       p->n_bins <= ((int64_t)1 << 23) /* (the side copy is zeroed per call) */ && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
     const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
     const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
     const int64_t units = (hist_rows + kExchUnitRows - 1) / kExchUnitRows;
-    const int64_t max_local = weighted ? kExchMaxLocal : kExchMaxLocalCounts;  // float64 sums / uint32 counts in LDS
-    const int64_t rows_per = L <= max_local ? std::min<int64_t>(max_local / L, units) : 0;
-    k_xch = xhist_pick_exchange(D, weighted);
+    const int64_t rows_per = L <= kExchMaxLocal ? std::min<int64_t>(kExchMaxLocal / L, units) : 0;
+    k_xch = xhist_pick_exchange(D);
     k_xprobe = xhist_pick_exchange_probe(D);
-    lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L), weighted) : 0;
+    lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
     if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max && !other_stream_busy) {
       xch = true;
       xch_probe = units > rows_per;  // (a histogram that fits the window needs no probe)
@@ -397,16 +396,16 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       const size_t words_bytes = ((size_t)(units + 1 + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts
       // one block for everything that is zeroed per call (one launch): control words | window, cold arguments, probe counts | side copy | rings
       const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)p->n_bins * 8;
-      const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * (weighted ? 8 : 4);
+      const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8;
       static_assert(sizeof(ExchCtl) % 8 == 0, "the block's parts stay 8-byte aligned");
       x_zero_words = (int64_t)((ctl_bytes + words_bytes + side_bytes + rings_bytes) / 8);
       HIPR(scratch_malloc(&x_ctl, ctl_bytes + words_bytes + side_bytes + rings_bytes, stream));
-      HIPR(scratch_malloc(&x_part, (size_t)kExchXcds * kExchRings * (size_t)xa.local_bins * (weighted ? 8 : 4), stream));
+      HIPR(scratch_malloc(&x_part, (size_t)kExchXcds * kExchRings * (size_t)xa.local_bins * 8, stream));
       xa.ctl = static_cast<ExchCtl*>(x_ctl);
       xa.win = reinterpret_cast<uint32_t*>(static_cast<char*>(x_ctl) + ctl_bytes);
-      xa.side = static_cast<char*>(x_ctl) + ctl_bytes + words_bytes;
-      xa.rings = static_cast<char*>(x_ctl) + ctl_bytes + words_bytes + side_bytes;
-      xa.part = x_part;
+      xa.side = reinterpret_cast<double*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes);
+      xa.rings = reinterpret_cast<uint64_t*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes + side_bytes);
+      xa.part = static_cast<double*>(x_part);
       xa.cold = reinterpret_cast<ExchCold*>(xa.win + 8);
       static_assert(sizeof(ExchCold) <= 32 * 4, "the cold arguments fit their 32 words");
       xa.counts = xa.win + 8 + 32;
@@ -489,7 +488,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
         xa.dim[d].arith_h = t.arith_h;
         xa.dim[d].nb = t.nb;
       }
-      xa.w_ptr = weighted ? static_cast<const double*>(weights->data) : nullptr;
+      xa.w_ptr = static_cast<const double*>(weights->data);
       xa.n = n_cols;
       if (xch_probe) {
         XH_LAUNCH_PICKED(k_xprobe, dim3(256), dim3(256), 0, stream, xa);
@@ -532,7 +531,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     XH_LAUNCH_PICKED(k_acc, dim3(Gb), dim3(1024), lds_acc, stream, ra, out, p->n_bins, shift, n_parts, rows > 1 ? parts_per_row : 0);
     HIPR(hipGetLastError());
     if (xch) {  // (runs when the mode was on and the weights had one sign: exactly when none of the four kernels above did)
-      XH_LAUNCH_PICKED(xhist_pick_exchange_merge(weighted), dim3((unsigned)((p->n_bins + 255) / 256)), dim3(256), 0, stream, xa, out, p->n_bins);
+      XH_LAUNCH_PICKED(xhist_pick_exchange_merge(), dim3((unsigned)((p->n_bins + 255) / 256)), dim3(256), 0, stream, xa, static_cast<double*>(out), p->n_bins);
       HIPR(hipGetLastError());
     }
   }
