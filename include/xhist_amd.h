@@ -223,7 +223,8 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       XCD; auto = float64 samples + float64 weights on numpy.linspace-style edges, one row of >= 2^25 samples, a chip of
  *       8 x 32 compute units, and a window that a probe on the GPU finds to hold 88 % of the call's samples; setting the key
  *       also re-admits a plan that an aborted exchange had taken off the mode), "exchange_budget_ms" (0 = 500: how long a
- *       workgroup of that mode waits for its peers before the call is redone with exact records; -1: not at all — tests),
+ *       workgroup of that mode waits for its peers before the mode is switched off for the call and the classic passes queued
+ *       behind take it; -1: not at all — tests),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "arith32" (0 auto / 1 prefer / -1 never: float32 samples on such edges digitized in float32 arithmetic),

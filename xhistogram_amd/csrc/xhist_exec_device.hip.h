@@ -275,12 +275,11 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   }
   if (p->mixed_hint && p->mixed_hint[2] != p->exchange_aborts_seen) {
     // an exchange kernel of an earlier call gave up (workgroups not all resident — another stream's kernel held compute units —
-    // or not 32 per XCD) and the exact passes redid that call: not a property of the weights, so the plan forgets the "both
-    // signs" note that redo left, and stays away from the mode (a second hang would cost its deadline again)
+    // or not 32 per XCD) and the classic passes took that call: the plan stays away from the mode (a second hang would cost its
+    // deadline again) until "exchange" is set again
     std::lock_guard<std::mutex> lk(p->mu);
     p->exchange_aborts_seen = p->mixed_hint[2];
     p->exchange_disabled = true;
-    p->mixed_hint[0] = 0u;
   }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
