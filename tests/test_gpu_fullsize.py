@@ -61,7 +61,7 @@ def test_c4_full_size_time_lat_lon(xh):
 
 def test_c5_full_size_4e9_samples_weighted_density(xh):
     """4*10^9 samples (x, y, w float64 = 96 GB), 1024 x 1024 bins, weighted, density (C5 on ONE GPU): the
-    partitioned multi-pass mode beyond 2^32 samples"""
+    exchange mode and the partitioned multi-pass mode beyond 2^32 samples"""
     if _free_gb() < 240:
         pytest.skip("needs 240 GB of free device memory")
     from xhistogram_amd import _native
@@ -88,6 +88,20 @@ def test_c5_full_size_4e9_samples_weighted_density(xh):
     plan = xh._get_plan([e, e], _native.CMP_F64, 0)
     assert "partitioned" in plan.describe(), plan.describe()
     assert tuple(counts.shape) == (1024, 1024) and counts.dtype == torch.float64
+    # which kernels: the exchange mode is offered and its probe finds ~94 % of these samples in its window, so it took
+    # the call above (the next call's description carries what the GPU reported); the classic passes on the same 96 GB agree
+    assert "exchange=if the probe" in plan.describe(), plan.describe()
+    torch.cuda.synchronize()
+    plan.set_param("exchange", -1)
+    try:
+        classic, _ = xh.histogram(x, y, bins=[e, e], weights=w)
+        desc = plan.describe()
+    finally:
+        plan.set_param("exchange", 0)
+    assert "exchange=no" in desc and int(desc.split("exchange_window_ppm_before=")[1].split()[0]) >= 880_000, desc
+    assert "exchange_aborts=0" in desc, desc
+    torch.testing.assert_close(counts, classic, rtol=2.0 ** -34, atol=0)  # (both round the weights to 36 mantissa bits, then add in float64)
+    del classic
     # total = weight of the samples inside the range of BOTH inputs (float64 sums: 1e-6 relative is the contract; observed ~1e-12)
     # both marginals = the 1-D weighted histograms of one input over the samples the OTHER one keeps (LDS kernel family: an
     # independent path); the weights of dropped samples are zeroed in a copy rather than masked out (no 32 GB gathers)
