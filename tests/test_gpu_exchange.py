@@ -203,7 +203,7 @@ def test_exchange_mode_keeps_its_kernels_from_meeting_on_two_streams(xh):
     import torch
 
     edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
-    n = 1 << 27
+    n = 1 << 28  # (the first call's kernel runs ~1.8 ms: the second call's look at its event comes well inside that)
     g = torch_gen(17)
     x = torch.empty((1, n), dtype=torch.float64, device="cuda").normal_(generator=g)
     y = torch.empty((1, n), dtype=torch.float64, device="cuda").normal_(generator=g)
