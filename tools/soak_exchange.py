@@ -4,7 +4,7 @@ by tools/soak.py).  Random shapes: 1-3 inputs, bins per input, np.linspace range
 constant, heavy NaN / infinity mixes, samples ON edges), weights of one sign (either), both signs now and then (the exact
 fallback), sizes around the 4096-sample tile and up to a few million.
 
-    python tools/soak_exchange.py [seconds] [seed]
+    python tools/soak_exchange.py [seconds] [seed] [one big case every N]
 """
 import os
 import sys
@@ -20,6 +20,7 @@ from xhistogram_amd import _native, core
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big_every = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # every how many cases one with 2*10^7 ... 7*10^7 samples (0: never)
 
 
 def one(seed):
@@ -34,6 +35,8 @@ def one(seed):
     if int(np.prod(nbs)) > (1 << 23) or int(np.prod(nbs)) < 30_000:
         return None
     n = int(rng.choice([int(rng.integers(4, 9000)), int(rng.integers(9000, 400_000)), int(rng.integers(400_000, 4_000_000))]))
+    if big_every and seed % big_every == 0:  # (now and then a call of many tiles per workgroup: the rings go round hundreds of times)
+        n = int(rng.integers(20_000_000, 70_000_000))
     edges, samples = [], []
     for nb in nbs:
         lo = float(rng.uniform(-10, 5))
