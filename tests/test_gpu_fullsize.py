@@ -91,6 +91,7 @@ def test_c5_full_size_4e9_samples_weighted_density(xh):
     # which kernels: the exchange mode is offered and its probe finds ~94 % of these samples in its window, so it took
     # the call above (the next call's description carries what the GPU reported); the classic passes on the same 96 GB agree
     assert "exchange=if the probe" in plan.describe(), plan.describe()
+    aborts_before = int(plan.describe().split("exchange_aborts=")[1].split()[0])  # (other tests of this process may have made the mode give up on purpose)
     torch.cuda.synchronize()
     plan.set_param("exchange", -1)
     try:
@@ -99,7 +100,7 @@ def test_c5_full_size_4e9_samples_weighted_density(xh):
     finally:
         plan.set_param("exchange", 0)
     assert "exchange=no" in desc and int(desc.split("exchange_window_ppm_before=")[1].split()[0]) >= 880_000, desc
-    assert "exchange_aborts=0" in desc, desc
+    assert int(desc.split("exchange_aborts=")[1].split()[0]) == aborts_before, desc  # the 96 GB call did not give up
     torch.testing.assert_close(counts, classic, rtol=2.0 ** -34, atol=0)  # (both round the weights to 36 mantissa bits, then add in float64)
     del classic
     # total = weight of the samples inside the range of BOTH inputs (float64 sums: 1e-6 relative is the contract; observed ~1e-12)

@@ -410,6 +410,17 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.counts = xa.win + 8 + 32;
       xa.note = p->mixed_hint;
       if (lds_xch > 48 * 1024) HIPR(hipFuncSetAttribute((const void*)k_xch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xch));
+      // every workgroup of the kernel must be resident (they wait for one another): one per compute unit is what its LDS and
+      // registers must allow; asked once per plan and LDS size (a kernel of the host's that holds compute units at run time is
+      // the deadline's business)
+      if (p->exchange_occ_lds != lds_xch) {
+        int per_cu_x = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_x, (const void*)k_xch, kExchBlock, lds_xch) != hipSuccess) { per_cu_x = 0; (void)hipGetLastError(); }
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->exchange_occ_lds = lds_xch;
+        p->exchange_occ_ok = per_cu_x >= 1;
+      }
+      if (!p->exchange_occ_ok) xch = false;
     }
   }
 

@@ -441,6 +441,8 @@ struct xhist_plan {
   int exchange_pref = 0;   // exchange mode of the partitioned path (xhist_exchange.hip.h): -1 never, 0 where eligible and the probe's window holds enough samples, 1 whenever the kernel can run (tests)
   bool exchange_disabled = false;  // an exchange kernel gave up (deadline, placement): this plan stays on the classic passes until "exchange" is set again
   uint32_t exchange_aborts_seen = 0;
+  size_t exchange_occ_lds = 0;  // the LDS size the occupancy question below was asked for, and its answer
+  bool exchange_occ_ok = false;
   int exchange_budget_ms = 0;  // deadline of a workgroup's waits in that mode: 0 = 500 ms; -1: every wait gives up at once (tests of the fallback)
   int route_pool_pct = 0;  // routing pass: chunk pool cut to this percentage of its worst-case size (tests of the pool-dry path; 0 = full)
   int slices_pref = 0;  // 0 auto, 1 prefer bin slices for histograms beyond LDS, -1 never
