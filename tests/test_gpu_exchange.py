@@ -65,7 +65,7 @@ def test_exchange_mode_specials_and_edges(xh):
     assert_hist_equal(got, want, True)
 
 
-@pytest.mark.parametrize("case", ["1d", "3d", "short_rows", "fits_window"])
+@pytest.mark.parametrize("case", ["1d", "3d", "3d_striped", "short_rows", "fits_window"])
 def test_exchange_mode_other_shapes(xh, case):
     """one input (rows are 256-bin pieces), three inputs (rows = the first two dimensions), rows of 40 bins (many rows per
     workgroup), and a histogram that fits the window (no probe, no side adds)"""
@@ -77,6 +77,9 @@ def test_exchange_mode_other_shapes(xh, case):
     elif case == "3d":
         edges = [np.linspace(-3, 3, 65), np.linspace(-3, 3, 49), np.linspace(0, 1, 401)]
         samples = [rng.standard_normal((1, n)), rng.standard_normal((1, n)), rng.uniform(-0.05, 1.05, (1, n))]
+    elif case == "3d_striped":  # rows = 32 x 32 bins of the first two inputs: the heavy rows repeat every 32 (the rotated owner map's case)
+        edges = [np.linspace(-4, 4, 33), np.linspace(-4, 4, 33), np.linspace(-4, 4, 1025)]
+        samples = [rng.standard_normal((1, n)), rng.standard_normal((1, n)), rng.standard_normal((1, n))]
     elif case == "short_rows":
         edges = [np.linspace(-3, 3, 20_001), np.linspace(0, 1, 41)]
         samples = [rng.standard_normal((1, n)), rng.uniform(0, 1, (1, n))]

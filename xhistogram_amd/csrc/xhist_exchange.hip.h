@@ -8,8 +8,8 @@
 //
 //   * 256 persistent workgroups of 1024 threads, ONE per compute unit, 32 per XCD (the workgroup reads HW_REG_XCC_ID and
 //     takes a place among its XCD's 32 with an atomic).  The 32 workgroups of an XCD keep a WINDOW of histogram rows between
-//     them: workgroup `me` owns rows r with (r - r0) mod 32 == me — consecutive rows go to different owners, so any smooth
-//     distribution loads them evenly — rows_per rows each, <= 15360 bins = 120 KB of float64 in LDS.  Every XCD holds the
+//     them: every 32 consecutive rows go to 32 different owners (rotated from block to block, exch_owner), so smooth
+//     distributions — and the striped ones of three inputs — load them evenly; rows_per rows each, <= 15360 bins = 120 KB of float64 in LDS.  Every XCD holds the
 //     whole window; the eight partial windows are added up by exchange_merge.  A "row" is the last dimension of the
 //     histogram (256 consecutive bins of a one-dimensional one).
 //   * Every workgroup is producer AND consumer.  Per tile of 4096 samples: digitize (bin_arith_fast + the exact redo, as
@@ -116,6 +116,12 @@ __device__ __forceinline__ uint32_t exch_xcc_id() {
 __device__ __forceinline__ uint64_t exch_ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t exch_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void exch_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The owner of window row r: one of every 32 consecutive rows each, rotated by 13 from one block of 32 rows to the next.  Plain
+// r mod 32 is as even for a smooth distribution, but rows = all inputs but the last, so a three-input histogram's heavy rows come
+// in runs that repeat with the second input's bin count — 32 x 32 x 1024 bins of N(0,1) samples: eight owners took every record
+// and the call 4.43 ms against 2.96 for the classic passes; rotated: see DESIGN 4.2b.  The row inside the owner's LDS copy stays r / 32.
+__device__ __forceinline__ uint32_t exch_owner(uint32_t r) { return (r + 13u * (r >> 5)) & 31u; }
 
 // pack48 for finite weights below the top binade: round to nearest-even on bit 16 with one 64-bit add.  `special` comes back
 // true for NaN / infinity / the top binade (where the carry could reach the infinity exponent): the caller redoes those with
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         bool special;
         rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
         special_any |= special;
-        dest[s4] = in_win ? (r & 31u) : (ins[s4] ? 32u : 33u);
+        dest[s4] = in_win ? exch_owner(r) : (ins[s4] ? 32u : 33u);
         if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side) + ((D == 1) ? gg[0] : row * L + col) * 8u), wq);
         s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
         s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
@@ -595,7 +601,7 @@ __global__ void __launch_bounds__(256) exchange_merge(const ExchArgs xa, double*
   const uint32_t r = row - __builtin_nontemporal_load(xa.win + 0);
   double s = xa.side[f];
   if (r < (uint32_t)kExchRings * (uint32_t)xa.rows_per) {
-    const uint32_t d = r & 31u, local = (r >> 5) * L + col;
+    const uint32_t d = exch_owner(r), local = (r >> 5) * L + col;
 #pragma unroll
     for (int xc = 0; xc < kExchXcds; ++xc) s += xa.part[((size_t)xc * kExchRings + d) * (size_t)xa.local_bins + local];
   }
