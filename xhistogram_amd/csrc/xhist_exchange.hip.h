@@ -90,7 +90,7 @@ struct ExchArgs {
   double* side;              // [n_bins], zeroed per call: samples outside the window
   uint32_t* win;             // device words: [0] first row of the window, [1] mode on, [2] coverage in ppm (exchange_pick writes them)
   ExchCold* cold;            // device copy of the rarely needed arguments (exchange_pick writes it)
-  uint32_t* counts;          // [n_units + 1] rows of the probe's samples per unit of 32 rows, zeroed per call
+  uint32_t* counts;          // [n_units] rows of the probe's samples per unit of 32 rows, [32] per owner; zeroed per call
   uint32_t* flags;           // the packed pass's sign word: 1 negative, 2 positive weights seen; 3 also stands for "redo exactly"
   uint32_t* note;            // pinned host words (may be NULL): [2] += 1 per abort, [3] coverage ppm of the last pick
   int64_t row_len;           // L: bins per row (last dimension; 256 for one dimension)
@@ -99,7 +99,9 @@ struct ExchArgs {
   int32_t local_bins;        // rows_per * L
   int32_t n_units;           // ceil(n_hist_rows / 32)
   int32_t force;             // 1: mode on whatever the coverage (tests, "exchange" = 1)
+  int32_t side_rot_mask;     // exch_side_index: (largest power of two <= L) - 1
   int32_t min_ppm;           // coverage that switches the mode on
+  int32_t max_uneven_ppm;    // ... unless the busiest owner would get more than this many ppm of an even share of the records
   long long budget_ticks;    // deadline of a workgroup's waits, in ticks of the 100 MHz clock
 };
 
@@ -122,6 +124,17 @@ __device__ __forceinline__ void exch_st(uint32_t* p, uint32_t v) { __hip_atomic_
 // in runs that repeat with the second input's bin count — 32 x 32 x 1024 bins of N(0,1) samples: eight owners took every record
 // and the call 4.43 ms against 2.96 for the classic passes; rotated: see DESIGN 4.2b.  The row inside the owner's LDS copy stays r / 32.
 __device__ __forceinline__ uint32_t exch_owner(uint32_t r) { return (r + 13u * (r >> 5)) & 31u; }
+
+// Where bin (row, col) lives in the SIDE copy of the output (what lies outside the window, added with memory-side atomics): every
+// row rotated by a row-dependent number of columns.  Those samples sit in the rows next to the window and — for a bell-shaped
+// second input — in the same run of columns of each: chunks of a few KB, a whole row (8-16 KB) apart, which the memory channels
+// interleave badly (512 x 2048 bins, 9 % outside: 2.79 ms against 2.39 for the classic passes; with the rotation: DESIGN 4.2b).
+// rot_mask = the largest power of two <= L, minus one, so one conditional subtraction wraps.
+__device__ __forceinline__ uint32_t exch_side_index(uint32_t row, uint32_t col, uint32_t L, uint32_t rot_mask) {
+  uint32_t c = col + ((row * 40503u >> 4) & rot_mask);
+  c -= c >= L ? L : 0u;
+  return row * L + c;
+}
 
 // pack48 for finite weights below the top binade: round to nearest-even on bit 16 with one 64-bit add.  `special` comes back
 // true for NaN / infinity / the top binade (where the carry could reach the infinity exponent): the caller redoes those with
@@ -210,9 +223,9 @@ __device__ __forceinline__ void exch_row_col(const uint32_t (&g)[D], const ExchA
 // ---- where the window should lie: rows of a sample of the input, per unit of 32 rows ------------------------------
 template <int D>
 __global__ void __launch_bounds__(256) exchange_probe(const ExchArgs xa) {
-  __shared__ uint32_t lc[4096];
+  __shared__ uint32_t lc[4096 + kExchRings];  // rows per unit of 32, then records per owner
   const int tid = threadIdx.x;
-  for (int i = tid; i < xa.n_units; i += 256) lc[i] = 0u;
+  for (int i = tid; i < xa.n_units + kExchRings; i += 256) lc[i] = 0u;
   __syncthreads();
   const int64_t n = xa.n;
   // workgroup b looks at 1024 consecutive samples a (1 / grid)-th of the way further into the input
@@ -231,10 +244,14 @@ __global__ void __launch_bounds__(256) exchange_probe(const ExchArgs xa) {
 #pragma unroll
     for (int d = 0; d < D; ++d) gg[d] = g[d][v];
     exch_row_col<D>(gg, xa, row, col);
-    if (ins[v]) atomicAdd(lc + min(row / kExchUnitRows, (uint32_t)xa.n_units - 1u), 1u);
+    if (ins[v]) {
+      atomicAdd(lc + min(row / kExchUnitRows, (uint32_t)xa.n_units - 1u), 1u);
+      // who would own it (a window starts on a multiple of 32 rows, which only rotates the owners: the LARGEST load is the same)
+      atomicAdd(lc + xa.n_units + exch_owner(row), 1u);
+    }
   }
   __syncthreads();
-  for (int i = tid; i < xa.n_units; i += 256)
+  for (int i = tid; i < xa.n_units + kExchRings; i += 256)
     if (lc[i]) atomicAdd(xa.counts + i, lc[i]);
 }
 
@@ -257,10 +274,20 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
   }
   if (wu >= nu) best_u = 0;  // the whole histogram fits the window
   const uint32_t ppm = total ? (uint32_t)(best * 1000000ull / total) : 1000000u;
+  // the busiest owner's share of the records against an even one (1.0 = even): every workgroup takes what 32 producers send it
+  // between its own tiles, so the busiest owner sets the pace — samples in a handful of rows (or striped rows that the rotation
+  // does not spread) would make one workgroup take everything (measured: 5-60 ms against 2.5-3.9 for the classic passes)
+  uint32_t busiest = 0;
+  for (int k = 0; k < kExchRings; ++k) busiest = max(busiest, xa.counts[nu + k]);
+  const uint32_t even_ppm = total ? (uint32_t)((uint64_t)busiest * kExchRings * 1000000ull / total) : 1000000u;
   xa.win[0] = (uint32_t)best_u * kExchUnitRows;
-  xa.win[1] = (xa.force || wu >= nu || ppm >= (uint32_t)xa.min_ppm) ? 1u : 0u;
+  xa.win[1] = (xa.force || (ppm >= (uint32_t)xa.min_ppm && even_ppm <= (uint32_t)xa.max_uneven_ppm)) ? 1u : 0u;
   xa.win[2] = ppm;
-  if (xa.note) xa.note[3] = ppm;
+  xa.win[3] = even_ppm;
+  if (xa.note) {
+    xa.note[3] = ppm;
+    xa.note[4] = even_ppm;
+  }
   for (int d = 0; d < 3; ++d) {
     xa.cold->eL[d] = xa.dim[d].eL;
     xa.cold->step[d] = xa.dim[d].step;
@@ -324,6 +351,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   const uint32_t L = (uint32_t)xa.row_len;
   const int64_t n = xa.n;
   double* side = xa.side;
+  const uint32_t rot_mask = (uint32_t)xa.side_rot_mask;
 
   const int64_t n_tiles = (n + TILE - 1) / TILE;
   const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
@@ -456,7 +484,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
         special_any |= special;
         dest[s4] = in_win ? exch_owner(r) : (ins[s4] ? 32u : 33u);
-        if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side) + ((D == 1) ? gg[0] : row * L + col) * 8u), wq);
+        if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side) + exch_side_index(row, col, L, rot_mask) * 8u), wq);
         s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
         s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
       }
@@ -599,7 +627,7 @@ __global__ void __launch_bounds__(256) exchange_merge(const ExchArgs xa, double*
   const uint32_t L = (uint32_t)xa.row_len;
   const uint32_t row = (uint32_t)(f / L), col = (uint32_t)(f - (int64_t)row * L);
   const uint32_t r = row - __builtin_nontemporal_load(xa.win + 0);
-  double s = xa.side[f];
+  double s = xa.side[exch_side_index(row, col, L, (uint32_t)xa.side_rot_mask)];
   if (r < (uint32_t)kExchRings * (uint32_t)xa.rows_per) {
     const uint32_t d = exch_owner(r), local = (r >> 5) * L + col;
 #pragma unroll

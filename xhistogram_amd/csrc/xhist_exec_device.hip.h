@@ -383,18 +383,20 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
     if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max && !other_stream_busy) {
       xch = true;
-      xch_probe = units > rows_per;  // (a histogram that fits the window needs no probe)
+      xch_probe = true;  // (always: a histogram that fits the window has nothing outside it, but its owners' loads must be even too)
       xa.row_len = L;
       xa.n_hist_rows = hist_rows;
       xa.rows_per = (int32_t)rows_per;
       xa.local_bins = (int32_t)(rows_per * L);
       xa.n_units = (int32_t)units;
       xa.force = p->exchange_pref > 0 ? 1 : 0;
+      { int64_t p2 = 1; while (p2 * 2 <= L) p2 *= 2; xa.side_rot_mask = (int32_t)(p2 - 1); }
       xa.min_ppm = 880000;
+      xa.max_uneven_ppm = 1250000;
       xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 500) * 100000;
-      const size_t words_bytes = ((size_t)(units + 1 + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts
+      const size_t words_bytes = ((size_t)(units + kExchRings + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts (units, then owners)
       // one block for everything that is zeroed per call (one launch): control words | window, cold arguments, probe counts | side copy | rings
-      const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)p->n_bins * 8;
+      const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)(hist_rows * L) * 8;  // (whole rows: exch_side_index rotates inside a row)
       const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8;
       static_assert(sizeof(ExchCtl) % 8 == 0, "the block's parts stay 8-byte aligned");
       x_zero_words = (int64_t)((ctl_bytes + words_bytes + side_bytes + rings_bytes) / 8);
@@ -549,12 +551,12 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     char desc[640];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u exchange_busiest_owner_ppm_before=%u",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64",
-             !xch ? "no" : xa.force ? "forced" : xch_probe ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window",
-             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u);  // (what the GPU has reported so far: the calls before this one)
+             !xch ? "no" : xa.force ? "forced" : xa.n_units > xa.rows_per ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window",
+             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u, p->mixed_hint ? p->mixed_hint[4] : 0u);  // (what the GPU has reported so far: the calls before this one)
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }
