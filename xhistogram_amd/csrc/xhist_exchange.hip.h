@@ -25,8 +25,9 @@
 //     3.97 against 3.29 ms in the stand-alone kernel — which is why the window is per XCD and not 8 x larger.
 //   * Samples outside the window go to a side copy of the output with memory-side atomics (2.4*10^10 per second: fine for
 //     ~10 % of the samples, hopeless for half of them), so WHERE the window lies decides whether the mode pays:
-//     exchange_probe histograms the rows of 2.6*10^5 samples spread over the input, exchange_pick takes the best window and
-//     switches the mode on when it holds >= 88 % of them — both on the GPU, every call, no host synchronisation; classic
+//     exchange_probe histograms the rows (and the owners) of 2.6*10^5 samples spread over the input, exchange_pick takes the
+//     best window and switches the mode on when it holds >= 88 % of them and no owner would get more than 1.25 x an even
+//     share of the records — both on the GPU, every call, no host synchronisation; classic
 //     kernels queued behind return at once when the mode is on, these return at once when it is off.
 //   * Weights of both signs: the kernel reports them in the flags word of the packed routing pass, its merge does not run, and
 //     the exact routing + adding-up passes queued behind redo the whole call from the (untouched) output — this kernel and
