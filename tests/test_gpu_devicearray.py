@@ -272,7 +272,8 @@ def test_library_first_then_torch_in_one_process():
     import os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    # (a fresh interpreter's first `import torch` pages in gigabytes: minutes on a box whose file cache was just flushed by 96 GB tests)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=900)
     assert "ORDER-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
 
 
