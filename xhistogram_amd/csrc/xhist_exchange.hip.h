@@ -9,8 +9,8 @@
 //   * 256 persistent workgroups of 1024 threads, ONE per compute unit, 32 per XCD (the workgroup reads HW_REG_XCC_ID and
 //     takes a place among its XCD's 32 with an atomic).  The 32 workgroups of an XCD keep a WINDOW of histogram rows between
 //     them: every 32 consecutive rows go to 32 different owners (rotated from block to block, exch_owner), so smooth
-//     distributions — and the striped ones of three inputs — load them evenly; rows_per rows each, <= 15360 bins = 120 KB of float64 in LDS.  Every XCD holds the
-//     whole window; the eight partial windows are added up by exchange_merge.  A "row" is the last dimension of the
+//     distributions — and the striped ones of three inputs — load them evenly; rows_per rows each, <= 15360 bins = 120 KB
+//     of float64 in LDS.  Every XCD holds the whole window; the eight partial windows are added up by exchange_merge.  A "row" is the last dimension of the
 //     histogram (256 consecutive bins of a one-dimensional one).
 //   * Every workgroup is producer AND consumer.  Per tile of 4096 samples: digitize (bin_arith_fast + the exact redo, as
 //     part_route does), rank the tile's records by owner with LDS counters, lay them out by owner in LDS, and write each
@@ -20,7 +20,7 @@
 //     finds (32 lanes per ring, 4 records each per tile) and adds it to its LDS rows; it publishes how far it has read
 //     (credits), which the producer reads once per tile.  A ring without room makes its producer take from its own rings
 //     until the owner has caught up (every workgroup is resident, so this always ends; a deadline turns a hang into the
-//     exact fallback below).  Plain stores and agent-scope (L1-bypassing) loads are enough INSIDE one XCD: both sides
+//     fallback below).  Plain stores and agent-scope (L1-bypassing) loads are enough INSIDE one XCD: both sides
 //     go through the same L2.  Across XCDs they are not (measured: stale for ever), and write-through stores cost
 //     3.97 against 3.29 ms in the stand-alone kernel — which is why the window is per XCD and not 8 x larger.
 //   * Samples outside the window go to a side copy of the output with memory-side atomics (2.4*10^10 per second: fine for
@@ -39,7 +39,7 @@
 // WRITE 5.07 GB = 3.76 of records + 1.3 of side atomics; with no stream beside them the reads do hit), so as many bytes cross
 // the far side of the L2 as in the classic pair — but the 33 MB of rings are rewritten every few microseconds and need
 // never reach HBM, the only bytes that must come from there are the samples', and there is no second kernel.  Measured
-// (tools/ubench/xchg.hip is the kernel as a stand-alone program, profiles/r05_x_*): C5 shard 3.26-3.34 ms
+// (tools/ubench/xchg.hip is the kernel as a stand-alone program, profiles/r05_x_*): C5 shard 3.26-3.44 ms
 // against 3.95-4.1; the producing half alone 2.5 ms.
 #pragma once
 
