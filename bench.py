@@ -30,6 +30,12 @@ Also reported on the same JSON line:
   distributions  (default N = 1 run) the headline's two legs again on uniform[-4,4) samples, on samples that all fall
                into ONE bin and on samples of which 90 % are out of range (the LDS-atomic contention legs)
   first_call_ms  plan creation + module load + first launch of the headline kernel, cold
+  host_inputs  (default N = 1 run) the reference's REAL call shape — numpy arrays in, numpy out (core.py:442 through
+               XHIST_MEM_HOST staging) — on pageable and on pinned host memory, next to the host-to-device copy rate of the
+               same bytes measured on this box, and the same samples as 16 host chunks summed (what the dask graph's tasks do)
+  ranks        who took part: backend, world size as the process group reports it, (rank, local rank, device, PCI bus id,
+               uuid) of every rank gathered over that backend, RCCL version
+  summary      LAST key of the line: roofline fraction of every config leg + all_verified, so that a truncated tail still says it
 """
 import argparse
 import json
@@ -107,6 +113,49 @@ def self_spawn(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: spawning %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
     return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_sha16():
+    """hash of the native sources the library was built from: profiles/traffic.json carries the same figure for the code state its
+    counters were taken on (tools/pmc_traffic.py), and `roofline.traffic` is refused when they differ (the GPU box has no .git)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "xhistogram_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".sh")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def rank_identity(torch, dist, dev, use_dist, selftest=False):
+    """the `"ranks"` block: gathered over the process group itself, so N entries with N distinct devices are the backend's own
+    proof that N ranks on N GPUs took part (VERDICT r5 "next" #4)"""
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "host": socket.gethostname(), "pid": os.getpid()}
+    if not selftest and dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        me.update(device=pr.name, arch=getattr(pr, "gcnArchName", None), pci_bus_id="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                  uuid=str(getattr(pr, "uuid", "")), hbm_bytes=int(pr.total_memory), compute_units=int(pr.multi_processor_count))
+    else:
+        me.update(device="cpu (selftest: no GPU, no kernel)")
+    block = {"backend": dist.get_backend() if use_dist else "none (single process, no process group)",
+             "world_size_seen": dist.get_world_size() if use_dist else 1}
+    if use_dist:
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, me)
+        block["devices"] = got
+    else:
+        block["devices"] = [me]
+    ids = [d.get("uuid") or d.get("pci_bus_id") or "%s/%s" % (d["host"], d["pid"]) for d in block["devices"]]
+    block["distinct_devices"] = len(set(ids))
+    try:
+        v = torch.cuda.nccl.version()
+        block["rccl_version"] = ".".join(str(i) for i in v) if isinstance(v, tuple) else str(v)
+    except Exception:  # noqa: BLE001
+        block["rccl_version"] = None
+    return block
 
 
 def cpu_model():
@@ -194,6 +243,73 @@ def torch_reference(torch, arrays, w, edges, n_rows, n_cols, weighted, chunk=1 <
                 out += torch.bincount(sel, minlength=n_rows * n_bins)
             del flat, ok, sel
     return out.reshape(n_rows, n_bins)
+
+
+def host_inputs_leg(torch, core, dev, arrays, w, edges, n_host=200_000_000, chunks=16):
+    """The reference's own call shape (core.py:442: numpy arrays in, numpy histogram out) through the XHIST_MEM_HOST boundary:
+    the first n_host samples (+ weights) of the headline workload copied to host memory, then core.histogram on them — once from
+    PAGEABLE numpy arrays (what every existing xhistogram caller has), once from PINNED ones (torch pin_memory, handed over as
+    numpy views) — each against the host-to-device copy rate of the same bytes from the same kind of memory, measured here with
+    a plain tensor copy.  Then the same samples as `chunks` host chunks, one histogram call per chunk, partials summed: what the
+    tasks of the reference's dask graph do (core.py:403-439; dask itself is not in this image).  Every result is compared with the
+    device-resident result of the same samples.  PCIe-inclusive: never the line's `value`."""
+    n = min(n_host, arrays[0].numel())
+    xs_dev = [a.reshape(-1)[:n] for a in arrays]
+    w_dev = None if w is None else w.reshape(-1)[:n]
+    nbytes = sum(a.element_size() for a in xs_dev) * n + (0 if w is None else w_dev.element_size() * n)
+    want, _ = core.histogram(*xs_dev, bins=edges, weights=w_dev)
+    torch.cuda.synchronize(dev)
+    want = want.cpu().numpy()
+    out = {"samples": n, "bytes_in": nbytes, "unit": "GB/s of input bytes (PCIe-inclusive wall time of the call, numpy in -> numpy out)"}
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        return min(ts), r
+
+    scratch = [torch.empty_like(a) for a in xs_dev] + ([] if w is None else [torch.empty_like(w_dev)])
+    for kind in ("pageable", "pinned"):
+        hosts = [a.cpu() for a in xs_dev] + ([] if w is None else [w_dev.cpu()])
+        if kind == "pinned":
+            hosts = [h.pin_memory() for h in hosts]
+        nps = [h.numpy() for h in hosts]
+
+        def copy_only():
+            for d, h in zip(scratch, hosts):
+                d.copy_(h, non_blocking=True)
+
+        def call():
+            return core.histogram(*nps[: len(xs_dev)], bins=edges, weights=None if w is None else nps[-1])[0]
+
+        t_copy, _ = best(copy_only)
+        t_call, got = best(call)
+        ok = bool(np.allclose(got, want, rtol=VERIFY_RTOL, atol=0)) if w is not None else bool(np.array_equal(got, want))
+        out[kind] = {"call_ms": round(t_call * 1e3, 3), "GBps": round(nbytes / t_call / 1e9, 2), "h2d_copy_ms": round(t_copy * 1e3, 3),
+                     "h2d_copy_GBps": round(nbytes / t_copy / 1e9, 2), "frac_of_copy_rate": round(t_copy / t_call, 3),
+                     "samples_per_s": n / t_call, "verified": ok}
+        if kind == "pageable":  # the dask-shaped leg: `chunks` host chunks, one call each (core.py:415-439), partials summed on the host
+            cuts = np.linspace(0, n, chunks + 1).astype(np.int64)
+
+            def chunked():
+                acc = None
+                for c0, c1 in zip(cuts[:-1], cuts[1:]):
+                    h = core.histogram(*[a[c0:c1] for a in nps[: len(xs_dev)]], bins=edges, weights=None if w is None else nps[-1][c0:c1])[0]
+                    acc = h if acc is None else acc + h
+                return acc
+
+            t_ch, got_ch = best(chunked, reps=2)
+            okc = bool(np.allclose(got_ch, want, rtol=VERIFY_RTOL, atol=0)) if w is not None else bool(np.array_equal(got_ch, want))
+            out["host_chunks"] = {"chunks": chunks, "call_ms": round(t_ch * 1e3, 3), "GBps": round(nbytes / t_ch / 1e9, 2),
+                                  "frac_of_copy_rate": round(t_copy / t_ch, 3), "verified": okc,
+                                  "what": "%d pageable host chunks, one core.histogram call per chunk on one thread, partial histograms summed on the host (the shape of the reference's dask graph)" % chunks}
+        del hosts, nps
+    out["verified"] = {"ok": bool(out["pageable"]["verified"] and out["pinned"]["verified"] and out["host_chunks"]["verified"]),
+                       "kind": "numpy results of the host calls against the device-resident result of the same samples"}
+    return out
 
 
 VERIFY_RTOL = 1e-6  # north_star: float64 weighted sums / density within 1e-6 relative; int64 counts bit-exact
@@ -543,6 +659,13 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest and not as_extra:
         k = min(args.cpu_sample // max(1, len(arrays)), arrays[0].numel())
         host_sample = ([a.reshape(-1)[:k].cpu().numpy() for a in arrays], w.reshape(-1)[:k].cpu().numpy() if weighted else None)
+    # the reference's real call shape (numpy in, numpy out) on a bounded prefix of the same samples: VERDICT r5 "next" #6
+    host_leg = None
+    if args.config == "c2" and world == 1 and rank == 0 and extra is not None and not args.selftest:
+        try:
+            host_leg = host_inputs_leg(torch, core, dev, arrays, w, edges)
+        except Exception as e:  # noqa: BLE001  (a failure here must not take the headline line with it)
+            host_leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     # SURVEY.md 8(d) / hard part #2: the headline again on three other sample distributions — uniform[-4,4) (every bin equally
     # likely: the low-contention bound), ALL samples in one bin (every lane of every wavefront on one counter: the contention
     # bound of core.py:81's sequential add turned into LDS atomics) and 90 % of the samples out of range (the drop path).
@@ -562,6 +685,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         other = "strong" if main_leg == "weak" else "weak"
         legs[other] = run_leg(cols_weak if other == "weak" else cols_strong, args.steps, args.warmup)
     m = legs[main_leg]
+    ranks_block = None if as_extra else rank_identity(torch, dist, dev, use_dist, selftest=args.selftest)  # (a collective: every rank)
 
     if rank == 0:
         def roofline(leg):
@@ -591,9 +715,14 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
             entry = json.load(open(tpath)).get("configs", {}).get(args.config + ("u" if args.unweighted else "") + ("_full" if args.full else ""))
         except Exception:
             entry = None
-        if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"]:
+        sha_now = csrc_sha16()
+        if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"] and entry.get("csrc_sha16") not in (None, sha_now):
+            roof["traffic_source"] = None
+            roof["traffic_refused"] = ("profiles/traffic.json was measured on csrc %s (code state %s), this library is built from csrc %s: "
+                                       "counters of another code state are not reported" % (entry.get("csrc_sha16"), entry.get("code_state", "?"), sha_now))
+        elif entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"] and entry.get("csrc_sha16") == sha_now:
             roof["traffic"] = entry["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/traffic.json: %s (code state %s)" % (entry.get("source", "?"), entry.get("code_state", "?"))
+            roof["traffic_source"] = "profiles/traffic.json: %s (code state %s, csrc %s = this build's sources)" % (entry.get("source", "?"), entry.get("code_state", "?"), sha_now)
             # the rocprofv3 --kernel-trace average of the same command (the first launches after the idle gap of data generation
             # left out) next to the HIP-event mean of THAT profiled process: the tracer slows these kernels by a few
             # percent, so profiles/ reproduces `frac` only through `profiled_slowdown`
@@ -638,6 +767,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 + (("; all-reduce(sum) of the partial histogram over RCCL each step, " + ("finished before the next step's kernel starts (it wants every compute unit)" if wl.get("wants_whole_gpu") else "overlapped with the next step's kernel")) if reduce_partials else ""),
             },
             "roofline": roof,
+            "ranks": ranks_block,
             "kernel_ms_per_rank": m["kernel_ms_per_rank"],
             "allreduce_ms_alone": m["allreduce_ms"],
             # everything a step costs beyond its histogram kernel(s): zeroing, launch, the exchange's share that does not
@@ -712,11 +842,43 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                     ex = summary.get("exact_records")
                     if isinstance(ex, dict) and ex.get("verified") is not None:
                         verified[cfg + " exact records"] = ex["verified"]
+        if host_leg is not None:
+            line["host_inputs"] = host_leg
+            if isinstance(host_leg.get("verified"), dict):
+                verified["c2 host inputs (numpy in, numpy out)"] = host_leg["verified"]
         if host_sample is not None:
             line["cpu_baseline"] = cpu_baseline(host_sample[0], host_sample[1], edges, one_chunk=args.config == "c1")
         if verified:
             line["verified"] = dict(all_ok=all(v["ok"] for v in verified.values()), rtol_float64=VERIFY_RTOL, legs=verified)
             failed[0] = not line["verified"]["all_ok"]
+        # LAST key: what a reader of a truncated tail needs — the roofline fraction (of 8 TB/s) of every leg and whether every
+        # verified leg matched (VERDICT r5 "weak" #8: the line is longer than the 8 KB the driver keeps)
+        summ = {args.config + ("u" if args.unweighted else ""): round(roof["frac"], 4)}
+        if unweighted_leg is not None:
+            summ["c2u"] = round(line["unweighted"]["roofline"]["frac"], 4)
+        if dist_legs:
+            summ["c2_uniform"] = round(line["distributions"]["uniform[-4,4)"]["weighted"]["frac"], 4)
+            summ["c2u_uniform"] = round(line["distributions"]["uniform[-4,4)"]["unweighted"]["frac"], 4)
+        cfgs = line.get("configs") or {}
+        for cfg in ("c3", "c4", "c5"):
+            c = cfgs.get(cfg)
+            if isinstance(c, dict) and "frac" in c:
+                summ[cfg] = round(c["frac"], 4)
+                if "cold_frac" in c:
+                    summ[cfg + "_cold"] = round(c["cold_frac"], 4)
+                for sub, key in (("exact_records", "c5_exact"), ("classic_passes", "c5_classic"), ("uniform_samples", "c5_uniform")):
+                    if isinstance(c.get(sub), dict) and "frac" in c[sub]:
+                        summ[key] = round(c[sub]["frac"], 4)
+            elif isinstance(c, dict):
+                summ[cfg] = c.get("error") or c.get("skipped")
+        if host_leg is not None and "pinned" in host_leg:
+            summ["host_pinned_GBps"] = host_leg["pinned"]["GBps"]
+            summ["host_pinned_frac_of_h2d_copy"] = host_leg["pinned"]["frac_of_copy_rate"]
+            summ["host_pageable_GBps"] = host_leg["pageable"]["GBps"]
+        summ["n_gpus"] = world
+        summ["distinct_devices"] = ranks_block["distinct_devices"] if ranks_block else None
+        summ["all_verified"] = line["verified"]["all_ok"] if "verified" in line else None
+        line["summary"] = summ
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

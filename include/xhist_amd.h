@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XHIST_ABI_VERSION 8
+#define XHIST_ABI_VERSION 9
 #define XHIST_MAX_DIMS 8 /* max number of sample arrays (histogram dimensionality) */
 
 typedef enum {
@@ -251,6 +251,14 @@ int xhist_plan_profile_read(xhist_plan* plan, float* ms, int cap, int* n_out);
  * cached (free, kept for reuse), [1] = bytes callers hold right now, [2] = bytes the cache may keep — twice what the largest
  * recent call held at once, at least 64 MiB, at most half of the device; $XHIST_AMD_POOL_KEEP_GB fixes it — [3] = that recent peak. */
 int xhist_scratch_stats(int device, uint64_t* stats, int n);
+
+/* TEST SUPPORT (ABI v9) — stands in for "somebody else's kernel holds compute units" (an RCCL kernel of a collective on another
+ * stream, another process on the GPU): launches `workgroups` workgroups of 64 threads with `lds_bytes` of LDS each on `stream`,
+ * which do nothing but wait until `microseconds` have passed.  With lds_bytes >= 64 KiB no 158 KB workgroup of the exchange mode
+ * (the persistent kernel behind BASELINE C5's path, /root/reference/xhistogram/core.py:73-83 beyond LDS) can share their compute
+ * units, which is what tests/test_gpu_exchange.py needs to show that such a call fails fast instead of waiting for a deadline.
+ * Asynchronous; replaces nothing of the reference. */
+int xhist_debug_hold_cus(int device, int workgroups, int lds_bytes, int64_t microseconds, void* stream);
 
 /* free cached plans and scratch on every device */
 int xhist_shutdown(void);

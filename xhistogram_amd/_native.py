@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # $XHIST_AMD_LIB points development builds (A/B kernel variants) at another shared object
 LIB_PATH = os.environ.get("XHIST_AMD_LIB") or os.path.join(_HERE, "libxhist_amd.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_DIMS = 8
 
 # status codes (xhist_status)
@@ -72,7 +72,7 @@ EXPORTS = (
     "xhist_minmax", "xhist_moments", "xhist_plan_set_param", "xhist_plan_describe", "xhist_plan_profile_read",
     "xhist_comm_unique_id", "xhist_comm_create", "xhist_comm_info", "xhist_comm_allreduce", "xhist_comm_allgather",
     "xhist_comm_wait", "xhist_comm_destroy", "xhist_buffer_alloc", "xhist_buffer_free", "xhist_buffer_copy", "xhist_buffer_add", "xhist_buffer_copy_nd",
-    "xhist_pointer_device", "xhist_scratch_stats", "xhist_shutdown",
+    "xhist_pointer_device", "xhist_scratch_stats", "xhist_debug_hold_cus", "xhist_shutdown",
 )
 
 
@@ -138,6 +138,7 @@ def load():
         lib.xhist_moments.argtypes = [C.c_int, C.POINTER(XhistArray), C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_int, C.c_void_p]
         lib.xhist_scratch_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
+        lib.xhist_debug_hold_cus.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]
         lib.xhist_plan_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.xhist_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.xhist_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
@@ -350,6 +351,11 @@ def scratch_stats(device=0):
     out = (C.c_uint64 * 4)()
     check(load().xhist_scratch_stats(int(device), out, 4))
     return {"cached": int(out[0]), "live": int(out[1]), "limit": int(out[2]), "recent_peak": int(out[3])}
+
+
+def debug_hold_cus(workgroups, lds_bytes, microseconds, stream=None, device=0):
+    """test support: `workgroups` idle workgroups with `lds_bytes` of LDS each occupy compute units for `microseconds` on `stream`"""
+    check(load().xhist_debug_hold_cus(int(device), int(workgroups), int(lds_bytes), int(microseconds), C.c_void_p(stream or 0)))
 
 
 def comm_unique_id():

@@ -54,11 +54,14 @@ constexpr int kExchTake = 4;                             // ring records a lane 
 constexpr int kExchMaxLocal = 15360;                     // bins a workgroup keeps: 120 KB of float64 next to the tile's 36 KB
 constexpr int kExchCtlBytes = 2048;
 constexpr uint32_t kExchUnitRows = 32;                   // the probe counts rows in units of 32; a window starts on a unit
+constexpr int kExchMinPpm = 880000;                      // window coverage from which the mode takes a call (exchange_pick; where 88 % comes from: DESIGN 4.2b)
+constexpr uint32_t kExchArrivedMask = 0xffffu, kExchArrivePoison = 0x10000u;  // ExchCtl::arrived: a count and one "somebody gave up waiting" bit
 
 struct ExchCtl {             // one per XCD
   uint32_t nreg;             // workgroups that took a place on this XCD
   uint32_t abort;            // [XCD 0 only] some workgroup gave up: everybody leaves
-  uint32_t pad[30];
+  uint32_t arrived;          // [XCD 0 only] workgroups that have started (low 16 bits) | kExchArrivePoison once one of them has stopped waiting for the rest
+  uint32_t pad[29];
   uint32_t head[kExchRings][kExchRings];  // [producer][owner]: records of that ring the owner has taken
   uint32_t fin[kExchRings][kExchRings];   // [producer][owner]: 1 + final record count of the ring (0 while the producer works)
 };
@@ -74,7 +77,7 @@ struct ExchDim {
 // 88 of them into vector-register lanes — 140 v_readlane per tile.  exchange_pick copies them here from the arguments.
 struct ExchCold {
   double eL[3], step[3];
-  long long budget_ticks;
+  long long budget_ticks, arrive_ticks;
   uint32_t* flags;
   uint32_t* note;
   double* part;
@@ -93,7 +96,7 @@ struct ExchArgs {
   ExchCold* cold;            // device copy of the rarely needed arguments (exchange_pick writes it)
   uint32_t* counts;          // [n_units] rows of the probe's samples per unit of 32 rows, [32] per owner; zeroed per call
   uint32_t* flags;           // the packed pass's sign word: 1 negative, 2 positive weights seen; 3 also stands for "redo exactly"
-  uint32_t* note;            // pinned host words (may be NULL): [2] += 1 per abort, [3] coverage ppm of the last pick
+  uint32_t* note;            // pinned host words (may be NULL): [2] += 1 per abort in flight, [3] coverage ppm of the last pick, [4] busiest owner, [5] += 1 per call whose workgroups were not all resident when it started
   int64_t row_len;           // L: bins per row (last dimension; 256 for one dimension)
   int64_t n_hist_rows;       // rows of the histogram
   int32_t rows_per;          // rows per owner: the window holds 32 * rows_per rows
@@ -103,7 +106,8 @@ struct ExchArgs {
   int32_t side_rot_mask;     // exch_side_index: (largest power of two <= L) - 1
   int32_t min_ppm;           // coverage that switches the mode on
   int32_t max_uneven_ppm;    // ... unless the busiest owner would get more than this many ppm of an even share of the records
-  long long budget_ticks;    // deadline of a workgroup's waits, in ticks of the 100 MHz clock
+  long long budget_ticks;    // deadline of a workgroup's waits once records travel, in ticks of the 100 MHz clock
+  long long arrive_ticks;    // how long a workgroup waits for the other 255 to start before it hands the call to the classic passes
 };
 
 __host__ __device__ constexpr size_t exchange_lds(int local_bins) {
@@ -294,6 +298,7 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
     xa.cold->step[d] = xa.dim[d].step;
   }
   xa.cold->budget_ticks = xa.budget_ticks;
+  xa.cold->arrive_ticks = xa.arrive_ticks;
   xa.cold->flags = xa.flags;
   xa.cold->note = xa.note;
   xa.cold->part = xa.part;
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
 template <int D>
 __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   constexpr int BLOCK = kExchBlock, TILE = kExchTile, NS = kExchRings, CAP = kExchCap, CAPL = kExchCapLog2, CL = kExchTake;
-  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));  // (a view like x[1:] is 8-byte aligned only; the loads stay 16-byte ones)
   if (__builtin_nontemporal_load(xa.win + 1) == 0u) return;  // the window does not hold enough of this call's samples
   const int tid = threadIdx.x;
   const size_t hist_bytes = ((size_t)xa.local_bins * 8 + 15) & ~(size_t)15;
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   uint32_t* lim = c + 320;     // [32] records of this tile's run for d that may be written so far
   uint32_t* sent = c + 352;    // [32] ... and that have been written
   uint32_t* wadj = c + 384;    // [32] wbase[d] - off[d]: ring position = wadj[d] + staged slot
-  uint32_t* misc = c + 416;    // [0] XCD [1] place [3] runs not written out yet [4] abort
+  uint32_t* misc = c + 416;    // [0] XCD [1] place [3] runs not written out yet [4] abort [5] not everybody arrived [6, 7] start time
   const volatile ExchCold* cold = xa.cold;
 
   for (int i = tid; i < xa.local_bins; i += BLOCK) hist[i] = 0.0;
@@ -331,16 +336,41 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     misc[1] = atomicAdd(&xa.ctl[xc].nreg, 1u);
     misc[3] = 0u;
     misc[4] = 0u;
-    *reinterpret_cast<long long*>(misc + 6) = wall_clock64();  // when this workgroup started: its waits give up budget_ticks later
+    // Everybody must be resident before anybody produces a record (a workgroup waits for 255 others): say "here", then wait
+    // for the rest — a few microseconds when the chip is free.  A compute unit held by somebody else's kernel (another stream,
+    // another process, a collective) keeps one of us out: the wait ends after arrive_ticks, NOTHING has been consumed or
+    // produced, and the classic passes queued behind take the call as if the probe had said no (note[5] counts those calls;
+    // the plan stays on the mode).  The long deadline (budget_ticks) is for stalls once records travel.
+    // (The word decides for everybody alike: the poison bit can only be set — by ONE compare-and-swap — while fewer than all have
+    // arrived, and once it is set everybody who looks, or arrives later, leaves; all arrived without it: nobody can set it any more.)
+    uint32_t v = atomicAdd(&xa.ctl[0].arrived, 1u) + 1u;
+    const long long t0 = wall_clock64();
+    const long long patience = cold->arrive_ticks;
+    bool first_to_give_up = false;
+    while ((v & kExchArrivedMask) < gridDim.x && !(v & kExchArrivePoison)) {
+      if (wall_clock64() - t0 > patience) {
+        const uint32_t seen = atomicCAS(&xa.ctl[0].arrived, v, v | kExchArrivePoison);
+        first_to_give_up = seen == v;
+        v = first_to_give_up ? (v | kExchArrivePoison) : seen;
+        continue;
+      }
+      __builtin_amdgcn_s_sleep(4);
+      v = exch_ld(&xa.ctl[0].arrived);
+    }
+    misc[5] = (v & kExchArrivePoison) ? (first_to_give_up ? 2u : 1u) : 0u;
+    *reinterpret_cast<long long*>(misc + 6) = wall_clock64();  // from here on: waits give up budget_ticks later
   }
   __syncthreads();
   const uint32_t xcd = misc[0], me = misc[1];
   uint32_t* g_abort = &xa.ctl[0].abort;
-  if (me >= (uint32_t)NS) {  // not 32 workgroups on this XCD: no ring ends here — everybody leaves, the exact passes redo the call
+  if (misc[5] || me >= (uint32_t)NS) {  // not everybody here, or not 32 workgroups on this XCD (no ring ends here): everybody leaves
     if (tid == 0) {
       exch_st(g_abort, 1u);
       exch_st(xa.win + 1, 0u);  // the mode is off for this call after all: the classic packed passes queued behind take it
-      if (cold->note) atomicAdd(cold->note + 2, 1u);
+      if (cold->note) {
+        if (misc[5] == 2u) atomicAdd(cold->note + 5, 1u);        // once per call: by the workgroup that stopped the wait
+        else if (misc[5] == 0u) atomicAdd(cold->note + 2, 1u);   // a placement other than 32 per XCD: an abort like those in flight
+      }
     }
     return;
   }

@@ -273,23 +273,38 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       else (void)hipGetLastError();
     }
   }
-  if (p->mixed_hint && p->mixed_hint[2] != p->exchange_aborts_seen) {
-    // an exchange kernel of an earlier call gave up (workgroups not all resident — another stream's kernel held compute units —
-    // or not 32 per XCD) and the classic passes took that call: the plan stays away from the mode (a second hang would cost its
-    // deadline again) until "exchange" is set again
+  if (p->mixed_hint) {
+    // An exchange kernel of an earlier call gave up IN FLIGHT (a wait that outlived its deadline, a placement other than 32
+    // workgroups per XCD) and the classic passes took that call: the plan stays away from the mode for its next 16 eligible
+    // calls, twice as many after every further abort (a second hang would cost its deadline again), and is admitted again after
+    // that; a clean call resets the count.  (Workgroups that were not all resident at the START cost arrive_ticks, not the
+    // deadline, and do not count: note[5].)  "exchange" set again forgets all of it.
     std::lock_guard<std::mutex> lk(p->mu);
-    p->exchange_aborts_seen = p->mixed_hint[2];
-    p->exchange_disabled = true;
+    if (p->mixed_hint[2] != p->exchange_aborts_seen) {
+      p->exchange_aborts_seen = p->mixed_hint[2];
+      p->exchange_skip = p->exchange_backoff;
+      p->exchange_backoff = std::min(p->exchange_backoff * 2, 4096);
+    } else if (p->exchange_skip > 0) {
+      p->exchange_skip -= 1;
+    } else if (p->exchange_ran_last) {
+      p->exchange_backoff = 16;
+    }
+    p->exchange_ran_last = false;
   }
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
-  bool other_stream_busy = false;  // an exchange kernel of ANOTHER stream may still hold the GPU (looked at before the scratch allocations below)
+  // an exchange kernel of ANOTHER stream may still hold the GPU: looked at before the scratch allocations below, and the lock is
+  // kept until this call's own exchange kernel has been launched and its event recorded (two host threads that both saw "idle"
+  // would otherwise both launch one)
+  bool other_stream_busy = false;
+  std::unique_lock<std::mutex> xfl_lock;
   if (pack && p->exchange_pref >= 0) {
     ExchInFlight& fl = exch_in_flight(p->device);
-    std::lock_guard<std::mutex> lk(fl.mu);
+    xfl_lock = std::unique_lock<std::mutex>(fl.mu);
     if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
     (void)hipGetLastError();
+    if (other_stream_busy) xfl_lock.unlock();
   }
   const int32_t table_words = scan == kScanArith ? 0 : tset.words;  // arithmetic edges: no tables
   const int tile = route_tile(block, spl);
@@ -372,7 +387,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   bool xch = false, xch_probe = false;
   kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
   size_t lds_xch = 0;
-  if (pack && rows == 1 && p->exchange_pref >= 0 && (!p->exchange_disabled || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
+  if (pack && rows == 1 && p->exchange_pref >= 0 && (p->exchange_skip == 0 || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
       p->n_bins <= ((int64_t)1 << 23) /* (the side copy is zeroed per call) */ && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
     const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
     const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
@@ -391,9 +406,10 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.n_units = (int32_t)units;
       xa.force = p->exchange_pref > 0 ? 1 : 0;
       { int64_t p2 = 1; while (p2 * 2 <= L) p2 *= 2; xa.side_rot_mask = (int32_t)(p2 - 1); }
-      xa.min_ppm = 880000;
+      xa.min_ppm = p->exchange_min_pct > 0 ? p->exchange_min_pct * 10000 : kExchMinPpm;
       xa.max_uneven_ppm = 1250000;
       xa.budget_ticks = p->exchange_budget_ms < 0 ? 0 : (long long)(p->exchange_budget_ms ? p->exchange_budget_ms : 500) * 100000;
+      xa.arrive_ticks = (long long)(p->exchange_arrive_us > 0 ? p->exchange_arrive_us : 200) * 100;  // 200 us: the launch of 256 workgroups on a free chip takes a few
       const size_t words_bytes = ((size_t)(units + kExchRings + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts (units, then owners)
       // one block for everything that is zeroed per call (one launch): control words | window, cold arguments, probe counts | side copy | rings
       const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)(hist_rows * L) * 8;  // (whole rows: exch_side_index rotates inside a row)
@@ -511,14 +527,18 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       XH_LAUNCH_PICKED(k_xch, dim3(kExchXcds * kExchRings), dim3(kExchBlock), lds_xch, stream, xa);
       HIPR(hipGetLastError());
       {
-        ExchInFlight& fl = exch_in_flight(p->device);
-        std::lock_guard<std::mutex> lk(fl.mu);
+        ExchInFlight& fl = exch_in_flight(p->device);  // (xfl_lock holds fl.mu since the look at the last kernel's event)
         if (!fl.ev && hipEventCreateWithFlags(&fl.ev, hipEventDisableTiming) != hipSuccess) { fl.ev = nullptr; (void)hipGetLastError(); }
         if (fl.ev && hipEventRecord(fl.ev, stream) == hipSuccess) { fl.stream = stream; fl.armed = true; }
         else { fl.armed = false; (void)hipGetLastError(); }
       }
+      {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->exchange_ran_last = true;
+      }
       ra.xgate = xa.win + 1;  // the classic packed kernels below return at once when the mode took the call
     }
+    if (xfl_lock.owns_lock()) xfl_lock.unlock();
     RouteArgs ra48 = ra;
     if (pack) {
       XH_LAUNCH_PICKED(k_route48, dim3(Gk), dim3(block), lds_route, stream, kp, ra);  // packed records, notes the signs
@@ -548,15 +568,15 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     }
   }
   {
-    char desc[640];
+    char desc[704];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u exchange_busiest_owner_ppm_before=%u",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u exchange_busiest_owner_ppm_before=%u exchange_arrival_misses=%u",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64",
-             !xch ? "no" : xa.force ? "forced" : xa.n_units > xa.rows_per ? "if the probe's window holds 88 % of the samples" : "whole histogram in the window",
-             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u, p->mixed_hint ? p->mixed_hint[4] : 0u);  // (what the GPU has reported so far: the calls before this one)
+             !xch ? "no" : xa.force ? "forced" : xa.n_units > xa.rows_per ? "if the probe's window holds enough of the samples" : "whole histogram in the window",
+             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u, p->mixed_hint ? p->mixed_hint[4] : 0u, p->mixed_hint ? p->mixed_hint[5] : 0u);  // (what the GPU has reported so far: the calls before this one)
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }

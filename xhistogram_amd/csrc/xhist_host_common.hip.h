@@ -370,6 +370,27 @@ extern "C" int xhist_scratch_stats(int device, uint64_t* stats, int n) {
   return XHIST_OK;
 }
 
+// test support: somebody else's kernel holding compute units (see include/xhist_amd.h)
+__global__ void __launch_bounds__(64) debug_hold_kernel(long long ticks) {
+  extern __shared__ unsigned char hold_smem[];
+  if (threadIdx.x == 0) hold_smem[0] = 1;  // (the LDS is this kernel's whole point: keep the allocation alive)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int xhist_debug_hold_cus(int device, int workgroups, int lds_bytes, int64_t microseconds, void* stream) {
+  if (workgroups < 1 || workgroups > 4096 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 10 * 1000 * 1000)
+    return fail(XHIST_ERR_INVALID, "hold_cus: workgroups in [1, 4096], lds_bytes in [0, 163840], microseconds in [0, 10^7]");
+  if (device < 0 || device >= n_devices()) return fail(XHIST_ERR_NO_DEVICE, "device %d not available", device);
+  DeviceGuard g;
+  if (int rc = g.set(device)) return rc;
+  if (lds_bytes > 48 * 1024 && hipFuncSetAttribute((const void*)debug_hold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return fail(XHIST_ERR_HIP, "hold_cus: %s", hipGetErrorString(hipGetLastError()));
+  hipLaunchKernelGGL(debug_hold_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+  if (hipError_t e = hipGetLastError()) return fail(XHIST_ERR_HIP, "hold_cus launch: %s", hipGetErrorString(e));
+  return XHIST_OK;
+}
+
 static void trim_pools() {  // xhist_shutdown: every cached block of every device goes back to the driver
   std::lock_guard<std::mutex> lk(g_sc_mu);
   int prev = -1;
@@ -439,7 +460,11 @@ struct xhist_plan {
   int min_parts = 0;       // partitioned mode: bins are cut finer until a pass has this many partitions (0 auto = 16; 1 = never)
   int route_grid = 0, acc_grid = 0;  // workgroups of the routing / adding-up pass of execute_partitioned_fused (0 auto) — scaling runs
   int exchange_pref = 0;   // exchange mode of the partitioned path (xhist_exchange.hip.h): -1 never, 0 where eligible and the probe's window holds enough samples, 1 whenever the kernel can run (tests)
-  bool exchange_disabled = false;  // an exchange kernel gave up (deadline, placement): this plan stays on the classic passes until "exchange" is set again
+  int exchange_skip = 0;       // an exchange kernel gave up in flight (deadline, placement): eligible calls that still stay on the classic passes
+  int exchange_backoff = 16;   // ... and how many that will be after the next abort (doubles per abort, back to 16 after a clean call)
+  bool exchange_ran_last = false;  // the last eligible call launched the exchange kernel
+  int exchange_min_pct = 0;    // window coverage (per cent of the probe's samples) from which the mode takes a call; 0 = kExchMinPpm
+  int exchange_arrive_us = 0;  // how long its workgroups wait for one another to start; 0 = 200 us
   uint32_t exchange_aborts_seen = 0;
   size_t exchange_occ_lds = 0;  // the LDS size the occupancy question below was asked for, and its answer
   bool exchange_occ_ok = false;

@@ -638,7 +638,14 @@ extern "C" int xhist_plan_set_param(xhist_plan* p, const char* key, int64_t valu
     if (p->mixed_hint) *p->mixed_hint = 0u;  // (setting the knob also forgets what earlier calls saw)
   } else if (!strcmp(key, "exchange")) {
     p->exchange_pref = value < 0 ? -1 : (value > 0 ? 1 : 0);
-    p->exchange_disabled = false;
+    p->exchange_skip = 0;
+    p->exchange_backoff = 16;
+  } else if (!strcmp(key, "exchange_min_pct")) {
+    if (value < 0 || value > 100) return fail(XHIST_ERR_INVALID, "exchange_min_pct must be in [0, 100]");
+    p->exchange_min_pct = (int)value;
+  } else if (!strcmp(key, "exchange_arrive_us")) {
+    if (value < 0 || value > 1000000) return fail(XHIST_ERR_INVALID, "exchange_arrive_us must be in [0, 1000000]");
+    p->exchange_arrive_us = (int)value;
   } else if (!strcmp(key, "exchange_budget_ms")) {
     if (value < -1 || value > 600000) return fail(XHIST_ERR_INVALID, "exchange_budget_ms must be in [-1, 600000]");
     p->exchange_budget_ms = (int)value;
