@@ -716,6 +716,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         except Exception:
             entry = None
         sha_now = csrc_sha16()
+        roof["csrc_sha16"] = sha_now  # the native sources this library was built from (tools/pmc_traffic.py files it with the counters)
         if entry and entry.get("kernel") == m["desc"] and entry.get("samples_per_launch") == m["n"] and entry.get("csrc_sha16") not in (None, sha_now):
             roof["traffic_source"] = None
             roof["traffic_refused"] = ("profiles/traffic.json was measured on csrc %s (code state %s), this library is built from csrc %s: "

@@ -583,9 +583,42 @@ def test_a_failed_exchange_drops_the_communicators_and_the_next_one_rebuilds_the
         assert group._comms is None and len(closed) == 2  # dropped and closed, not cached
         assert group.exchange(lambda comm, rank, device, item: (comm.wait(0), comm.generation)[1], [None, None]) == [1, 1]
         assert len(made) == 4 and group._comms is not None  # the second exchange ran on new communicators
-        # errors that are not the communicator's (a bad argument inside the caller's function) keep the communicators
+        # ANY exception out of an exchange drops them (a MemoryError / NotImplementedError on one rank between two
+        # collectives leaves its peers inside the next one) — the following exchange builds the third generation
         with pytest.raises(ValueError):
-            group.exchange(lambda comm, rank, device, item: (_ for _ in ()).throw(ValueError("caller bug")), [None, None])
-        assert group._comms is not None
+            group.exchange(lambda comm, rank, device, item: (_ for _ in ()).throw(ValueError("raised on one rank mid-exchange")), [None, None])
+        assert group._comms is None and len(closed) == 4
+        assert group.exchange(lambda comm, rank, device, item: comm.generation, [None, None]) == [2, 2]
+    finally:
+        group.close()
+
+
+def test_a_rendezvous_that_fails_on_one_rank_closes_what_the_other_ranks_built(monkeypatch):
+    """`comms()` ran outside the try and kept nothing of a half-built set — the communicators the other ranks'
+    threads had created were neither cached nor closed.  Now they are closed on their own GPU threads, and the next exchange
+    starts from scratch."""
+    made, closed = [], []
+    fail_first = [True]
+
+    class CommDouble:
+        def __init__(self, device, rank, world, uid):
+            if rank == 1 and fail_first[0]:
+                fail_first[0] = False
+                raise RuntimeError("XHIST_ERR_COMM: rank 1 of 2: the rendezvous deadline passed")
+            self.rank = rank
+            made.append(self)
+
+        def close(self):
+            closed.append(self)
+
+    monkeypatch.setattr(_native, "Comm", CommDouble)
+    monkeypatch.setattr(_native, "comm_unique_id", lambda: b"\0" * 128)
+    group = multigpu.DeviceGroup([5, 6])
+    try:
+        with pytest.raises(RuntimeError, match="rendezvous"):
+            group.exchange(lambda comm, rank, device, item: rank, [None, None])
+        assert group._comms is None and len(made) == 1 and closed == made  # rank 0's communicator was closed, not leaked
+        assert group.exchange(lambda comm, rank, device, item: rank, [None, None]) == [0, 1]
+        assert len(made) == 3 and group._comms is not None
     finally:
         group.close()

@@ -176,3 +176,51 @@ def test_wrapper_over_hip_path():
     num, den = xhx.histogram(da, bins=[bins], dim=["lat", "lon"], weights=(tw, w))  # one pass, two weights
     np.testing.assert_allclose(num.values, onp.histogram(t, bins=bins, axis=(1, 2), weights=t * w.values)[0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(den.values, onp.histogram(t, bins=bins, axis=(1, 2), weights=np.broadcast_to(w.values, t.shape))[0], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_dims_and_coords_over_hip_path():  # test_xarray.py:139-173 (issue #5), the HIP path under the wrapper — not the patched-in oracle
+    rng = np.random.default_rng(5)
+    time_axis, depth_axis, x_axis, y_axis = np.arange(4), np.arange(10), np.arange(30), np.arange(30)
+    dat1 = rng.integers(0, 100, size=(4, 10, 30, 30))
+    dat2 = rng.integers(0, 50, size=(4, 10, 30, 30))
+    coords = {"time": time_axis, "depth": depth_axis, "X": x_axis, "Y": y_axis}
+    one = xr.DataArray(dat1, dims=["time", "depth", "X", "Y"], coords=coords, name="one")
+    two = xr.DataArray(dat2, dims=["time", "depth", "X", "Y"], coords=coords, name="two")
+    bins1, bins2 = np.linspace(0, 100, 50), np.linspace(0, 50, 25)
+    h = xhx.histogram(one, two, dim=["X", "Y"], bins=[bins1, bins2])
+    assert tuple(h.dims) == ("time", "depth", "one_bin", "two_bin") and h.name == "histogram_one_two"
+    np.testing.assert_array_equal(h["time"].values, time_axis)
+    np.testing.assert_array_equal(h["depth"].values, depth_axis)
+    np.testing.assert_allclose(h["one_bin"].values, 0.5 * (bins1[:-1] + bins1[1:]))
+    np.testing.assert_allclose(h["two_bin"].values, 0.5 * (bins2[:-1] + bins2[1:]))
+    want = onp.histogram(dat1, dat2, bins=[bins1, bins2], axis=(2, 3))[0]
+    np.testing.assert_array_equal(h.values, want)
+    assert h.values.sum() == dat1.size - np.count_nonzero(dat1 > 100)  # (integers on [0, 100): every pair is counted once)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("number_of_inputs", [1, 2])
+@pytest.mark.parametrize("keep_coords", [True, False])
+@pytest.mark.parametrize("include_weights", [True, False])
+def test_carry_coords_over_hip_path(keep_coords, number_of_inputs, include_weights):  # test_xarray.py:176-211
+    rng = np.random.default_rng(6)
+    time_axis, x_axis, y_axis = np.arange(40), np.arange(10), np.arange(10)
+    data = rng.integers(0, 100, size=(40, 10, 10))
+    lon = x_axis[:, None] ** 2 + y_axis[None, :] ** 2  # "faking coordinates": a two-dimensional non-index coordinate
+    da = xr.DataArray(data, dims=["time", "X", "Y"], name="one",
+                      coords={"time": time_axis, "X": x_axis, "Y": y_axis, "lon": (("X", "Y"), lon)})
+    assert "lon" in da.coords
+    weights = xr.DataArray(np.full(data.shape, 0.5), dims=["time", "X", "Y"], name="w") if include_weights else None
+    bins = np.linspace(0, 100, 10)
+    h = xhx.histogram(*[da] * number_of_inputs, bins=[bins] * number_of_inputs, dim=["time"], weights=weights, keep_coords=keep_coords)
+    assert ("lon" in h.coords) == keep_coords
+    if keep_coords:
+        np.testing.assert_array_equal(h["lon"].values, lon)
+    assert tuple(h.dims) == ("X", "Y") + ("one_bin",) * number_of_inputs
+    want = onp.histogram(*[data] * number_of_inputs, bins=[bins] * number_of_inputs, axis=0,
+                         weights=None if weights is None else weights.values)[0]
+    if include_weights:
+        np.testing.assert_allclose(h.values, want, rtol=1e-6)
+    else:
+        np.testing.assert_array_equal(h.values, want)

@@ -104,6 +104,9 @@ def main():
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --config %s%s`, summaries %s_pmc_*.txt"
                       % (name[:2] + (" --unweighted" if name[2:3] == "u" else ""), " --full" if name.endswith("_full") else "", (os.path.basename(copy_to) + "_" if copy_to else "") + name),
             "code_state": state,
+            # hash of xhistogram_amd/csrc as the measured process saw it (bench.py::csrc_sha16): bench.py reports these counters
+            # only from a library built from the same sources
+            "csrc_sha16": bench.get("roofline", {}).get("csrc_sha16"),
         }
         print("%-8s traffic %.4g B / algorithmic %.4g B = %.4f" % (name, total, alg, total / alg))
     json.dump(doc, open(tpath, "w"), indent=1)

@@ -1151,10 +1151,8 @@ static int execute_device(xhist_plan* p, const xhist_array* samples, const xhist
       const size_t b0 = hist_bytes;
       padded_bins = D == 1;
       place(0, true);
-      if (hist != kHistLds) {
-        padded_bins = false;
-        place(0, true);
-      }
+      // (no second try without the padding: the kernel's PADDED layout is a compile-time property of <kScanArith32, D == 1, LDS>,
+      //  so a one-input histogram that fits LDS only unpadded — n_bins within 64 of the cap — keeps the digitize it had)
       if (hist == kHistLds) {
         scan = kScanArith32;
         use_f32 = false;

@@ -29,10 +29,11 @@ static int fail(int code, const char* fmt, ...) {
 static void log_picked_kernel(const void* fn) {
   static const char* const path = getenv("XHIST_AMD_KERNEL_LOG");
   if (!path || !*path) return;
+  static const bool every_pick = [] { const char* e = getenv("XHIST_AMD_KERNEL_LOG_ALL"); return e && *e == '1'; }();  // (tests/test_gpu_census.py's discovery mode: which CASE picks what)
   static std::mutex mu;
   static std::set<const void*> seen;
   std::lock_guard<std::mutex> lk(mu);
-  if (!seen.insert(fn).second) return;
+  if (!seen.insert(fn).second && !every_pick) return;
   // the host stub's own symbol (`__device_stub__<kernel>`), from the dynamic symbol table: no call into the HIP runtime
   // (hipKernelNameRefByPtr hung a process that had loaded this library before torch's bundled runtime)
   Dl_info info;

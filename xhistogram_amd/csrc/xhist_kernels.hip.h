@@ -1068,7 +1068,9 @@ __global__ void __launch_bounds__(1024) hist_fast(const Params p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           if constexpr (PADDED) {
-            lds_t* slot = reinterpret_cast<lds_t*>(slot_base0 + (cnt[0][u][v] << slot_shift));  // [-pad, nb + pad) -> the pad bins catch the dropped
+            // [-pad, nb + pad) -> the pad bins catch the dropped.  The offset is SIGNED: dropped samples carry bins -1 - k, and an
+            // unsigned 32-bit offset would only land in the front pad bins as long as the address arithmetic itself is 32-bit
+            lds_t* slot = reinterpret_cast<lds_t*>(slot_base0 + (ptrdiff_t)(int32_t)(cnt[0][u][v] << slot_shift));
             if (kWeighted) {
               unsafeAtomicAdd(reinterpret_cast<double*>(slot), (double)wv[u][v]);
               if constexpr (W2) unsafeAtomicAdd(reinterpret_cast<double*>(slot) + hist_elems, (double)wv2[u][v]);

@@ -239,24 +239,48 @@ class DeviceGroup:
         return results
 
     def comms(self):
-        """one ``_native.Comm`` per GPU (rank k = k-th device); collective creation from the GPU threads"""
+        """one ``_native.Comm`` per GPU (rank k = k-th device); collective creation from the GPU threads.  When the rendezvous
+        fails on any rank (its deadline, a GPU that is gone), the communicators the OTHER ranks' threads did get are closed
+        here — nothing half-built is kept or leaked."""
         with self.collective:
             if self._comms is None:
                 world = len(self.devices)
                 uid = _native.comm_unique_id()
-                self._comms = self.run(lambda rank, device, _: _native.Comm(device, rank, world, uid), [None] * world)
+                made = [None] * world
+
+                def create(rank, device, _):
+                    made[rank] = _native.Comm(device, rank, world, uid)
+                    return made[rank]
+
+                try:
+                    self._comms = self.run(create, [None] * world)
+                except BaseException:
+                    for k, c in enumerate(made):
+                        if c is not None:
+                            try:
+                                self._pools[k].submit(c.close).result()
+                            except Exception:  # noqa: BLE001 - best effort
+                                pass
+                    raise
             return self._comms
 
     def exchange(self, fn, items):
-        """``fn(comm, rank, device, item)`` on every GPU's thread, under the collective lock.  A RuntimeError out of it — a
-        deadline (`xhist_comm_wait` / the rendezvous), an asynchronous RCCL error — leaves ABORTED communicators behind
-        that fail every later call at once; a long-lived worker must not be poisoned by one slow peer, so
-        they are dropped here and the next exchange builds new ones."""
+        """``fn(comm, rank, device, item)`` on every GPU's thread, under the collective lock.  ANY exception out of it — a
+        deadline (`xhist_comm_wait` / the rendezvous), an asynchronous RCCL error, but also a MemoryError or NotImplementedError
+        raised between two collectives on one rank while its peers are already inside the next one — may leave communicators
+        aborted or mid-collective; a long-lived worker must not be poisoned by one failed call, so they are
+        dropped here and the next exchange builds new ones.
+
+        What runs beside a collective: every collective of this module ends in ``comm.wait`` on the thread that issued it, so a
+        GPU's thread never queues its next histogram kernel under its own all-reduce (the rule ``bench.py`` applies to C5 with a
+        stream-side wait).  Another thread's kernel on the same GPU can still meet an RCCL kernel; for the exchange mode's
+        persistent kernel that costs its arrival handshake (200 us, then the classic passes take that call — DESIGN 4.2b),
+        never its deadline."""
         with self.collective:
-            comms = self.comms()
             try:
+                comms = self.comms()
                 return self.run(lambda rank, device, item: fn(comms[rank], rank, device, item), items)
-            except RuntimeError:
+            except BaseException:
                 self._drop_comms()
                 raise
 
