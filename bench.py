@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the in-process torch cross-check of every leg's output (profiler passes)")
     ap.add_argument("--distributions", action="store_true",
                     help="c2: also time (and verify) the headline's legs on uniform, one-bin and 90 %%-out-of-range samples; on by default in the default N = 1 run")
+    ap.add_argument("--dist", default="normal", choices=["normal", "uniform"],
+                    help="c1 / c2 sample distribution for profiler passes and A/B runs: N(0,1) (the headline) or uniform[-4,4) (every bin equally likely)")
     ap.add_argument("--cpu-sample", type=int, default=400_000_000)
     args = ap.parse_args()
     # a C4 shard step is one 0.3 ms kernel: the first tens of launches after an idle GPU run 5-8 % slower (0.309 ms over steps
@@ -345,13 +347,14 @@ def build_workload(cfg, args, torch, dev, rank):
     if cfg in ("c1", "c2"):
         n = 1_000_000 if cfg == "c1" else args.samples
         weighted = cfg == "c2" and not args.unweighted
-        x = torch.empty(n, dtype=f64, device=dev).normal_(generator=g)
+        x = torch.empty(n, dtype=f64, device=dev)
+        x.uniform_(-4.0, 4.0, generator=g) if getattr(args, "dist", "normal") == "uniform" else x.normal_(generator=g)
         w = torch.empty(n, dtype=f64, device=dev).uniform_(generator=g) if weighted else None
         return dict(
             arrays=[x], weights=w, edges=[np.linspace(-4.0, 4.0, args.bins + 1)], rows=1, cols=n, reduce="allreduce",
             metric="samples/s binned (f64), 1D %d-bin %s elems per GPU" % (args.bins, "10^6" if cfg == "c1" else "10^9") + (" + f64 weights" if weighted else ""),
             workload="%s: 1-D histogram, %d f64 samples per GPU, %d uniform bins on [-4,4], %s" % (cfg.upper(), n, args.bins, "f64 weights" if weighted else "unweighted"),
-            dtype="f64", data="synthetic (N(0,1) samples%s, generated on device)" % (", U[0,1) weights" if weighted else ""))
+            dtype="f64", data="synthetic (%s samples%s, generated on device)" % ("uniform[-4,4)" if getattr(args, "dist", "normal") == "uniform" else "N(0,1)", ", U[0,1) weights" if weighted else ""))
     if cfg == "c3":
         n = args.samples
         x = torch.empty(n, dtype=f64, device=dev).normal_(generator=g)
@@ -487,7 +490,7 @@ def main():
             torch.cuda.empty_cache()
         return out
 
-    default_run = (args.config == "c2" and world == 1 and not args.unweighted and not args.profiler_pass and not args.tune and
+    default_run = (args.config == "c2" and world == 1 and not args.unweighted and not args.profiler_pass and not args.tune and args.dist == "normal" and
                    args.samples == 1_000_000_000 and not args.no_other_configs)
     measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, rank, use_dist, result_fd, sync=sync, stream=stream,
                        extra=other_configs if default_run else None)

@@ -680,7 +680,9 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
   }
 
   int vec = 1;
-  kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes, &vec);
+  // (counts: uint16 counter columns, two per word — the only unweighted form: a column segment longer than 65535 samples
+  //  would need 2^24 rows to be asked for, see the packed16 rule below; sums: float64 columns)
+  kernel_fn_lanes fn = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, weighted ? kHistLanes : kHistLanes16, &vec);
   if (!fn) return XHIST_ERR_UNSUPPORTED;
 
   const bool fused_ok = D == 1 && !weighted && n_cols < 65536 && samples[0].col_stride == 1 && samples[0].row_stride != 0;
@@ -871,14 +873,12 @@ static int execute_lanes(xhist_plan* p, const xhist_array* samples, const xhist_
     const int bpc16 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds16));
     int64_t segs16 = std::max<int64_t>(1, ((int64_t)p->cus * bpc16 * 2 + row_blocks - 1) / row_blocks);
     segs16 = std::min<int64_t>(std::min<int64_t>(segs16, std::max<int64_t>(1, n_cols / 64)), 65535);
-    if ((n_cols + segs16 - 1) / segs16 <= 65535) {
-      kernel_fn_lanes f16 = (kernel_fn_lanes)fast_kernel(sdt, wdt, D, scan, kHistLanes16, &vec);
-      if (f16) {
-        fn = f16;
-        packed16 = true;
-        lds_use = lds16;
-      }
-    }
+    // (a segment of more than 65535 columns: only with so many row blocks that there is one segment each — beyond 10^10
+    //  samples; the row-streaming kernels take that call.  The uint32-column kernels this used to fall back to were never
+    //  selected by anything — census of round 6 — and are gone)
+    if ((n_cols + segs16 - 1) / segs16 > 65535) return release(XHIST_ERR_UNSUPPORTED);
+    packed16 = true;
+    lds_use = lds16;
   }
   if (lane_pitch) lane_pitch = packed16 ? lane_rows / 2 + 1 : lane_rows + 1;
   kp.lane_pitch = lane_pitch;

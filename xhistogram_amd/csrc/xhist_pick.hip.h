@@ -37,6 +37,29 @@ constexpr int unroll_for(int D, int vec, int scan) {
   return u > 4 ? 4 : u;
 }
 
+// ---- what the pickers of xhist_exec_device.hip.h can never ask for (round 6, VERDICT r5 "next" #2) -------------------------------
+// The dispatch tables below were a plain cross product; the census of round 6 (tests/test_gpu_census.py walks the product with the
+// smallest inputs that select each entry) found entries that NO input selects, for reasons of arithmetic, not of test coverage.
+// They are not instantiated any more; the rules, with the reason each one holds:
+//
+//  * ONE input (D == 1), histogram beyond the replicated LDS copies.  The plan's bucket grid has at most 8192 buckets per input, so
+//    n bins put n / 8192 edges into a bucket: "one edge per bucket" (SCAN 1) means <= 8192 bins — 64 KB of float64 sums, 32 KB of
+//    counts — which always fit LDS next to their edges: no packed-uint16, bin-slice, partition-count or routing kernel is ever
+//    asked for with D == 1 and SCAN 1.  Two per bucket (<= 16384 bins) still fit as uint32 counts next to float32 thresholds, so
+//    float32 counts never reach the packed / sliced forms with SCAN 2 either; float64 counts do (14 000 bins: the edges take 112 KB).
+//    Packed bucket entries (SCAN 6-8) need at least n / 3 sixteen-byte entries: beyond ~10 000 bins they do not fit LDS, below
+//    that the histogram fits as uint32 — never with the packed-uint16 home for one input.
+//  * The routing pass keeps its tables in LDS next to the sort buffers (>= 70 KB): for ONE input beyond LDS only float32
+//    thresholds of a weighted histogram fit (<= 16384 bins, SCAN 0 or 2, the short tile); everything else with one input digitizes
+//    arithmetically or takes the three-pass route.
+//  * Bin slices keep float64 sums in LDS and counts as packed uint16 pairs: there is no sliced uint32 home.
+//  * The generic family keeps its histogram in LDS only when its tables are there too (place() in execute_device).
+constexpr bool one_input_home_exists(bool is_f64, bool unweighted, int scan, int hist_home /* 0 global, 1 lds, 2 packed */) {
+  (void)unweighted;
+  if (hist_home == 2) return scan == 0 || scan == 3 || scan == 4 || scan == kScanArith || (scan == 2 && is_f64);
+  return true;
+}
+
 // partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
 constexpr int kHistPartCount = 4, kHistLanes = 6, kHistLanes16 = 7;
 constexpr int kPartMaxParts = 256;
@@ -47,15 +70,21 @@ static kernel_fn fast_pick(int hist) {
   constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, SCAN);
-  if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, SCAN>;
-  if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+  if (hist == kHistPartCount) {
+    if constexpr (D == 1 && SCAN == 1) return nullptr;  // (one input, one edge per bucket: fits LDS, see above)
+    else return (kernel_fn)part_count<ST, D, VEC, SCAN>;
+  }
+  if (hist == kHistLanes) {  // (float64 sum columns; counts take the uint16 columns below and nothing else)
+    if constexpr (!unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+    else return nullptr;
+  }
   if (hist == kHistLanes16) {
     if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
     else return nullptr;
   }
   if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
   if (hist == kHistPacked) {
-    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+    if constexpr (unweighted && (D > 1 || one_input_home_exists(std::is_same<ST, double>::value, true, SCAN, 2))) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
     else return nullptr;
   }
   return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistGlobal, SCAN>;
@@ -88,7 +117,10 @@ static kernel_fn fast_pick_pack(int hist) {
     constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
     constexpr int U = unroll_for(D, VEC, SCAN);
     if constexpr (SCAN == kScanPackG) {  // the row-per-lane family takes the general variant only (one set of kernels)
-      if (hist == kHistLanes) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+      if (hist == kHistLanes) {
+        if constexpr (!unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), false>;
+        else return nullptr;
+      }
       if (hist == kHistLanes16) {
         if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
         else return nullptr;
@@ -96,7 +128,7 @@ static kernel_fn fast_pick_pack(int hist) {
     }
     if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
     if (hist == kHistPacked) {
-      if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
+      if constexpr (unweighted && D > 1) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;  // (one input: see above)
     }
   }
   return nullptr;
@@ -160,9 +192,14 @@ static kernel_fn sliced_pick(int hist) {
   constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, SCAN);
-  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN, false, true>;
+  // (execute_device asks for float64 sums in LDS when weighted, for packed uint16 counts when not: nothing else; one input:
+  //  never with one edge per bucket, and float32 counts not with two — see the rules at the top)
+  if (hist == kHistLds) {
+    if constexpr (!unweighted && !(D == 1 && SCAN == 1)) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN, false, true>;
+  }
   if (hist == kHistPacked) {
-    if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN, false, true>;
+    if constexpr (unweighted && (D > 1 || SCAN == kScanArith || (SCAN == 2 && std::is_same<ST, double>::value)))
+      return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN, false, true>;
   }
   return nullptr;
 }
@@ -198,7 +235,11 @@ static kernel_fn mixed_pick_ds(int D, int scan) {
     if (scan == 0) return XH_MIXED(DD, 0);                   \
     if (scan == 1) return XH_MIXED(DD, 1);                   \
     if (scan == 2) return XH_MIXED(DD, 2);                   \
-    if (scan == kScanArith) return XH_MIXED(DD, kScanArith); \
+    if (scan == kScanArith) {                                \
+      /* (one unweighted input is never a "mixture": no such call reaches the arithmetic form — census of round 6) */ \
+      if constexpr (DD > 1 || !std::is_same<WT, NoWeight>::value) return XH_MIXED(DD, kScanArith); \
+      else return nullptr;                                   \
+    }                                                        \
     return nullptr;
   switch (D) {
     XH_MIXED_CASE(1)
@@ -228,9 +269,17 @@ constexpr bool route_variant_exists() {
   constexpr int wb = std::is_same<WT, NoWeight>::value ? 0 : std::is_same<WT, float>::value ? 4 : 8;
   return SPL == 4 || route_long_tile_ok((int)sizeof(ST), wb, D, SCAN == kScanArith);
 }
+// one input with a table digitize: only float32 thresholds of a weighted histogram fit LDS next to the sort buffers — binary search
+// or two edges per bucket, the short tile, one row per pass (the rules at the top of this file; census of round 6)
+template <typename ST, typename WT, int D, int SCAN, bool MULTI, int SPL>
+constexpr bool route_one_input_ok() {
+  return D > 1 || SCAN == kScanArith ||
+         (std::is_same<ST, float>::value && !std::is_same<WT, NoWeight>::value && (SCAN == 0 || SCAN == 2) && SPL == 4 && !MULTI);
+}
 template <typename ST, typename WT, int D, int SCAN, bool MULTI, int BLOCK, int SPL>
 static kernel_fn_route route_variant() {
-  if constexpr (route_variant_exists<ST, WT, D, SCAN, SPL>()) return (kernel_fn_route)part_route<ST, WT, D, SCAN, MULTI, BLOCK, SPL>;
+  if constexpr (route_variant_exists<ST, WT, D, SCAN, SPL>() && route_one_input_ok<ST, WT, D, SCAN, MULTI, SPL>())
+    return (kernel_fn_route)part_route<ST, WT, D, SCAN, MULTI, BLOCK, SPL>;
   else return nullptr;
 }
 

@@ -53,9 +53,9 @@ template <typename ST>
 static kernel_fn small_pick(int wdt, int D, int scan, int hist) {
   if (D != 1 || (scan != 0 && scan != 1)) return nullptr;
   if (hist == kHistLanes || hist == kHistLanes16) {  // row-per-lane kernels: leading-axis reductions of such arrays
-    if (wdt == -1) {
+    if (wdt == -1) {  // (counts: uint16 counter columns only, as for float samples)
       if (hist == kHistLanes16) return scan ? (kernel_fn)hist_lanes<ST, NoWeight, 1, 1, 8, true> : (kernel_fn)hist_lanes<ST, NoWeight, 1, 0, 8, true>;
-      return scan ? (kernel_fn)hist_lanes<ST, NoWeight, 1, 1, 8, false> : (kernel_fn)hist_lanes<ST, NoWeight, 1, 0, 8, false>;
+      return nullptr;
     }
     if (wdt == XHIST_F64 && hist == kHistLanes) return scan ? (kernel_fn)hist_lanes<ST, double, 1, 1, 8, false> : (kernel_fn)hist_lanes<ST, double, 1, 0, 8, false>;
     return nullptr;
@@ -182,6 +182,15 @@ static kernel_fn generic_kernel_t(int cmp, bool weighted, bool lds) {
   return lds ? (kernel_fn)hist_generic<3, false, true, TLDS> : (kernel_fn)hist_generic<3, false, false, TLDS>;
 }
 
+// tables outside LDS: the histogram is never in LDS then (place() in execute_device puts it there only next to its tables), so
+// those three-times-two kernels are not instantiated (census of round 6)
+static kernel_fn generic_kernel_no_lds(int cmp, bool weighted) {
+  if (cmp == XHIST_CMP_F64) return weighted ? (kernel_fn)hist_generic<0, true, false, false> : (kernel_fn)hist_generic<0, false, false, false>;
+  if (cmp == XHIST_CMP_I64) return weighted ? (kernel_fn)hist_generic<1, true, false, false> : (kernel_fn)hist_generic<1, false, false, false>;
+  return weighted ? (kernel_fn)hist_generic<3, true, false, false> : (kernel_fn)hist_generic<3, false, false, false>;
+}
+
 static kernel_fn generic_kernel(int cmp, bool weighted, bool lds, bool tables_in_lds) {
-  return tables_in_lds ? generic_kernel_t<true>(cmp, weighted, lds) : generic_kernel_t<false>(cmp, weighted, lds);
+  if (tables_in_lds) return generic_kernel_t<true>(cmp, weighted, lds);
+  return lds ? nullptr : generic_kernel_no_lds(cmp, weighted);
 }
