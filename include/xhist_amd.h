@@ -222,9 +222,14 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       workgroup per compute unit keeps rows of a window of the histogram in LDS and records travel through rings inside each
  *       XCD; auto = float64 samples + float64 weights on numpy.linspace-style edges, one row of >= 2^25 samples, a chip of
  *       8 x 32 compute units, and a window that a probe on the GPU finds to hold 88 % of the call's samples; setting the key
- *       also re-admits a plan that an aborted exchange had taken off the mode), "exchange_budget_ms" (0 = 500: how long a
- *       workgroup of that mode waits for its peers before the mode is switched off for the call and the classic passes queued
- *       behind take it; -1: not at all — tests),
+ *       also re-admits a plan at once that an exchange aborted IN FLIGHT had taken off the mode — otherwise such a plan stays
+ *       on the classic passes for its next 16 eligible calls, twice as many after every further abort, and is admitted again),
+ *       "exchange_arrive_us" (0 = 200: how long the mode's 256 workgroups wait for one another to START — a compute unit held
+ *       by another stream's or process's kernel keeps one out; after that nothing has been produced and the classic passes queued
+ *       behind take the call; such calls are counted in the description, "exchange_arrival_misses", and do not take the plan off
+ *       the mode), "exchange_budget_ms" (0 = 500: how long a workgroup waits for its peers ONCE RECORDS TRAVEL before the mode is
+ *       switched off for the call and the classic passes take it; -1: not at all — tests), "exchange_min_pct" (0 = 88: the window
+ *       coverage, per cent of the probe's samples, from which the mode takes a call),
  *       "lanes" (0 auto / 1 prefer / -1 never: one-row-per-lane kernels for many short rows),
  *       "arith" (0 auto / 1 prefer / -1 never: table-free digitize for numpy.linspace-style edges),
  *       "arith32" (0 auto / 1 prefer / -1 never: float32 samples on such edges digitized in float32 arithmetic),

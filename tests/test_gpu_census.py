@@ -396,6 +396,11 @@ def test_dispatch_surface_odds_and_ends(xh):
             e = edges_of(kind, 96 if x is not xb else 12, lo=lo, hi=hi, seed=2)
             for params in ({}, {"arith": 1}, {"arith": -1}):
                 _run_general(xh, [x], [e], None, params, False)
+            # the same from HOST memory (numpy in, numpy out: the dtype reaches the library as it is — torch has no uint16 /
+            # uint32 arithmetic to hand it over resident), plus uint32
+            for xin in ((x, x.astype(np.uint32)) if x is x16 else (x,)):
+                got = xh._bincount_2d_vectorized(xin, bins=[e], weights=None)
+                assert_hist_equal(got, onp.bincount_rows([xin], [e], None), False)
     nb = 1_600  # 1600 x 1600 float64 sums = 157 partitions of 2^14 bins
     edges = [np.linspace(-4, 4, nb + 1), edges_of("k1", nb, seed=5)]
     xs = samples_for(edges, 1, 40_013, F32, 3)
@@ -414,6 +419,46 @@ def test_dispatch_surface_odds_and_ends(xh):
     finally:
         plan.set_param("partition", 0)
     assert_hist_equal(got.cpu().numpy(), onp.bincount_rows([x.astype(F64) for x in xs], edges, w.astype(F64)), True)
+    # counts with more than 128 partitions (2100 x 2100 bins = 135 partitions of 2^15): three passes, records in groups of four
+    nb = 2_100
+    edges = [np.linspace(-4, 4, nb + 1), edges_of("k1", nb, seed=6)]
+    xs = samples_for(edges, 1, 40_013, F64, 4)
+    _run_general(xh, xs, edges, None, {"partition": 1}, False)
+    # ONE column taken out of a wider array (a [rows, 1] view with a column stride): no vector kernel of the homogeneous family
+    # takes a strided column, the MIXED one does (n_cols == 1) — unweighted, on a binary search, one and two edges per bucket
+    base = torch.as_tensor(rng.uniform(-4.4, 4.4, (6_007, 3))).cuda()
+    col = base[:, 1:2]
+    assert col.stride() == (3, 1) and col.shape == (6_007, 1)
+    for kind in ("k1", "k2", "crowd", "lin"):
+        e = edges_of(kind, 96, seed=9)
+        got = xh._bincount_2d_vectorized(col, bins=[e], weights=None)
+        torch.cuda.synchronize()
+        assert_hist_equal(got.cpu().numpy(), onp.bincount_rows([col.cpu().numpy()], [e], None), False)
+
+
+def test_dispatch_surface_one_long_float64_row(xh):
+    """one float64 row of >= 2^29 samples without weights takes tiles twice as long (the headline's 8 B/sample variant; one or two
+    edges per bucket).  Too long for the oracle in a test: the whole row must equal the sum of its two halves — which are short
+    enough for the ordinary kernels the rest of this module holds to the oracle — and the total the in-range count torch finds."""
+    import torch
+
+    n = (1 << 29) + 4_099
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    x = torch.empty((1, n), dtype=torch.float64, device="cuda").normal_(generator=g)
+    x[0, ::1_000_003] = float("nan")
+    for kind in ("k1", "k2"):
+        e = edges_of(kind, 100, seed=3)
+        x[0, 5::2_000_003] = float(e[17])  # on an edge
+        x[0, 7::3_000_017] = float(e[-1])  # the right edge counts
+        whole = xh._bincount_2d_vectorized(x, bins=[e], weights=None)
+        h = n // 2
+        a = xh._bincount_2d_vectorized(x[:, :h], bins=[e], weights=None)
+        b = xh._bincount_2d_vectorized(x[:, h:], bins=[e], weights=None)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, a + b)
+        inside = int(((x >= float(e[0])) & (x <= float(e[-1]))).sum().item())
+        assert int(whole.sum().item()) == inside
 
 
 @pytest.mark.parametrize("D", [1, 2, 3])
