@@ -683,7 +683,11 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
         for name, fill in fills:
             fill()
             sync()
-            dist_legs[name] = (run_leg(cols_weak, 5, 3), run_leg(cols_weak, 5, 3, weighted=False, outs=outs_u))
+            # (10 untimed launches, like the headline's legs: each of these starts after an in-place refill and the torch kernels
+            #  of the last leg's verification — with 3, the 8 B/sample leg on uniform samples was timed inside the clock excursion
+            #  of a just-woken GPU, DESIGN 4.3, and read 3-6 % low through rounds 4-5; a dedicated run reads it level with N(0,1):
+            #  profiles/r06_b_c2u_uniform_dedicated.txt)
+            dist_legs[name] = (run_leg(cols_weak, 10, 10), run_leg(cols_weak, 10, 10, weighted=False, outs=outs_u))
     if world > 1:  # the other leg rides along (N = 1: the two legs are the same run)
         other = "strong" if main_leg == "weak" else "weak"
         legs[other] = run_leg(cols_weak if other == "weak" else cols_strong, args.steps, args.warmup)
@@ -815,7 +819,7 @@ def measure_and_report(args, torch, dist, _native, core, wl, plan, dev, world, r
                 return {"kernel_ms_mean": r["kernel_ms_mean"], "frac": r["frac"], "value": leg["value"], "kernel": leg["desc"],
                         "verified": None if leg["verified"] is None else leg["verified"]["ok"]}
 
-            line["distributions"] = {"steps": 5, "warmup": 3,
+            line["distributions"] = {"steps": 10, "warmup": 10,
                                      "N(0,1) (the headline)": {"weighted": {"kernel_ms_mean": roof["kernel_ms_mean"], "frac": roof["frac"]},
                                                               "unweighted": {"kernel_ms_mean": line["unweighted"]["kernel_ms_mean"],
                                                                              "frac": line["unweighted"]["roofline"]["frac"]}}}

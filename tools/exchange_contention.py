@@ -59,6 +59,12 @@ print(json.dumps({"leg": "exchange mode, free GPU", "ms": [round(t, 3) for t in 
 for k in (1, 8, 64):
     def hold(k=k):
         _native.debug_hold_cus(k, 96 * 1024, 50_000, stream=side.cuda_stream)  # 50 ms, far longer than the call
+    # (the classic passes under the same contention: their grids are one workgroup per compute unit too, so with any of them
+    #  held the last workgroups run in a second round — what a held compute unit costs ANY full-chip kernel)
+    plan.set_param("exchange", -1)
+    ts, _, _ = call(before=hold)
+    print(json.dumps({"leg": "classic passes, %d compute unit(s) held for 50 ms on another stream" % k, "ms": [round(t, 3) for t in ts]}), flush=True)
+    plan.set_param("exchange", 0)
     m0 = note(plan.describe(), "exchange_arrival_misses")
     ts, out, d = call(before=hold)
     print(json.dumps({"leg": "exchange mode, %d compute unit(s) held for 50 ms on another stream" % k, "ms": [round(t, 3) for t in ts],
