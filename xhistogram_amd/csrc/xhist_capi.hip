@@ -635,10 +635,8 @@ extern "C" int xhist_minmax(int device, const xhist_array* a, int64_t n_rows, in
   // contiguous float data (the usual `bins=int` on a whole array): the vectorised kernel
   const bool flat = (view.dtype == XHIST_F64 || view.dtype == XHIST_F32) && view.inner_rows == 0 && (n_cols == 1 || view.col_stride == 1) &&
                     (n_rows == 1 || view.row_stride == n_cols) && ((uintptr_t)view.data % (size_t)dtype_size(view.dtype)) == 0;
-  if (flat && view.dtype == XHIST_F64)
-    hipLaunchKernelGGL(minmax_flat<double>, dim3(grid), dim3(256), 0, s, (const double*)view.data, n_rows * n_cols, d_part);
-  else if (flat)
-    hipLaunchKernelGGL(minmax_flat<float>, dim3(grid), dim3(256), 0, s, (const float*)view.data, n_rows * n_cols, d_part);
+  if (flat)  // (`bins=int` on a whole float array is a first call's shape too: these two live in the hot code object)
+    (void)xhist_hot_minmax_flat(view.dtype == XHIST_F64, view.data, n_rows * n_cols, d_part, grid, s);
   else
     hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, view.data, view.dtype, view.row_stride, view.col_stride, view.inner_rows,
                        view.outer_stride, n_rows, n_cols, d_part);

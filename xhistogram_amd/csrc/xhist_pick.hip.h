@@ -60,6 +60,24 @@ constexpr bool one_input_home_exists(bool is_f64, bool unweighted, int scan, int
   return true;
 }
 
+// ---- the "hot" translation unit (round 6) ------------------------------------------------------------------------------------
+// HIP loads a translation unit's code object when the first kernel of it is launched: 7-8 ms for each of the 3 MB objects of
+// xhist_capi / xhist_pick_f64 / xhist_pick_f32 (tools/first_call_split.py: the first plan paid 8.2 ms for build_tables' module,
+// the first execute 7 ms for the histogram kernel's).  The kernels a FIRST call most likely needs — output zeroing, the table
+// builders, and the vector kernels for one or two float inputs with a histogram in LDS on uniform-style edges (one edge per bucket,
+// or the arithmetic digitize: `bins=int`, np.linspace), i.e. BASELINE C1 / C2 / C4 and most dask-chunk-sized calls — live in a small
+// translation unit of their own (xhist_hot.hip, ~40 kernels): its code object loads in a fraction of a millisecond and nothing
+// else is loaded until a call needs it.  The big units do not instantiate them (one kernel, one code object).
+constexpr bool is_hot_kernel(int D, int scan, int hist) {
+  return (D == 1 || D == 2) && hist == kHistLds && (scan == 1 || scan == kScanArith || scan == kScanArith32);
+}
+kernel_fn xhist_pick_hot(int sdt, int wdt, int D, int scan, int hist);  // nullptr: not a hot kernel (xhist_hot.hip)
+kernel_fn xhist_pick_hot_long(int sdt, int scan);                       // the long-tile variants of one unweighted float input
+int xhist_hot_zero_words(unsigned long long* p, int64_t n, int grid, hipStream_t stream);  // launches; returns hipGetLastError()
+int xhist_hot_build_tables(int dom, bool lut16, const DimTable& t, uint64_t* blob, int32_t* scratch);
+int xhist_hot_build_pack_tables(const DimTable& t, uint64_t* blob, int32_t* scratch, const float* thr);
+int xhist_hot_minmax_flat(bool f64, const void* x, int64_t n, double* partial, int grid, hipStream_t stream);
+
 // partitioned mode: pseudo "hist" codes selecting the two part_pass kernels, and their geometry
 constexpr int kHistPartCount = 4, kHistLanes = 6, kHistLanes16 = 7;
 constexpr int kPartMaxParts = 256;
@@ -82,7 +100,10 @@ static kernel_fn fast_pick(int hist) {
     if constexpr (unweighted) return (kernel_fn)hist_lanes<ST, WT, D, SCAN, (D == 1 ? 8 : 4), true>;
     else return nullptr;
   }
-  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
+  if (hist == kHistLds) {
+    if constexpr (is_hot_kernel(D, SCAN, kHistLds) && (std::is_same<ST, double>::value || std::is_same<ST, float>::value)) return nullptr;  // (xhist_hot.hip has it)
+    else return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, SCAN>;
+  }
   if (hist == kHistPacked) {
     if constexpr (unweighted && (D > 1 || one_input_home_exists(std::is_same<ST, double>::value, true, SCAN, 2))) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, SCAN>;
     else return nullptr;
@@ -98,7 +119,10 @@ static kernel_fn fast_pick_arith(int hist) {
   constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
   constexpr int U = unroll_for(D, VEC, kScanArith);
   if (hist == kHistPartCount) return (kernel_fn)part_count<ST, D, VEC, kScanArith>;
-  if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith>;
+  if (hist == kHistLds) {
+    if constexpr (is_hot_kernel(D, kScanArith, kHistLds)) return nullptr;  // (xhist_hot.hip has it)
+    else return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith>;
+  }
   if (hist == kHistPacked) {
     if constexpr (unweighted) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistPacked, kScanArith>;
     else return nullptr;
@@ -142,7 +166,10 @@ static kernel_fn fast_pick_arith32(int hist) {
     constexpr int wsz = unweighted ? 0 : (int)sizeof(typename std::conditional<unweighted, float, WT>::type);
     constexpr int VEC = 16 / (((int)sizeof(ST) > wsz) ? (int)sizeof(ST) : wsz);
     constexpr int U = unroll_for(D, VEC, kScanArith32);
-    if (hist == kHistLds) return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith32>;
+    if (hist == kHistLds) {
+      if constexpr (is_hot_kernel(D, kScanArith32, kHistLds)) return nullptr;  // (xhist_hot.hip has it)
+      else return (kernel_fn)hist_fast<ST, WT, D, VEC, U, kHistLds, kScanArith32>;
+    }
   }
   return nullptr;
 }

@@ -13,8 +13,7 @@ kernel_fn xhist_pick_sliced_f32(int wdt, int D, int scan, int hist) {
 // one float32 input, unweighted, LDS histogram: 32 samples per lane and tile instead of 16 (128 bytes per lane in flight) for
 // long rows — BASELINE C4's shape (xhist_exec_device.hip.h)
 kernel_fn xhist_pick_f32_long(int scan) {
-  if (scan == 1) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, 1>;
+  if (scan == 1 || scan == kScanArith32) return xhist_pick_hot_long(XHIST_F32, scan);  // (BASELINE C4's kernels: in the hot unit)
   if (scan == 2) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, 2>;
-  if (scan == kScanArith32) return (kernel_fn)hist_fast<float, NoWeight, 1, 4, 8, kHistLds, kScanArith32>;
   return nullptr;
 }

@@ -13,7 +13,7 @@ kernel_fn xhist_pick_sliced_f64(int wdt, int D, int scan, int hist) {
 // one float64 input, unweighted, LDS histogram: 16 samples per lane and tile instead of 8 — 128 bytes per lane in flight, what
 // the weighted kernel has with its two streams (xhist_exec_device.hip.h picks it for one long row)
 kernel_fn xhist_pick_f64_long(int scan) {
-  if (scan == 1) return (kernel_fn)hist_fast<double, NoWeight, 1, 2, 8, kHistLds, 1>;
+  if (scan == 1) return xhist_pick_hot_long(XHIST_F64, 1);  // (the headline's 8 B/sample variant: in the hot unit)
   if (scan == 2) return (kernel_fn)hist_fast<double, NoWeight, 1, 2, 8, kHistLds, 2>;
   return nullptr;
 }

@@ -103,12 +103,7 @@ static int build_domain(xhist_plan* p, int dom_all, bool lut16, int n_inputs, co
   for (int d = 0; d < n_inputs; ++d) {
     if (dims[d].lut_k == 0) continue;
     const int dom = dim_dom ? dim_dom[d] : dom_all;
-    if (dom == 0 && !lut16) hipLaunchKernelGGL((build_tables<0, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else if (dom == 0) hipLaunchKernelGGL((build_tables<0, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else if (dom == 1) hipLaunchKernelGGL((build_tables<1, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else if (!lut16) hipLaunchKernelGGL((build_tables<2, false>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    else hipLaunchKernelGGL((build_tables<2, true>), dim3(1), dim3(256), 0, 0, dims[d], d_blob, d_scratch);
-    HIPP(hipGetLastError());
+    HIPP((hipError_t)xhist_hot_build_tables(dom, lut16, dims[d], d_blob, d_scratch));  // (the builders live in the small hot code object: xhist_hot.hip)
     HIPP(hipDeviceSynchronize());
   }
   HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));
@@ -308,8 +303,7 @@ static int build_pack_domain(xhist_plan* p, bool f32dom, int n_inputs, const int
       d_thr = reinterpret_cast<float*>(d_scratch + max_e);
       HIPP(hipMemcpy(d_thr, thr_all[(size_t)d].data(), thr_all[(size_t)d].size() * 4, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(build_pack_tables, dim3(1), dim3(256), 0, 0, ts->dim[d], d_blob, d_scratch, (const float*)d_thr);
-    HIPP(hipGetLastError());
+    HIPP((hipError_t)xhist_hot_build_pack_tables(ts->dim[d], d_blob, d_scratch, (const float*)d_thr));
     HIPP(hipDeviceSynchronize());
   }
   HIPP(hipMemcpy(blob.data(), d_blob, blob.size() * 8, hipMemcpyDeviceToHost));

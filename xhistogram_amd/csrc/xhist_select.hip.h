@@ -95,8 +95,10 @@ static kernel_fn fast_kernel(int sdt, int wdt, int D, int scan, int hist, int* v
   const int ssz = dtype_size(sdt), wsz = wdt < 0 ? 0 : dtype_size(wdt);
   *vec = 16 / std::max(ssz, wsz);
   switch (sdt) {
-    case XHIST_F64: return xhist_pick_f64(wdt, D, scan, hist);  // (instantiated in xhist_pick_f64.hip / _f32.hip)
-    case XHIST_F32: return xhist_pick_f32(wdt, D, scan, hist);
+    // (the kernels of a typical first call come from the small hot unit, xhist_hot.hip; the rest are instantiated in
+    //  xhist_pick_f64.hip / _f32.hip, whose code objects are loaded when one of them is first needed)
+    case XHIST_F64: if (kernel_fn h = xhist_pick_hot(sdt, wdt, D, scan, hist)) return h; return xhist_pick_f64(wdt, D, scan, hist);
+    case XHIST_F32: if (kernel_fn h = xhist_pick_hot(sdt, wdt, D, scan, hist)) return h; return xhist_pick_f32(wdt, D, scan, hist);
     case XHIST_I32: return small_pick<int32_t>(wdt, D, scan, hist);
     case XHIST_I64: return small_pick<int64_t>(wdt, D, scan, hist);
     case XHIST_I16: return small_pick<int16_t>(wdt, D, scan, hist);
