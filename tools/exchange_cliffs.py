@@ -1,6 +1,6 @@
 """Where the DEFAULT rule of the exchange mode loses against the classic passes (development tool): a matrix of histogram shapes
 (1-3 inputs) and sample distributions, 3*10^8 float64 samples + float64 weights each; prints default / classic per case and
-flags what is more than 3 % slower.    python tools/exchange_cliffs.py [samples]"""
+flags what is more than 3 % slower.    python tools/exchange_cliffs.py [samples] [only this shape, e.g. 1000000 or 512x2048]"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ import torch
 from xhistogram_amd import _native, core
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000_000
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # e.g. "1000000" or "1024x1024": only that shape (a flagged cell looked at again)
 _native.require_device(0)
 g = torch.Generator(device="cuda"); g.manual_seed(8)
 xs = [torch.empty((1, n), dtype=torch.float64, device="cuda") for _ in range(3)]
@@ -53,6 +54,8 @@ bad = 0
 for kind in ("normal", "normal_off", "uniform", "bimodal", "exp", "narrow"):
     fill(kind)
     for nbs in shapes:
+        if only and "x".join(str(b) for b in nbs) != only:
+            continue
         edges = [np.linspace(-4.0, 4.0, nb + 1) for nb in nbs]
         plan = core._get_plan(edges, _native.CMP_F64, 0)
         plan.set_param("partition", 1)
