@@ -436,6 +436,23 @@ def test_dispatch_surface_odds_and_ends(xh):
         assert_hist_equal(got.cpu().numpy(), onp.bincount_rows([col.cpu().numpy()], [e], None), False)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_padded_layout_at_the_lds_capacity_border(xh, weighted):
+    """one float32 input on np.linspace edges takes the float32 arithmetic digitize with a PADDED LDS layout (32 slots in
+    front, 32 behind).  Within 64 bins of the LDS capacity the padded histogram does not fit while the unpadded one would: the
+    picker must not hand the padded kernel an unpadded allocation there (it now keeps the digitize it had).  Bin counts on both
+    sides of both borders, against the oracle."""
+    rng = np.random.default_rng(13)
+    cap = (160 * 1024) // (8 if weighted else 4)
+    x = rng.uniform(-4.2, 4.2, (1, 300_007)).astype(F32)
+    x[0, ::211] = np.nan
+    w = rng.uniform(0.5, 1.5, x.shape).astype(F32) if weighted else None
+    for nb in (cap - 80, cap - 64, cap - 50, cap - 33, cap - 32, cap - 20, cap - 1):
+        e = np.linspace(-4.0, 4.0, nb + 1)
+        for params in ({}, {"arith32": 1}):
+            _run_general(xh, [x], [e], w, params, weighted)
+
+
 def test_dispatch_surface_one_long_float64_row(xh):
     """one float64 row of >= 2^29 samples without weights takes tiles twice as long (the headline's 8 B/sample variant; one or two
     edges per bucket).  Too long for the oracle in a test: the whole row must equal the sum of its two halves — which are short
