@@ -11,14 +11,12 @@ searchsorted + ravel_multi_index + bincount (/root/reference/xhistogram/core.py:
 edges, outside the range and on NaN; the column count leaves a ragged last tile.
 
 With XHIST_AMD_KERNEL_LOG set (tests/conftest.py sets it for `-m gpu` runs) the library logs the symbol of every kernel it
-picks; `test_zz_every_dispatchable_kernel_was_compared` (last test of the last-sorted GPU module) then holds the log against
-the host stubs of the shared object: an instantiation that nothing selected fails the run — it has to be given a case here or
-leave the library.
+picks; tests/test_zz_gpu_census_total.py (the last-sorted module) then holds the session's log against the host stubs of the
+shared object: an instantiation that nothing selected fails the run — it has to be given a case here or leave the library.
+The product of the float families (`_cases`, ~9 200 cases) is run in full only in discovery mode; the suite runs the set cover of
+it that tests/golden/census_cases.json names (tools/census_cover.py), plus the special families below, which are always complete.
 """
-import itertools
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -183,6 +181,19 @@ def _cases(st, wt, D):
                 yield dict(home=home, kind=kind, nbs=nbs, shape=h["shape"], params=dict(h["params"], **form), lead=bool(h.get("lead")))
 
 
+_KNOBS = ("block_threads", "grid_blocks", "force_global", "force_generic", "fused", "records48", "exchange", "route_spl", "flat_rows",
+          "min_parts", "route_pool_pct", "partition", "lanes", "slices", "route_grid", "acc_grid", "pack", "arith", "arith32", "lds_copies",
+          "exchange_budget_ms", "exchange_arrive_us", "exchange_min_pct")
+
+
+def _fresh(plan):
+    """every tuning key back to its default: plans are cached by their edges, and np.linspace / geometric edges are shared with
+    other tests of the session — what a case selects must not depend on what ran before it"""
+    for k in _KNOBS:
+        plan.set_param(k, 0)
+    return plan
+
+
 def _dev_lead(a):
     """[rows, cols] on the GPU with the ROWS as the contiguous direction (strides (1, rows)): what a reduction over a leading
     axis of a C-ordered array hands to the hot path"""
@@ -206,7 +217,7 @@ def _run_case(core, st, wt, D, case, seed):
     wd = None if w is None else put(w)
     dts = [core._np_dtype_of(s) for s in xd]
     cmp_domain, conv, _ = core._compare_domain(dts, edges)
-    plan = core._get_plan(conv, cmp_domain, 0)
+    plan = _fresh(core._get_plan(conv, cmp_domain, 0))
     for k, v in case["params"].items():
         plan.set_param(k, v)
     try:
@@ -286,7 +297,7 @@ def _run_general(core, samples, edges, w, params, weighted, lead=False):
     wd = None if w is None else put(w)
     dts = [core._np_dtype_of(t) for t in xd]
     cmp_domain, conv, _ = core._compare_domain(dts, edges)
-    plan = core._get_plan(conv, cmp_domain, 0)
+    plan = _fresh(core._get_plan(conv, cmp_domain, 0))
     for k, v in params.items():
         plan.set_param(k, v)
     try:
