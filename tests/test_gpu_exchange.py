@@ -407,3 +407,76 @@ def test_exchange_mode_is_admitted_again_after_an_abort_in_flight(xh):
         plan.set_param("exchange", 0)
         plan.set_param("partition", 0)
     assert seen[:16] == [True] * 16 and seen[16:] == [False, False], seen
+
+
+# ---- exact records through the rings (round 6): the reference's float64 adds of unrounded weights, any sign mixture ------------
+def _exchange_exact(xh, samples, edges, w, **more):
+    got, desc = _run(xh, samples, edges, w, True, partition=1, exchange=1, records48=-1, **more)
+    assert "exchange=forced" in desc and "exchange_records=exact12" in desc, desc
+    return got, desc
+
+
+@pytest.mark.parametrize("n", [4, 4095, 4097, 1_000_003, 3_000_001])
+@pytest.mark.parametrize("signs", ["one", "both"])
+def test_exchange_mode_exact_records_c5_shape(xh, n, signs):
+    """"records48" = -1: the weight travels whole (the packed word + its 16 low bits in a second ring, each with the lap tag) —
+    weights of one sign and of both, at sizes around the tile; the result is the classic exact passes' to the last bits of a
+    float64 sum taken in another order, and the oracle's within the contract"""
+    edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+    rng = np.random.default_rng(600 + n % 89)
+    x, y = rng.standard_normal((1, n)), rng.standard_normal((1, n))
+    w = rng.uniform(0, 1, (1, n)) if signs == "one" else rng.standard_normal((1, n))
+    want = onp.bincount_rows([x, y], edges, w)
+    got, _ = _exchange_exact(xh, [x, y], edges, w)
+    classic, desc = _run(xh, [x, y], edges, w, True, partition=1, exchange=-1, records48=-1)
+    assert "exchange=no" in desc, desc
+    np.testing.assert_allclose(got, classic, rtol=1e-12, atol=1e-12 * np.abs(w).max())
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9 * np.abs(w).max())
+
+
+def test_exchange_mode_exact_records_keep_every_bit_of_a_weight(xh):
+    """every sample in a bin of its own column, weights whose 16 low mantissa bits are all set / alternate / are the only bits
+    that differ: a sum of ONE weight per bin must come back bit for bit (a packed record would round it); NaN, infinities and
+    subnormal weights included"""
+    nb = 1024
+    edges = [np.linspace(0, nb, nb + 1), np.linspace(0, nb, nb + 1)]
+    rng = np.random.default_rng(61)
+    n = 200_000
+    cells = rng.choice(nb * nb, n, replace=False)
+    x = (cells // nb + 0.5)[None, :].astype(np.float64)
+    y = (cells % nb + 0.5)[None, :].astype(np.float64)
+    bits = rng.integers(0, 1 << 62, n, dtype=np.int64) | 0xFFFF
+    bits[::3] ^= 0xAAAA
+    w = bits.view(np.float64).copy()
+    w[::1009] = np.nan
+    w[5::2003] = np.inf
+    w[7::3001] = -np.inf
+    w[11::4001] = 5e-324
+    w = w[None, :]
+    got, _ = _exchange_exact(xh, [x, y], edges, w)
+    want = np.zeros(nb * nb)
+    want[cells] = w[0]
+    np.testing.assert_array_equal(got.reshape(-1).view(np.int64)[~np.isnan(want)], want.view(np.int64)[~np.isnan(want)])
+    assert np.array_equal(np.isnan(got.reshape(-1)), np.isnan(want))
+
+
+@pytest.mark.parametrize("case", ["1d", "3d", "one_owner", "outside"])
+def test_exchange_mode_exact_records_other_shapes(xh, case):
+    rng = np.random.default_rng(62)
+    n = 1_200_007
+    if case == "1d":
+        edges = [np.linspace(-5, 5, 300_001)]
+        samples = [rng.standard_normal((1, n)) * 1.5]
+    elif case == "3d":
+        edges = [np.linspace(-3, 3, 65), np.linspace(-3, 3, 49), np.linspace(0, 1, 401)]
+        samples = [rng.standard_normal((1, n)), rng.standard_normal((1, n)), rng.uniform(-0.05, 1.05, (1, n))]
+    elif case == "one_owner":  # every tile sends 4096 records to one ring of 512: out in pieces
+        edges = [np.linspace(-4, 4, 1025), np.linspace(-4, 4, 1025)]
+        samples = [np.full((1, n), 0.00123), rng.standard_normal((1, n))]
+    else:  # uniform samples over twice the window: half of them beside it
+        edges = [np.linspace(0, 1, 1025), np.linspace(0, 1, 1025)]
+        samples = [rng.uniform(0, 1, (1, n)), rng.uniform(0, 1, (1, n))]
+    w = rng.standard_normal((1, n))
+    want = onp.bincount_rows(samples, edges, w)
+    got, _ = _exchange_exact(xh, samples, edges, w)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9 * np.abs(w).max())

@@ -2,7 +2,7 @@
 passes of the same library, both on the GPU (development tool; the classic passes are held to the oracle by the test-suite and
 by tools/soak.py).  Random shapes: 1-3 inputs, bins per input, np.linspace ranges, sample distributions (normal, uniform, a
 constant, heavy NaN / infinity mixes, samples ON edges), weights of one sign (either), both signs now and then (the exact
-fallback), sizes around the 4096-sample tile and up to a few million.
+fallback), every third case with exact float64 records through the rings, sizes around the 4096-sample tile and up to a few million.
 
     python tools/soak_exchange.py [seconds] [seed] [one big case every N]
 """
@@ -71,15 +71,17 @@ def one(seed):
     wd = torch.as_tensor(np.ascontiguousarray(w)).cuda()
     plan = core._get_plan(edges, _native.CMP_F64, 0)
     out = {}
+    exact = seed % 3 == 0  # every third case with exact float64 records (12 bytes through two rings) against the classic exact passes
     for mode in (-1, 1):
         plan.set_param("partition", 1)
-        plan.set_param("records48", 0)
+        plan.set_param("records48", -1 if exact else 0)
         plan.set_param("exchange", mode)
         try:
             out[mode] = core._bincount_2d_vectorized(*dev, bins=edges, weights=wd).cpu().numpy()
             desc = plan.describe()
         finally:
             plan.set_param("exchange", 0)
+            plan.set_param("records48", 0)
             plan.set_param("partition", 0)
         if mode == 1 and "hist=partitioned" in desc and "exchange=forced" not in desc:
             return ("skipped", desc[-80:])

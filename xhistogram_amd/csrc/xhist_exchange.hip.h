@@ -52,6 +52,7 @@ constexpr int kExchXcds = 8, kExchRings = 32;            // XCDs of the chip; wo
 constexpr int kExchCapLog2 = 9, kExchCap = 1 << kExchCapLog2;  // records per ring (256: producers wait for credits half the time, 4.04 against 3.3 ms)
 constexpr int kExchTake = 4;                             // ring records a lane looks at per tile (6: 3.34 against 3.15 ms — what it finds not yet written is traffic too)
 constexpr int kExchMaxLocal = 15360;                     // bins a workgroup keeps: 120 KB of float64 next to the tile's 36 KB
+constexpr int kExchMaxLocalExact = 14336;                // ... with EXACT records, whose tile takes 44 KB (the 16 low weight bits beside the packed word)
 constexpr int kExchCtlBytes = 2048;
 constexpr uint32_t kExchUnitRows = 32;                   // the probe counts rows in units of 32; a window starts on a unit
 constexpr int kExchMinPpm = 880000;                      // window coverage from which the mode takes a call (exchange_pick; where 88 % comes from: DESIGN 4.2b)
@@ -90,6 +91,7 @@ struct ExchArgs {
   ExchDim dim[3];
   ExchCtl* ctl;              // [kExchXcds], zeroed per call
   uint64_t* rings;           // [xcd][owner][producer][kExchCap], zeroed per call (tag 0 = never written)
+  uint32_t* rings_lo;        // EXACT records only: a second ring of the same shape, {the 16 weight bits the packed word drops | lap tag << 16}
   double* part;              // [xcd][owner][local_bins]: the XCD partials of the window
   double* side;              // [n_bins], zeroed per call: samples outside the window
   uint32_t* win;             // device words: [0] first row of the window, [1] mode on, [2] coverage in ppm (exchange_pick writes them)
@@ -110,8 +112,8 @@ struct ExchArgs {
   long long arrive_ticks;    // how long a workgroup waits for the other 255 to start before it hands the call to the classic passes
 };
 
-__host__ __device__ constexpr size_t exchange_lds(int local_bins) {
-  return (((size_t)local_bins * 8 + 15) & ~(size_t)15) + (size_t)kExchTile * 8 + kExchTile + kExchCtlBytes;
+__host__ __device__ constexpr size_t exchange_lds(int local_bins, bool exact = false) {
+  return (((size_t)local_bins * 8 + 15) & ~(size_t)15) + (size_t)kExchTile * (exact ? 10 : 8) + kExchTile + kExchCtlBytes;
 }
 
 __device__ __forceinline__ uint32_t exch_xcc_id() {
@@ -304,7 +306,11 @@ __global__ void __launch_bounds__(64) exchange_pick(const ExchArgs xa) {
   xa.cold->part = xa.part;
 }
 
-template <int D>
+// EXACT (round 6): the weight travels whole — the packed word carries its upper 48 bits (truncated, not rounded), a second ring of
+// 4-byte words {the 16 bits below | the same lap tag} the rest; a record is valid when BOTH words carry the lap's tag (each is
+// written and read as one aligned word).  The reference's arithmetic (float64 adds of unrounded weights, core.py:81), weights of
+// any sign mixture, 12 bytes per record through the rings instead of 8; the tile's staging takes 8 KB more LDS, the window one row less.
+template <int D, bool EXACT = false>
 __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   constexpr int BLOCK = kExchBlock, TILE = kExchTile, NS = kExchRings, CAP = kExchCap, CAPL = kExchCapLog2, CL = kExchTake;
   typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));  // (a view like x[1:] is 8-byte aligned only; the loads stay 16-byte ones)
@@ -313,7 +319,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   const size_t hist_bytes = ((size_t)xa.local_bins * 8 + 15) & ~(size_t)15;
   double* hist = reinterpret_cast<double*>(xhist_smem);
   uint64_t* srec = reinterpret_cast<uint64_t*>(xhist_smem + hist_bytes);   // [TILE] the tile's ring records, by owner
-  uint8_t* sd = xhist_smem + hist_bytes + (size_t)TILE * 8;                 // [TILE] owner of every staged record
+  uint16_t* slo = reinterpret_cast<uint16_t*>(xhist_smem + hist_bytes + (size_t)TILE * 8);  // [TILE] EXACT: the 16 low weight bits of every staged record
+  uint8_t* sd = xhist_smem + hist_bytes + (size_t)TILE * (EXACT ? 10 : 8);  // [TILE] owner of every staged record
   uint32_t* c = reinterpret_cast<uint32_t*>(sd + TILE);
   uint32_t* cnt2 = c;          // [2][64] records per owner of the tile, alternating per tile
   uint32_t* off = c + 128;     // [64] first staged slot of every owner; [32] = records staged
@@ -377,6 +384,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   ExchCtl& C = xa.ctl[xcd];
   uint64_t* xring = xa.rings + (size_t)xcd * NS * NS * CAP;        // [owner][producer][CAP]
   const uint64_t* myring = xring + (size_t)me * NS * CAP;          // the rings that end here
+  uint32_t* xring_lo = EXACT ? xa.rings_lo + (size_t)xcd * NS * NS * CAP : nullptr;
+  const uint32_t* myring_lo = EXACT ? xring_lo + (size_t)me * NS * CAP : nullptr;
   const uint32_t r0 = __builtin_nontemporal_load(xa.win + 0);
   const uint32_t win_rows = (uint32_t)NS * (uint32_t)xa.rows_per;
   const uint32_t L = (uint32_t)xa.row_len;
@@ -421,13 +430,17 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   // ---- the consumer side: 32 lanes per ring, CL records each ---------------------------------------------------
   const uint32_t psub = (uint32_t)tid >> 5, l = (uint32_t)tid & 31u;
   uint64_t rr[CL];
+  uint32_t rb[EXACT ? CL : 1];
   uint32_t rh = 0;
   auto issue_ring_loads = [&]() {
     const uint32_t t = lane_now(), ps = t >> 5, ll = t & 31u;
     rh = chead[ps];
 #pragma unroll
-    for (int j = 0; j < CL; ++j)
-      rr[j] = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + ((ps << CAPL) + ((rh + ll + 32u * j) & (uint32_t)(CAP - 1))) * 8u));
+    for (int j = 0; j < CL; ++j) {
+      const uint32_t slot = (ps << CAPL) + ((rh + ll + 32u * j) & (uint32_t)(CAP - 1));
+      rr[j] = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + slot * 8u));
+      if constexpr (EXACT) rb[j] = exch_ld(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(myring_lo) + slot * 4u));
+    }
   };
   auto take_ring_records = [&]() {  // adds the valid prefix of what was loaded
     const uint32_t tid = lane_now(), psub = tid >> 5, l = tid & 31u;
@@ -437,7 +450,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     for (int j = 0; j < CL; ++j) {
       const uint32_t pos = rh + l + 32u * j;
       const uint32_t expect = ((pos >> CAPL) + 1u) & 3u;
-      const bool valid = (((uint32_t)rr[j] >> 14) & 3u) == expect;
+      bool valid = (((uint32_t)rr[j] >> 14) & 3u) == expect;
+      if constexpr (EXACT) valid &= ((rb[j] >> 16) & 3u) == expect;
       const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
       const uint32_t m = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
       if (cont) {
@@ -449,7 +463,8 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     for (int j = 0; j < CL; ++j)
       if (l + 32u * j < pre) {
         const uint64_t r = rr[j];
-        unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)(r & ~0xffffull)));
+        const uint64_t wbits = EXACT ? ((r & ~0xffffull) | (uint64_t)(rb[j] & 0xffffu)) : (r & ~0xffffull);
+        unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)wbits));
       }
     if (l == 0 && pre) {
       chead[psub] = rh + pre;
@@ -464,12 +479,16 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
 #pragma unroll 1
     for (int j = 0; j < CL; ++j) {
       const uint32_t pos = h + l + 32u * j;
-      const uint64_t r = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + ((psub << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u));
-      const bool valid = (((uint32_t)r >> 14) & 3u) == (((pos >> CAPL) + 1u) & 3u);
+      const uint32_t slot = (psub << CAPL) + (pos & (uint32_t)(CAP - 1));
+      const uint64_t r = exch_ld(reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(myring) + slot * 8u));
+      uint32_t b = 0;
+      if constexpr (EXACT) b = exch_ld(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(myring_lo) + slot * 4u));
+      bool valid = (((uint32_t)r >> 14) & 3u) == (((pos >> CAPL) + 1u) & 3u);
+      if constexpr (EXACT) valid &= ((b >> 16) & 3u) == (((pos >> CAPL) + 1u) & 3u);
       const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
       const uint32_t m = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
       const uint32_t kk = !cont ? 0u : (m == 0xffffffffu ? 32u : (uint32_t)__builtin_ctz(~m));
-      if (l < kk) unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)(r & ~0xffffull)));
+      if (l < kk) unsafeAtomicAdd(hist + ((uint32_t)r & 0x3fffu), __longlong_as_double((long long)(EXACT ? ((r & ~0xffffull) | (uint64_t)(b & 0xffffu)) : (r & ~0xffffull))));
       pre += kk;
       cont = cont && kk == 32u;
     }
@@ -492,6 +511,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
     // output, with the weight as it was read -------------------------------------------------------------------------
     uint32_t dest[4];  // owner (32: outside the window, 33: dropped)
     uint64_t rec[4];
+    uint32_t lo2[EXACT ? 2 : 1];  // EXACT: the 16 low weight bits of the four records, two to a register
     {
       double xs[D][4];
 #pragma unroll
@@ -511,17 +531,28 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
         const uint32_t r = row - r0;
         const bool in_win = ins[s4] & (r < win_rows);
         const double wq = wv[s4 >> 1][s4 & 1];
-        bool special;
-        rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
-        special_any |= special;
+        if constexpr (EXACT) {  // the weight's bits as they are: 48 with the code, 16 beside it — nothing rounded, no sign to watch
+          const uint64_t b = (uint64_t)__double_as_longlong(wq);
+          rec[s4] = (b & ~0xffffull) | ((r >> 5) * L + col);
+          const uint32_t low = (uint32_t)b & 0xffffu;
+          lo2[s4 >> 1] = (s4 & 1) ? (lo2[s4 >> 1] | (low << 16)) : low;
+        } else {
+          bool special;
+          rec[s4] = exch_pack_fast(wq, (r >> 5) * L + col, special);  // (the code of a record that does not travel is never looked at)
+          special_any |= special;
+        }
         dest[s4] = in_win ? exch_owner(r) : (ins[s4] ? 32u : 33u);
         if (ins[s4] & !in_win) unsafeAtomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(side) + exch_side_index(row, col, L, rot_mask) * 8u), wq);
-        s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
-        s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
+        if constexpr (!EXACT) {
+          s_neg |= __builtin_amdgcn_ballot_w64(wq < 0.0);
+          s_pos |= __builtin_amdgcn_ballot_w64(wq > 0.0);
+        }
       }
-      if (__builtin_amdgcn_ballot_w64(special_any) != 0ull) {  // NaN / infinite / top-binade weights: the careful rounding
+      if constexpr (!EXACT) {
+        if (__builtin_amdgcn_ballot_w64(special_any) != 0ull) {  // NaN / infinite / top-binade weights: the careful rounding
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) rec[s4] = (uint64_t)__double_as_longlong(pack48(wv[s4 >> 1][s4 & 1], (uint32_t)rec[s4] & 0x3fffu));
+          for (int s4 = 0; s4 < 4; ++s4) rec[s4] = (uint64_t)__double_as_longlong(pack48(wv[s4 >> 1][s4 & 1], (uint32_t)rec[s4] & 0x3fffu));
+        }
       }
     }
     // ---- ring loads first (older), then the next tile's samples (newer): waiting for the former leaves the latter in flight
@@ -558,6 +589,7 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
       if (dest[s4] < 32u) {
         const uint32_t i = off[dest[s4]] + rank[s4];
         srec[i] = rec[s4];
+        if constexpr (EXACT) slo[i] = (uint16_t)(lo2[s4 >> 1] >> ((s4 & 1) * 16));
         sd[i] = (uint8_t)dest[s4];
       }
     __syncthreads();
@@ -572,8 +604,9 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
           const uint32_t d = sd[i];
           const uint32_t pos = wadj[d] + i;
           const uint32_t tag = ((pos >> CAPL) + 1u) & 3u;
-          *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u) =
-              (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
+          const uint32_t slot = (((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1));
+          *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + slot * 8u) = (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
+          if constexpr (EXACT) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(xring_lo) + slot * 4u) = (uint32_t)slo[i] | (tag << 16);
         }
       }
     } else {
@@ -587,8 +620,9 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
             if (j >= sent[d] && j < lim[d]) {
               const uint32_t pos = wadj[d] + i;
               const uint32_t tag = ((pos >> CAPL) + 1u) & 3u;
-              *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + ((((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1))) * 8u) =
-                  (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
+              const uint32_t slot = (((d << 5) + me) << CAPL) + (pos & (uint32_t)(CAP - 1));
+              *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(xring) + slot * 8u) = (srec[i] & ~0xc000ull) | ((uint64_t)tag << 14);
+              if constexpr (EXACT) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(xring_lo) + slot * 4u) = (uint32_t)slo[i] | (tag << 16);
             }
           }
         }
@@ -643,8 +677,10 @@ __global__ void __launch_bounds__(kExchBlock) part_exchange(const ExchArgs xa) {
   __syncthreads();
   double* po = cold->part + ((size_t)xcd * NS + me) * (size_t)xa.local_bins;
   for (int i = tid; i < xa.local_bins; i += BLOCK) po[i] = hist[i];
-  const uint32_t signs = (s_neg ? 1u : 0u) | (s_pos ? 2u : 0u);
-  if ((tid & 63) == 0 && signs) atomicOr(cold->flags, signs);
+  if constexpr (!EXACT) {  // (exact records: whatever the signs, this call's result stands)
+    const uint32_t signs = (s_neg ? 1u : 0u) | (s_pos ? 2u : 0u);
+    if ((tid & 63) == 0 && signs) atomicOr(cold->flags, signs);
+  }
 }
 
 // out += side + (inside the window) the eight XCD partials.  Runs when the mode was on and the weights had one sign;

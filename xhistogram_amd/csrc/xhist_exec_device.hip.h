@@ -293,12 +293,19 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   if (pack && (!p->mixed_hint || *p->mixed_hint != 0u)) pack = false;  // (earlier calls met both signs: straight to exact records)
   kernel_fn_route k_route48 = pack ? route_kernel(sdt, kWdtPacked48, D, scan, rows > 1, block, spl) : nullptr;
   if (pack && !k_route48) pack = false;
+  // float64 weights that travel as FULL float64 records ("records48" = -1, XHIST_AMD_EXACT_RECORDS, or a plan that has met weights of
+  // both signs): the exchange mode takes these too, with 12-byte records through two rings (part_exchange<D, true>, round 6)
+  // (by default for joint histograms only: measured over the shape matrix of tools/exchange_cliffs.py with exact records,
+  //  3*10^8 samples, 2-3 inputs read 0.93-1.03 of the classic exact passes — whose own time moves by 10 % from process to process
+  //  and size to size with the placement of their five streams, while this form does not: C5 4.14-4.18 ms in every process against
+  //  4.09 | 4.50-4.53 — and ONE input reads 1.08-1.11: profiles/r06_e_*)
+  const bool xexact = weighted && wdt == XHIST_F64 && !pack && rows == 1 && (D >= 2 || p->exchange_pref > 0);
   // an exchange kernel of ANOTHER stream may still hold the GPU: looked at before the scratch allocations below, and the lock is
   // kept until this call's own exchange kernel has been launched and its event recorded (two host threads that both saw "idle"
   // would otherwise both launch one)
   bool other_stream_busy = false;
   std::unique_lock<std::mutex> xfl_lock;
-  if (pack && p->exchange_pref >= 0) {
+  if ((pack || xexact) && p->exchange_pref >= 0) {
     ExchInFlight& fl = exch_in_flight(p->device);
     xfl_lock = std::unique_lock<std::mutex>(fl.mu);
     if (fl.armed && fl.stream != stream && hipEventQuery(fl.ev) == hipErrorNotReady) other_stream_busy = true;
@@ -386,15 +393,16 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
   bool xch = false, xch_probe = false;
   kernel_fn_exch k_xch = nullptr, k_xprobe = nullptr;
   size_t lds_xch = 0;
-  if (pack && rows == 1 && p->exchange_pref >= 0 && (p->exchange_skip == 0 || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
+  if ((pack || xexact) && rows == 1 && p->exchange_pref >= 0 && (p->exchange_skip == 0 || p->exchange_pref > 0) && sdt == XHIST_F64 && p->arith && p->arith_pref >= 0 && D <= 3 && p->cus == kExchXcds * kExchRings &&
       p->n_bins <= ((int64_t)1 << 23) /* (the side copy is zeroed per call) */ && (p->exchange_pref > 0 || n_cols >= ((int64_t)1 << 25))) {
     const int64_t L = D >= 2 ? (int64_t)p->ts[0][0].dim[D - 1].nb : 256;
     const int64_t hist_rows = D >= 2 ? p->n_bins / L : (p->n_bins + 255) / 256;
     const int64_t units = (hist_rows + kExchUnitRows - 1) / kExchUnitRows;
-    const int64_t rows_per = L <= kExchMaxLocal ? std::min<int64_t>(kExchMaxLocal / L, units) : 0;
-    k_xch = xhist_pick_exchange(D);
+    const int64_t max_local = xexact ? kExchMaxLocalExact : kExchMaxLocal;
+    const int64_t rows_per = L <= max_local ? std::min<int64_t>(max_local / L, units) : 0;
+    k_xch = xhist_pick_exchange(D, xexact);
     k_xprobe = xhist_pick_exchange_probe(D);
-    lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L)) : 0;
+    lds_xch = rows_per >= 1 ? exchange_lds((int)(rows_per * L), xexact) : 0;
     if (rows_per >= 1 && units <= 4096 && k_xch && k_xprobe && lds_xch <= p->lds_max && !other_stream_busy) {
       xch = true;
       xch_probe = true;  // (always: a histogram that fits the window has nothing outside it, but its owners' loads must be even too)
@@ -412,7 +420,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       const size_t words_bytes = ((size_t)(units + kExchRings + 8 + 32) * 4 + 7) & ~(size_t)7;  // win[8], the cold arguments (32 words), the probe's counts (units, then owners)
       // one block for everything that is zeroed per call (one launch): control words | window, cold arguments, probe counts | side copy | rings
       const size_t ctl_bytes = sizeof(ExchCtl) * kExchXcds, side_bytes = (size_t)(hist_rows * L) * 8;  // (whole rows: exch_side_index rotates inside a row)
-      const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * 8;
+      const size_t rings_bytes = (size_t)kExchXcds * kExchRings * kExchRings * kExchCap * (xexact ? 12 : 8);  // (exact records: the ring of low bits behind the ring of packed words)
       static_assert(sizeof(ExchCtl) % 8 == 0, "the block's parts stay 8-byte aligned");
       x_zero_words = (int64_t)((ctl_bytes + words_bytes + side_bytes + rings_bytes) / 8);
       HIPR(scratch_malloc(&x_ctl, ctl_bytes + words_bytes + side_bytes + rings_bytes, stream));
@@ -421,6 +429,7 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
       xa.win = reinterpret_cast<uint32_t*>(static_cast<char*>(x_ctl) + ctl_bytes);
       xa.side = reinterpret_cast<double*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes);
       xa.rings = reinterpret_cast<uint64_t*>(static_cast<char*>(x_ctl) + ctl_bytes + words_bytes + side_bytes);
+      xa.rings_lo = xexact ? reinterpret_cast<uint32_t*>(xa.rings + (size_t)kExchXcds * kExchRings * kExchRings * kExchCap) : nullptr;
       xa.part = static_cast<double*>(x_part);
       xa.cold = reinterpret_cast<ExchCold*>(xa.win + 8);
       static_assert(sizeof(ExchCold) <= 32 * 4, "the cold arguments fit their 32 words");
@@ -567,15 +576,16 @@ static int execute_partitioned_fused(xhist_plan* p, const xhist_array* samples, 
     }
   }
   {
-    char desc[704];
+    char desc[768];
     snprintf(desc, sizeof desc,
              "family=fast hist=partitioned route=fused rows_per_pass=%d parts=%d bins_per_part=%d group=%d chunk=%d chunks<=%lld tile=%d block=%d grid=%d "
-             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u exchange_busiest_owner_ppm_before=%u exchange_arrival_misses=%u",
+             "acc_grid=%d lds_route=%zu lds_acc=%zu scan=%d weighted=%d D=%d cmp=%s records=%s exchange=%s exchange_window_ppm_before=%u exchange_aborts=%u exchange_busiest_owner_ppm_before=%u exchange_arrival_misses=%u exchange_records=%s",
              rows, n_parts, 1 << shift, kRouteGrp, 1 << lg, (long long)pool_chunks, tile, block, G, Gb, lds_route, lds_acc, scan,
              (int)weighted, D, use_f32 ? "f32thr" : "f64",
              !weighted ? "u16" : pack ? "packed48(+exact if both signs)" : wdt == XHIST_F32 ? "u16+f32" : "u16+f64",
              !xch ? "no" : xa.force ? "forced" : xa.n_units > xa.rows_per ? "if the probe's window holds enough of the samples" : "whole histogram in the window",
-             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u, p->mixed_hint ? p->mixed_hint[4] : 0u, p->mixed_hint ? p->mixed_hint[5] : 0u);  // (what the GPU has reported so far: the calls before this one)
+             p->mixed_hint ? p->mixed_hint[3] : 0u, p->mixed_hint ? p->mixed_hint[2] : 0u, p->mixed_hint ? p->mixed_hint[4] : 0u, p->mixed_hint ? p->mixed_hint[5] : 0u,  // (what the GPU has reported so far: the calls before this one)
+             !xch ? "-" : xexact ? "exact12(two_rings)" : "packed8");
     if (last)
       if (int rrc = rec.end(desc)) return release(rrc);
   }

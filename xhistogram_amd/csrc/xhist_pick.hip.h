@@ -366,7 +366,7 @@ XH_ROUTE_TU(f32, 1024) XH_ROUTE_TU(f32, 1024s8)
 // the exchange mode of the partitioned path (xhist_exchange.hip.h; translation unit xhist_exchange.hip): float64 samples,
 // float64 weights as packed records, arithmetic edges, 1-3 inputs
 typedef void (*kernel_fn_exch)(const ExchArgs);
-kernel_fn_exch xhist_pick_exchange(int D);
+kernel_fn_exch xhist_pick_exchange(int D, bool exact);  // exact: full float64 records (12 bytes through two rings)
 kernel_fn_exch xhist_pick_exchange_probe(int D);
 typedef void (*kernel_fn_exch_pick)(const ExchArgs);
 typedef void (*kernel_fn_exch_merge)(const ExchArgs, double*, int64_t);
