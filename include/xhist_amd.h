@@ -217,7 +217,9 @@ int xhist_pointer_device(const void* ptr, int* device);
  *       "fused" (0 auto / 1 always / -1 never: that mode in one routing pass instead of count + prefix + scatter),
  *       "records48" (0 auto / -1 never: that pass moves float64 weights as 8-byte records — 36 mantissa bits next to the bin code,
  *       2^-37 relative per weight — while a call's weights have one sign, decided on the GPU; both signs fall back to full
- *       float64 records in the same call; XHIST_AMD_EXACT_RECORDS=1 is the process-wide "never"),
+ *       float64 records in the same call; XHIST_AMD_EXACT_RECORDS=1 is the process-wide "never"; full float64 records of a joint
+ *       histogram travel through the rings of the "exchange" mode too, as 12-byte records in two tagged words — the weight bit
+ *       for bit, any sign mixture),
  *       "exchange" (0 auto / 1 whenever the kernel can run / -1 never: such packed records never written to HBM — one persistent
  *       workgroup per compute unit keeps rows of a window of the histogram in LDS and records travel through rings inside each
  *       XCD; auto = float64 samples + float64 weights on numpy.linspace-style edges, one row of >= 2^25 samples, a chip of
