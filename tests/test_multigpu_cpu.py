@@ -285,6 +285,13 @@ def test_bench_multi_rank_control_flow_selftest(scaling):
     for key in ("value", "ms_per_step", "kernel_ms_mean", "overhead_us_per_step"):
         assert u[key] is not None
     assert "overhead_us_per_step" in d[other]
+    # who ran it, gathered over the process group itself (VERDICT r5 "next" #4): two ranks, two distinct entries
+    rk = d["ranks"]
+    assert rk["backend"] == "gloo" and rk["world_size_seen"] == 2 and rk["distinct_devices"] == 2
+    assert sorted(e["rank"] for e in rk["devices"]) == [0, 1] and len({e["pid"] for e in rk["devices"]}) == 2
+    # the LAST key of the line is the summary (an 8 KB tail of the driver's record still holds it)
+    assert list(d.keys())[-1] == "summary" and d["summary"]["n_gpus"] == 2 and d["summary"]["distinct_devices"] == 2
+    assert lines[0].rstrip().endswith("}}") and '"summary"' in lines[0][-600:]
 
 
 def test_blocks_in_flight_per_gpu_are_bounded():
